@@ -1,0 +1,123 @@
+"""Seeded synthetic inputs shared by the golden-vector generator and the parity tests.
+
+Inputs are REGENERATED from ``np.random.RandomState(seed)`` (legacy MT19937: stable across
+NumPy versions and machines) wherever they are needed; only expected OUTPUTS are stored in
+``tests/golden/*.npz``.  This module is build-side test tooling and does not touch the
+reference.
+"""
+import numpy as np
+
+GAE_CASES = {
+    # name: (T, N or None for the unbatched (T,) case, gamma, lambda, p_reset, reward dtype)
+    "c2": (128, 256, 0.99, 0.95, 0.01, np.float32),
+    "c3": (64, 2048, 0.99, 0.95, 0.001, np.float32),
+    "c5": (5, 4096, 0.99, 1.0, 0.01, np.float32),
+    "c1": (128, 8, 0.99, 0.95, 0.05, np.float64),
+    "ragged": (37, 19, 0.9, 0.8, 0.2, np.float64),
+    "single_step": (1, 7, 0.99, 0.95, 0.5, np.float32),
+    "unbatched": (2048, None, 0.99, 0.95, 0.01, np.float64),
+}
+
+
+def gae_inputs(name):
+  """rewards in {-1,0,1}, Bernoulli resets, N(0,1) values / last_values."""
+  T, N, gamma, lam, p_reset, rdtype = GAE_CASES[name]
+  rs = np.random.RandomState(sum(map(ord, name)))
+  shape = (T,) if N is None else (T, N)
+  rewards = (np.sign(rs.standard_normal(shape)) * (rs.uniform(size=shape) < 0.3)).astype(rdtype)
+  resets = rs.uniform(size=shape) < p_reset
+  values = rs.standard_normal(shape + (1,)).astype(np.float32)
+  last_values = rs.standard_normal(shape[1:] + (1,)).astype(np.float32)
+  return dict(rewards=rewards, resets=resets, values=values, last_values=last_values,
+              gamma=gamma, lambda_=lam)
+
+
+def nature_cnn_weights(num_actions, seed, with_value=True):
+  """state_dict-shaped float32 arrays: N(0, 1/fan_in) weights, N(0, 0.05) biases."""
+  rs = np.random.RandomState(seed)
+  shapes = [("base.conv-0", (32, 4, 8, 8)), ("base.conv-1", (64, 32, 4, 4)),
+            ("base.conv-2", (64, 64, 3, 3)), ("base.linear", (512, 3136)),
+            ("output_layers.0", (num_actions, 512))]
+  if with_value:
+    shapes.append(("output_layers.1", (1, 512)))
+  out = {}
+  for name, shape in shapes:
+    fan_in = int(np.prod(shape[1:]))
+    gain = 1.4 if name.startswith("base") else 1.0
+    out[f"{name}.weight"] = (rs.standard_normal(shape) * gain / np.sqrt(fan_in)).astype(np.float32)
+    out[f"{name}.bias"] = (rs.standard_normal(shape[0]) * 0.05).astype(np.float32)
+  return out
+
+
+def mujoco_weights(obs_dim, act_dim, seed):
+  rs = np.random.RandomState(seed)
+  out = {"logstd": (rs.standard_normal(act_dim) * 0.3).astype(np.float32)}
+  for m, nout in enumerate((act_dim, 1)):
+    dims = (obs_dim, 64, 64, nout)
+    for layer, (nin, no) in enumerate(zip(dims[:-1], dims[1:])):
+      out[f"module_list.{m}.{2 * layer}.weight"] = (
+          rs.standard_normal((no, nin)) / np.sqrt(nin)).astype(np.float32)
+      out[f"module_list.{m}.{2 * layer}.bias"] = (rs.standard_normal(no) * 0.05).astype(np.float32)
+  return out
+
+
+def frames(batch, seed):
+  """uint8 (batch,84,84,4) frames: smooth blobs + noise so ReLUs are not all-on."""
+  rs = np.random.RandomState(seed)
+  base = rs.randint(0, 256, size=(batch, 84, 84, 4)).astype(np.int32)
+  mask = rs.uniform(size=(batch, 84, 84, 1)) < 0.35
+  return np.where(mask, base, base // 8).astype(np.uint8)
+
+
+def cnn_minibatch(batch, num_actions, seed):
+  """Minibatch pieces that do not depend on the model."""
+  rs = np.random.RandomState(seed)
+  return dict(observations=frames(batch, seed + 1),
+              actions=rs.randint(0, num_actions, size=batch).astype(np.int64),
+              advantages=(rs.standard_normal(batch) * 2 + 0.3).astype(np.float32),
+              logp_noise=(rs.standard_normal(batch) * 0.15).astype(np.float32),
+              value_noise=(rs.standard_normal((batch, 1)) * 0.3).astype(np.float32),
+              target_noise=(rs.standard_normal((batch, 1))).astype(np.float32))
+
+
+def mlp_minibatch(batch, obs_dim, act_dim, seed):
+  rs = np.random.RandomState(seed)
+  return dict(observations=np.clip(rs.standard_normal((batch, obs_dim)), -10, 10).astype(np.float32),
+              actions=rs.standard_normal((batch, act_dim)).astype(np.float32),
+              advantages=(rs.standard_normal(batch) * 2 + 0.3).astype(np.float32),
+              logp_noise=(rs.standard_normal(batch) * 0.3).astype(np.float32),
+              value_noise=(rs.standard_normal((batch, 1)) * 0.3).astype(np.float32),
+              target_noise=(rs.standard_normal((batch, 1))).astype(np.float32))
+
+
+# (name, kind, batch, A / (obs_dim, act_dim), alg, hyper-parameters)
+STEP_CASES = {
+    "ppo_step_cnn": dict(kind="cnn", batch=48, num_actions=4, alg="ppo", seed=11,
+                         cliprange=0.1, value_loss_coef=0.25, entropy_coef=0.01,
+                         lr=2.5e-4, num_train_steps=10e6, step_count=32768 * 3,
+                         max_grad_norm=0.5, optimizer_epsilon=1e-5, nsteps=3),
+    "ppo_step_mlp": dict(kind="mlp", batch=256, obs_dim=17, act_dim=6, alg="ppo", seed=12,
+                         cliprange=0.2, value_loss_coef=0.25, entropy_coef=0.0,
+                         lr=3e-4, num_train_steps=1e6, step_count=131072,
+                         max_grad_norm=0.5, optimizer_epsilon=1e-5, nsteps=3),
+    "a2c_step_cnn": dict(kind="cnn", batch=40, num_actions=6, alg="a2c", seed=13,
+                         value_loss_coef=0.5, entropy_coef=0.01,
+                         lr=7e-4, num_train_steps=10e6, step_count=20480 * 5,
+                         max_grad_norm=0.5, optimizer_epsilon=1e-5, optimizer_alpha=0.99,
+                         nsteps=3),
+}
+
+# parameters small enough to be stored in full in the CNN step fixtures; the rest are
+# pinned by per-tensor L2 norm, sum and a strided sample
+FULL_TENSOR_LIMIT = 20000
+SAMPLE_STRIDE = 97
+
+
+def summarize_tensor(arr):
+  arr = np.asarray(arr, np.float32)
+  flat = arr.reshape(-1)
+  if flat.size <= FULL_TENSOR_LIMIT:
+    return dict(full=flat.copy())
+  return dict(norm=np.float64(np.sqrt(np.sum(flat.astype(np.float64) ** 2))),
+              sum=np.float64(flat.astype(np.float64).sum()),
+              sample=flat[::SAMPLE_STRIDE].copy())
