@@ -1,0 +1,39 @@
+// Shared host-side helpers for the C-ABI translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/derl_amd.h"
+
+namespace dx {
+
+char *error_buffer();  // thread-local, 512 bytes
+
+inline int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define DX_REQUIRE(cond, ...) \
+  do { if (!(cond)) return ::dx::fail(DX_EINVAL, __VA_ARGS__); } while (0)
+
+#define DX_HIP(expr)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess)                                                         \
+      return ::dx::fail(DX_EHIP, "%s failed: %s (%s:%d)", #expr,                  \
+                        hipGetErrorString(e_), __FILE__, __LINE__);               \
+  } while (0)
+
+// after a kernel launch: catches bad launch configurations without synchronising
+#define DX_LAUNCH_CHECK() DX_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+inline int cdiv(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
+
+}  // namespace dx

@@ -1,0 +1,58 @@
+"""CPU-only checks of the C-ABI boundary: the library loads, exports every symbol that
+include/derl_amd.h declares, the ctypes table matches the header, and host-side argument
+validation fails with an error string (no compute calls: there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+  text = open(os.path.join(ROOT, "include", "derl_amd.h")).read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return sorted(set(re.findall(r"\b(dx_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+  import __graft_entry__
+  from derl_amd import build
+  if not os.path.exists(build.LIB):
+    __graft_entry__.build()
+  from derl_amd import _lib
+  return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+  handle = lib.load()
+  names = header_functions()
+  assert len(names) >= 4
+  for name in names:
+    assert hasattr(handle, name), f"{name} declared in include/derl_amd.h but not exported"
+  assert sorted(lib.SIGNATURES) == names, "ctypes table and header disagree"
+  assert handle.dx_abi_version() == lib.ABI_VERSION
+
+
+def test_host_side_validation_reports_errors(lib):
+  handle = lib.load()
+  # negative shape: rejected on the host before any HIP call
+  status = handle.dx_gae_f32(None, None, None, None, -1, 4, 0.99, 0.95, None, None, None)
+  assert status == -1
+  assert "negative shape" in lib.last_error()
+  # null pointers with a non-empty shape
+  status = handle.dx_gae_f32(None, None, None, None, 2, 4, 0.99, 0.95, None, None, None)
+  assert status == -1 and "null pointer" in lib.last_error()
+  with pytest.raises(lib.NativeError):
+    lib.call("dx_gae_f32", None, None, None, None, 2, 4, 0.99, 0.95, None, None, None)
+  # empty problem is a no-op
+  assert handle.dx_gae_f32(None, None, None, None, 0, 4, 0.99, 0.95, None, None, None) == 0
+
+
+def test_ops_refuse_cpu_tensors(lib):
+  import torch
+  from derl_amd import ops
+  z = torch.zeros(2, 3)
+  with pytest.raises(ValueError, match="no CPU path"):
+    ops.gae(z, torch.zeros(2, 3, dtype=torch.bool), z, torch.zeros(3), 0.99, 0.95)
