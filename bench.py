@@ -1,0 +1,223 @@
+"""Headline benchmark: env-steps/sec of PPO on BreakoutNoFrameskip-v4-shaped synthetic frames,
+nenvs=256, nsteps=128 (BASELINE.json configs[1]) on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full PPO iteration: a 128-step rollout of the batched policy over the
+device-resident synthetic env, the GAE scan, and 3 epochs x 4 minibatches of
+forward + fused loss + backward + (all-reduce) + clip + Adam.  Inputs are generated on the
+GPU; nothing of the timed region touches host memory.  Rank 0 prints ONE JSON line.
+
+Scaling is STRONG by default (the metric fixes nenvs=256 in total, sharded nenvs/N per
+rank; BASELINE.json north_star); --weak keeps 256 envs per rank (configs[3]).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STAGES = ["conv0_fwd", "conv1_fwd", "conv2_fwd", "fc_fwd", "heads_fwd", "heads_wgrad",
+          "heads_dgrad", "fc_wgrad", "fc_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad",
+          "conv1_dgrad", "conv0_wgrad", "finalize"]
+# algorithmic multiply-accumulates per sample (dgrad = the transposed
+# convolution's MACs = forward MACs, no padding waste counted)
+MACS = dict(conv0=3_276_800, conv1=2_654_208, conv2=1_806_336, fc=1_605_632)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_HBM_GBPS = 8000.0
+
+
+def stage_flops(name, batch, num_actions):
+  layer = name.split("_")[0]
+  if layer == "heads":
+    return 2.0 * (num_actions + 1) * 512 * batch
+  if layer in MACS:
+    return 2.0 * MACS[layer] * batch
+  return 0.0
+
+
+def time_stages(model, obs, idx, batch, iters=10):
+  """Average duration (us) of every network stage at `batch`, with HIP events on the stream
+  the kernels are launched on (torch's current stream)."""
+  import ctypes
+  from derl_amd import _lib
+  eng = model.engine
+  eng.reserve(batch)
+  eng._ensure_backward()
+  eng.pack()
+  is_u8 = int(obs.dtype == torch.uint8)
+  stream = _lib.stream_ptr(eng.device)
+
+  def launch(stage):
+    _lib.call("dx_cnn_stage", ctypes.byref(eng.ctx), stage, _lib.ptr(obs), is_u8, _lib.ptr(idx),
+              batch, stream)
+
+  for stage in range(len(STAGES)):  # run the whole net once so every buffer is defined
+    launch(stage)
+  eng.dhead[:batch * 32].normal_()
+  out = {}
+  for stage, name in enumerate(STAGES):
+    launch(stage)
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+      launch(stage)
+    end.record()
+    end.synchronize()
+    out[name] = start.elapsed_time(end) * 1e3 / iters
+  return out
+
+
+def time_gae(T, N, iters=20):
+  from derl_amd import ops
+  dev = torch.device("cuda", torch.cuda.current_device())
+  r = torch.randn(T, N, device=dev)
+  z = torch.rand(T, N, device=dev) < 0.01
+  v = torch.randn(T, N, device=dev)
+  lv = torch.randn(N, device=dev)
+  adv, vt = torch.empty_like(v), torch.empty_like(v)
+  for _ in range(3):
+    ops.gae(r, z, v, lv, 0.99, 0.95, adv, vt)
+  start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  start.record()
+  for _ in range(iters):
+    ops.gae(r, z, v, lv, 0.99, 0.95, adv, vt)
+  end.record()
+  end.synchronize()
+  us = start.elapsed_time(end) * 1e3 / iters
+  nbytes = 17.0 * T * N + 4.0 * N
+  return dict(T=T, N=N, us=round(us, 2), achieved=round(nbytes / us / 1e3, 1), peak=PEAK_HBM_GBPS,
+              unit="GB/s", frac=round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4))
+
+
+def main():
+  parser = argparse.ArgumentParser()
+  parser.add_argument("--gpus", type=int, default=1)
+  parser.add_argument("--steps", type=int, default=5)
+  parser.add_argument("--warmup", type=int, default=2)
+  parser.add_argument("--nenvs", type=int, default=256)
+  parser.add_argument("--nsteps", type=int, default=128)
+  parser.add_argument("--weak", action="store_true", help="256 envs per rank instead of in total")
+  parser.add_argument("--no-cpu-baseline", action="store_true")
+  parser.add_argument("--cpu-nsteps", type=int, default=32)
+  parser.add_argument("--no-roofline", action="store_true")
+  args = parser.parse_args()
+
+  import derl_amd as derl
+  from derl_amd import distributed
+
+  world = distributed.init_from_env()
+  rank = distributed.rank()
+  if world != max(args.gpus, 1) and rank == 0:
+    print(f"warning: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  torch.cuda.set_device(local_rank)
+  device = torch.device("cuda", local_rank)
+
+  nenvs_total = args.nenvs * world if args.weak else args.nenvs
+  if nenvs_total % world:
+    raise SystemExit(f"nenvs={nenvs_total} is not divisible by {world} ranks")
+  nenvs = nenvs_total // world
+  torch.manual_seed(0)  # identical initial parameters on every rank
+  import numpy as np
+  np.random.seed(1234 + rank)
+  env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=nenvs, seed=0, device=device, rank=rank)
+  kwargs = derl.PPOFactory.get_kwargs("atari")
+  kwargs.update(nenvs=nenvs, num_runner_steps=args.nsteps, num_train_steps=1e12)
+  alg = derl.PPOFactory(**kwargs).make(env, nlogs=1e5)
+  derl.summary.stop_recording()
+  distributed.broadcast_(alg.model.engine.params)
+  alg.model.engine.mark_dirty()
+  updates_per_iter = kwargs["num_epochs"] * kwargs["num_minibatches"]
+  data_iter = alg.runner.run()
+
+  def iteration():
+    for _ in range(updates_per_iter):
+      alg.step(next(data_iter))
+      derl.summary.stop_recording()  # PeriodicSummaries re-arms it every rollout
+
+  for _ in range(args.warmup):
+    iteration()
+  torch.cuda.synchronize()
+  distributed.barrier()
+  start = time.perf_counter()
+  for _ in range(args.steps):
+    iteration()
+  torch.cuda.synchronize()
+  distributed.barrier()
+  elapsed = torch.tensor([time.perf_counter() - start], dtype=torch.float64, device=device)
+  if world > 1:
+    torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+  elapsed = float(elapsed.item())
+
+  env_steps = args.steps * args.nsteps * nenvs_total
+  value = env_steps / elapsed
+  result = {
+      "metric": "env-steps/sec PPO BreakoutNoFrameskip-v4 nenvs=256",
+      "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+      "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+      "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
+      "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "config": {"workload": "PPO BreakoutNoFrameskip-v4 nenvs=256 nsteps=128 on 1xMI355X "
+                             "(BASELINE.json configs[1]): NatureCNN(A=4), 3 epochs x 4 minibatches, "
+                             "Adam, synthetic uint8 84x84x4 frames generated on the GPU",
+                 "nenvs_total": nenvs_total, "nenvs_per_gpu": nenvs, "nsteps": args.nsteps,
+                 "minibatch_per_gpu": nenvs * args.nsteps // kwargs["num_minibatches"],
+                 "updates_per_step": updates_per_iter, "parallelism": f"dp{world}",
+                 "final_loss": float(alg.loss_fn.last_terms[0].item())},
+  }
+
+  if rank == 0 and not args.no_roofline:
+    model = alg.model
+    A = model.engine.num_actions
+    mb = nenvs * args.nsteps // kwargs["num_minibatches"]
+    obs = alg.runner.unwrapped._buffers["obs"][:args.nsteps].reshape((-1,) + tuple(env.observation_space.shape))
+    idx = torch.randperm(obs.shape[0], device=device)[:mb].to(torch.int32)
+    train = time_stages(model, obs, idx, mb)
+    roll = time_stages(model, obs[:nenvs].contiguous(), None, nenvs)
+    # time per PPO iteration spent in each kernel: forward stages also run in the rollout
+    per_iter = {}
+    for name in STAGES:
+      t = train[name] * updates_per_iter
+      if name.endswith("_fwd"):
+        t += roll[name] * (args.nsteps + 1)
+      per_iter[name] = t
+    dominant = max((n for n in STAGES if stage_flops(n, 1, A) > 0), key=lambda n: per_iter[n])
+    tf = stage_flops(dominant, mb, A) / (train[dominant] * 1e-6) / 1e12
+    table = {n: {"train_us": round(train[n], 1), "rollout_us": round(roll[n], 1),
+                 "train_TFLOPs": round(stage_flops(n, mb, A) / (train[n] * 1e-6) / 1e12, 2)
+                 if stage_flops(n, mb, A) else None,
+                 "us_per_iteration": round(per_iter[n], 1)} for n in STAGES}
+    total_flops = sum(stage_flops(n, mb, A) for n in STAGES)
+    total_us = sum(train[n] for n in STAGES)
+    result["roofline"] = {
+        "bound": "mfma", "kernel": f"igemm stage {dominant} (batch {mb})",
+        "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "network_fwd_bwd_achieved": round(total_flops / (total_us * 1e-6) / 1e12, 2),
+        "stages": table}
+    gae_local = time_gae(args.nsteps, nenvs)
+    gae_big = time_gae(args.nsteps, 1 << 20)
+    result["gae_roofline"] = {"bound": "hbm", "at_config": gae_local, "asymptote": gae_big}
+
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    from oracle.ppo_cpu import time_cpu_baseline
+    base = time_cpu_baseline(nenvs=args.nenvs, nsteps=args.cpu_nsteps)
+    result["cpu_baseline"] = {"value": round(base["value"], 1), "unit": "env-steps/s",
+                              "cores": base["cores"], "kind": "port", "sample": base["sample"],
+                              "seconds": round(base["seconds"], 2)}
+
+  if rank == 0:
+    print(json.dumps(result), flush=True)
+  if world > 1:
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

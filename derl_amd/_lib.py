@@ -13,6 +13,7 @@ ABI_VERSION = 1
 
 c_int, c_float, c_void_p, c_char_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p
 c_size_t, c_int64, c_uint64, c_double = ctypes.c_size_t, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
+c_longlong = ctypes.c_longlong
 P = c_void_p
 
 # name -> argtypes; every function returns int (0 = OK) unless listed in _RESTYPES
@@ -21,7 +22,39 @@ SIGNATURES = {
     "dx_last_error": [],
     "dx_device_info": [c_int, c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "dx_gae_f32": [P, P, P, P, c_int, c_int, c_float, c_float, P, P, P],
+    "dx_adv_stats_f32": [P, c_longlong, P, P],
+    "dx_adv_normalize_f32": [P, P, c_longlong, c_float, P, c_int, P],
+    "dx_grad_sumsq_f32": [P, c_longlong, P, c_int, P],
+    "dx_clip_adam_step_f32": [P, P, P, P, c_longlong, P, c_int, c_double, c_double, c_double,
+                              c_double, c_double, c_longlong, P, P],
+    "dx_clip_rmsprop_step_f32": [P, P, P, c_longlong, P, c_int, c_double, c_double, c_double,
+                                 c_double, P, P],
+    "dx_gather_rows": [P, P, P, c_longlong, c_longlong, P],
+    "dx_categorical_act_f32": [P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
+    "dx_categorical_loss_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float,
+                                c_float, c_longlong, P, P, c_int, P, P],
+    "dx_synth_atari_step": [P, c_longlong, P, P, c_int, c_uint64, c_uint64, c_float, c_float, P],
+    "dx_cnn_init": [P],
+    "dx_cnn_pack": [P, P],
+    "dx_cnn_forward": [P, P, c_int, P, c_int, P],
+    "dx_cnn_backward": [P, P, c_int, P, c_int, P],
+    "dx_cnn_stage": [P, c_int, P, c_int, P, c_int, P],
 }
+
+
+class CnnCtx(ctypes.Structure):
+  """Mirror of ``dx_cnn_ctx`` (include/derl_amd.h); dx_cnn_init checks the size."""
+  _fields_ = (
+      [(n, c_int) for n in ("struct_bytes", "in_h", "in_w", "in_c", "num_actions", "max_batch",
+                            "h0", "w0", "h1", "w1", "h2", "w2", "flat", "reserved0")]
+      + [("off_w", ctypes.c_longlong * 6), ("off_b", ctypes.c_longlong * 6),
+         ("param_count", ctypes.c_longlong)]
+      + [(n, ctypes.c_longlong) for n in ("pk_c0f", "pk_c1f", "pk_c2f", "pk_fcf", "pk_hdf", "pk_hdb")]
+      + [("pk_c1d", ctypes.c_longlong * 4)]
+      + [(n, ctypes.c_longlong) for n in ("pk_c2d", "pk_fcd", "pk_hdd", "packed_count", "slab_count",
+                                          "y0_count", "y1_count", "y2_count", "hid_count", "head_count")]
+      + [(n, c_void_p) for n in ("params", "grads", "packed", "y0", "y1", "y2", "hid", "head",
+                                 "dy0", "dy1", "dy2", "dhid", "dhead", "slabs")])
 _RESTYPES = {"dx_last_error": c_char_p}
 
 _lib = None

@@ -1,0 +1,142 @@
+"""Algorithm base classes (derl/alg/common.py:9-106)."""
+from abc import ABC, abstractmethod
+
+import torch
+
+from .. import summary
+from ..optim import _FlatOptimizer
+
+
+def r_squared(targets, predictions):
+  """Coefficient of determination (alg/common.py:9-12)."""
+  variance = torch.pow(predictions.std(), 2)
+  return 1. - torch.mean(torch.pow(predictions - targets, 2)) / variance
+
+
+def total_norm(tensors, norm_type=2):
+  """Total norm of the tensors as if concatenated (alg/common.py:15-20)."""
+  if norm_type == float('inf'):
+    return max(t.abs().max() for t in tensors)
+  return sum(t.norm(norm_type) ** norm_type for t in tensors) ** (1. / norm_type)
+
+
+class _LossBackward(torch.autograd.Function):
+  """The scalar a device loss returns: ``.backward()`` runs the engine's backward from the
+  head gradient the fused loss kernel already produced."""
+
+  @staticmethod
+  def forward(ctx, anchor, value, backward_fn):
+    ctx.backward_fn = backward_fn
+    return value.clone()
+
+  @staticmethod
+  def backward(ctx, grad_output):
+    ctx.backward_fn(grad_output)
+    return None, None, None
+
+
+class Loss(ABC):
+  """Algorithm loss function (alg/common.py:23-45)."""
+  def __init__(self, model, name=None):
+    self.model = model
+    if name is None:
+      name = self.__class__.__name__
+      name = name[:-len("Loss")] if name.endswith("Loss") else name
+      name = name.lower()
+    self.name = name
+    self.call_count = 0
+
+  @property
+  def device(self):
+    return next(self.model.parameters()).device
+
+  def to_device(self, arr, dtype=None):
+    """Host array or tensor -> contiguous device tensor (the reference's
+    torch_from_numpy, alg/common.py:39-41); device tensors pass through."""
+    if not isinstance(arr, torch.Tensor):
+      arr = torch.as_tensor(arr)
+    return arr.to(device=self.device, dtype=dtype).contiguous()
+
+  torch_from_numpy = to_device
+
+  @abstractmethod
+  def __call__(self, data):
+    """Computes and returns loss value on given data."""
+
+
+class Trainer:
+  """Performs algorithm training steps (alg/common.py:48-78): loss -> zero_grad ->
+  backward -> global-norm clip -> anneals -> optimizer step.  With a derl_amd optimizer the
+  gradient all-reduce (sharded batches), the norm, the clip and the update are three
+  launches on the flat buffers; a torch optimizer still works through the parameter views."""
+  def __init__(self, optimizer, anneals=None, max_grad_norm=None):
+    self.optimizer = optimizer
+    self.anneals = anneals or []
+    self.max_grad_norm = max_grad_norm
+    self.step_count = 0
+
+  def preprocess_gradients(self, parameters, tag):
+    grad_norm = None
+    if isinstance(self.optimizer, _FlatOptimizer):
+      self.optimizer.max_grad_norm = self.max_grad_norm
+      self.optimizer.reduce_and_norm()
+      if summary.should_record():
+        # the fused step writes the pre-clip norm; read back lazily by the summary writer
+        summary.add_scalar(tag, self.optimizer.grad_norm, global_step=self.step_count)
+      return
+    parameters = list(parameters)
+    if self.max_grad_norm is not None:
+      grad_norm = torch.nn.utils.clip_grad_norm_(parameters, self.max_grad_norm)
+    if summary.should_record():
+      if grad_norm is None:
+        grad_norm = total_norm(p.grad for p in parameters if p.grad is not None)
+      summary.add_scalar(tag, grad_norm, global_step=self.step_count)
+
+  def step(self, alg, data):
+    loss = alg.loss(data)
+    self.optimizer.zero_grad()
+    loss.backward()
+    self.preprocess_gradients(alg.model.parameters(), f"{alg.name}/grad_norm")
+    for anneal in self.anneals:
+      if summary.should_record():
+        anneal.summarize(alg.runner.step_count)
+      anneal.step_to(alg.runner.step_count)
+    self.optimizer.step()
+    if not isinstance(self.optimizer, _FlatOptimizer):
+      engine = getattr(alg.model, "engine", None)
+      if engine is not None:
+        engine.mark_dirty()
+    self.step_count += 1
+    return loss
+
+
+class Alg:
+  """Generic learning algorithm specified by its loss function (alg/common.py:81-106)."""
+  def __init__(self, runner, trainer, loss_fn, name=None):
+    self.runner = runner
+    self.model = self.runner.policy.model
+    self.trainer = trainer
+    self.loss_fn = loss_fn
+    if name is None:
+      name = self.__class__.__name__.lower()
+    self.name = name
+
+  def loss(self, data):
+    return self.loss_fn(data)
+
+  def step(self, data):
+    return self.trainer.step(self, data)
+
+  def learn(self):
+    try:
+      from tqdm import tqdm  # pylint: disable=import-outside-toplevel
+    except ImportError:
+      tqdm = None
+    if tqdm is None:
+      for data in self.runner.run():
+        self.step(data)
+      return
+    with tqdm(total=len(self.runner)) as pbar:
+      for data in self.runner.run():
+        pbar.update(self.runner.step_count - pbar.n)
+        self.step(data)

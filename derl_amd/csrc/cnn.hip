@@ -1,0 +1,394 @@
+// Nature-DQN actor-critic network on the implicit-GEMM kernels: packing, forward, backward.
+//
+// Restates derl/models.py:94-124 (NatureCNNBase) + :166-214 (NatureCNNModel with
+// output_units=[A, 1]) and the autograd backward that derl/alg/common.py:70 triggers.
+// Parameters and gradients live in flat buffers in the reference's state_dict order and
+// layout (conv OIHW, linear [out][in]); the GEMMs read packed mirrors whose K axis follows
+// the NHWC activations.  NOTE (models.py:112,119-124): the reference flattens NCHW, so the
+// 3136-wide linear layer is permuted while packing; there is no ReLU after it.
+#include "igemm.hpp"
+#include <cstring>
+
+using namespace dx;
+
+namespace {
+
+constexpr int kHeadLd = 32, kHid = 512, kC0 = 32, kC1 = 64, kC2 = 64;
+
+struct Derived {
+  int h0, w0, h1, w1, h2, w2, flat;
+};
+
+int conv_out(int n, int k, int s) { return (n - k) / s + 1; }
+
+int roundup(long long v, int m) { return static_cast<int>((v + m - 1) / m * m); }
+
+// reduction split of a wgrad over its M rows: enough blocks to fill 256 CUs, >= 256 rows each
+void pick_msplit(long long M, int blocks_kn, int *msplit, int *mper) {
+  long long ms = 512 / blocks_kn;
+  if (ms < 1) ms = 1;
+  long long cap = (M + 255) / 256;
+  if (ms > cap) ms = cap;
+  if (ms < 1) ms = 1;
+  *mper = roundup((M + ms - 1) / ms, 32);
+  *msplit = static_cast<int>((M + *mper - 1) / *mper);
+}
+
+struct SlabPlan {
+  int msplit, mper;
+  long long w_off, b_off;  // offsets (floats) of the weight / bias slabs inside ctx->slabs
+};
+
+enum Layer { L_C0 = 0, L_C1, L_C2, L_FC, L_HD, L_COUNT };
+
+struct Plan {
+  SlabPlan s[L_COUNT];
+  long long total;
+};
+
+}  // namespace
+
+extern "C" {
+
+static Derived derive(const dx_cnn_ctx *c) {
+  Derived d;
+  d.h0 = conv_out(c->in_h, 8, 4); d.w0 = conv_out(c->in_w, 8, 4);
+  d.h1 = conv_out(d.h0, 4, 2); d.w1 = conv_out(d.w0, 4, 2);
+  d.h2 = conv_out(d.h1, 3, 1); d.w2 = conv_out(d.w1, 3, 1);
+  d.flat = d.h2 * d.w2 * kC2;
+  return d;
+}
+
+static void layer_nk(const dx_cnn_ctx *c, int layer, int *N, int *K, int *blocks_kn) {
+  const int n[L_COUNT] = {kC0, kC1, kC2, kHid, kHeadLd};
+  const int k[L_COUNT] = {64 * c->in_c, 16 * kC0, 9 * kC1, c->flat, kHid};
+  *N = n[layer];
+  *K = k[layer];
+  *blocks_kn = n[layer] <= 32 ? cdiv(k[layer], 256) * cdiv(n[layer], 32)
+                              : cdiv(k[layer], 128) * cdiv(n[layer], 64);
+}
+
+static long long layer_rows(const dx_cnn_ctx *c, int layer, long long B) {
+  switch (layer) {
+    case L_C0: return B * c->h0 * c->w0;
+    case L_C1: return B * c->h1 * c->w1;
+    case L_C2: return B * c->h2 * c->w2;
+    default: return B;
+  }
+}
+
+static Plan make_plan(const dx_cnn_ctx *c, long long B) {
+  Plan p;
+  long long off = 0;
+  for (int l = 0; l < L_COUNT; ++l) {
+    int N, K, bkn;
+    layer_nk(c, l, &N, &K, &bkn);
+    // capacity (offsets) from max_batch, split from the actual batch
+    int ms_cap, mper_cap;
+    pick_msplit(layer_rows(c, l, c->max_batch), bkn, &ms_cap, &mper_cap);
+    pick_msplit(layer_rows(c, l, B), bkn, &p.s[l].msplit, &p.s[l].mper);
+    p.s[l].w_off = off;
+    off += static_cast<long long>(ms_cap) * N * K;
+    p.s[l].b_off = off;
+    off += static_cast<long long>(ms_cap) * N;
+    off = (off + 63) / 64 * 64;
+  }
+  p.total = off;
+  return p;
+}
+
+int dx_cnn_init(dx_cnn_ctx *c) {
+  DX_REQUIRE(c != nullptr, "dx_cnn_init: null ctx");
+  DX_REQUIRE(c->struct_bytes == static_cast<int>(sizeof(dx_cnn_ctx)),
+             "dx_cnn_init: struct size mismatch (caller %d, library %d)", c->struct_bytes,
+             static_cast<int>(sizeof(dx_cnn_ctx)));
+  DX_REQUIRE(c->in_c == 4, "dx_cnn_init: only 4 stacked frames are supported (in_c=%d)", c->in_c);
+  DX_REQUIRE(c->in_h >= 36 && c->in_w >= 36, "dx_cnn_init: input %dx%d too small", c->in_h, c->in_w);
+  DX_REQUIRE(c->num_actions >= 1 && c->num_actions <= 31, "dx_cnn_init: need 1 <= A <= 31");
+  DX_REQUIRE(c->max_batch >= 1, "dx_cnn_init: max_batch < 1");
+  const Derived d = derive(c);
+  DX_REQUIRE(d.h2 >= 1 && d.w2 >= 1, "dx_cnn_init: input too small for the conv stack");
+  c->h0 = d.h0; c->w0 = d.w0; c->h1 = d.h1; c->w1 = d.w1; c->h2 = d.h2; c->w2 = d.w2;
+  c->flat = d.flat;
+  const int A = c->num_actions;
+  // canonical (state_dict) layout: weight, bias per layer in order
+  const long long wsz[6] = {kC0 * c->in_c * 64LL, kC1 * kC0 * 16LL, kC2 * kC1 * 9LL,
+                            static_cast<long long>(kHid) * d.flat, static_cast<long long>(A) * kHid, kHid};
+  const long long bsz[6] = {kC0, kC1, kC2, kHid, A, 1};
+  long long off = 0;
+  for (int i = 0; i < 6; ++i) {
+    c->off_w[i] = off; off += wsz[i];
+    c->off_b[i] = off; off += bsz[i];
+  }
+  c->param_count = off;
+  // packed mirrors
+  long long po = 0;
+  auto take = [&](long long n) { long long o = po; po += (n + 63) / 64 * 64; return o; };
+  c->pk_c0f = take(wsz[0]); c->pk_c1f = take(wsz[1]); c->pk_c2f = take(wsz[2]); c->pk_fcf = take(wsz[3]);
+  c->pk_hdf = take(kHeadLd * kHid); c->pk_hdb = take(kHeadLd);
+  for (int p = 0; p < 4; ++p) c->pk_c1d[p] = take(kC0 * 4LL * kC1);
+  c->pk_c2d = take(wsz[2]); c->pk_fcd = take(wsz[3]); c->pk_hdd = take(kHid * kHeadLd);
+  c->packed_count = po;
+  c->slab_count = make_plan(c, c->max_batch).total;
+  const long long mb = c->max_batch;
+  c->y0_count = mb * d.h0 * d.w0 * kC0;
+  c->y1_count = mb * d.h1 * d.w1 * kC1;
+  c->y2_count = mb * d.flat;
+  c->hid_count = mb * kHid;
+  c->head_count = mb * kHeadLd;
+  return DX_OK;
+}
+
+static int check_ctx(const dx_cnn_ctx *c, const char *who, long long B, bool need_bwd) {
+  DX_REQUIRE(c && c->struct_bytes == static_cast<int>(sizeof(dx_cnn_ctx)) && c->param_count > 0,
+             "%s: ctx not initialised by dx_cnn_init", who);
+  DX_REQUIRE(B >= 1 && B <= c->max_batch, "%s: batch %lld outside [1, max_batch=%d]", who, B, c->max_batch);
+  DX_REQUIRE(c->params && c->packed && c->y0 && c->y1 && c->y2 && c->hid && c->head,
+             "%s: forward buffers not set", who);
+  if (need_bwd)
+    DX_REQUIRE(c->grads && c->dy0 && c->dy1 && c->dy2 && c->dhid && c->dhead && c->slabs,
+               "%s: backward buffers not set", who);
+  return DX_OK;
+}
+
+// canonical parameters -> packed mirrors (call after every parameter change)
+int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
+  if (int rc = check_ctx(c, "dx_cnn_pack", 1, false)) return rc;
+  hipStream_t s = as_stream(stream);
+  const int A = c->num_actions, IC0 = c->in_c, P = c->h2 * c->w2, flat = c->flat;
+  const float *w = c->params;
+  float *pk = c->packed;
+  // padded head rows beyond A stay zero
+  DX_HIP(hipMemsetAsync(pk + c->pk_hdf, 0, sizeof(float) * kHeadLd * kHid, s));
+  DX_HIP(hipMemsetAsync(pk + c->pk_hdb, 0, sizeof(float) * kHeadLd, s));
+  PermuteJob j[kMaxJobs];
+  int n = 0;
+  auto add = [&](const float *src, float *dst, long long total, int D1, int D2, int D3, long long s0,
+                 long long s1, long long s2, long long s3, long long off) {
+    j[n++] = PermuteJob{src, dst, total, D1, D2, D3, s0, s1, s2, s3, off, 1, 0};
+  };
+  // conv forward: dst [oc][kh][kw][ic] <- OIHW
+  add(w + c->off_w[0], pk + c->pk_c0f, kC0 * 64LL * IC0, 8, 8, IC0, IC0 * 64LL, 8, 1, 64, 0);
+  add(w + c->off_w[1], pk + c->pk_c1f, kC1 * 16LL * kC0, 4, 4, kC0, kC0 * 16LL, 4, 1, 16, 0);
+  add(w + c->off_w[2], pk + c->pk_c2f, kC2 * 9LL * kC1, 3, 3, kC1, kC1 * 9LL, 3, 1, 9, 0);
+  // linear: dst [n][p][c] <- [n][c*P + p]
+  add(w + c->off_w[3], pk + c->pk_fcf, static_cast<long long>(kHid) * flat, P, kC2, 1, flat, 1, P, 0, 0);
+  // heads: rows 0..A-1 policy logits, row A value
+  add(w + c->off_w[4], pk + c->pk_hdf, static_cast<long long>(A) * kHid, 1, 1, kHid, kHid, 0, 0, 1, 0);
+  add(w + c->off_w[5], pk + c->pk_hdf + static_cast<long long>(A) * kHid, kHid, 1, 1, kHid, kHid, 0, 0, 1, 0);
+  add(w + c->off_b[4], pk + c->pk_hdb, A, 1, 1, 1, 1, 0, 0, 0, 0);
+  add(w + c->off_b[5], pk + c->pk_hdb + A, 1, 1, 1, 1, 1, 0, 0, 0, 0);
+  // conv1 dgrad, one pack per input-pixel parity (py,px): dst [ic][a][b][oc] <- W[oc][ic][py+2a][px+2b]
+  for (int p = 0; p < 4; ++p)
+    add(w + c->off_w[1], pk + c->pk_c1d[p], kC0 * 4LL * kC1, 2, 2, kC1, 16, 8, 2, kC0 * 16LL,
+        (p >> 1) * 4 + (p & 1));
+  // conv2 dgrad: dst [ic][kh][kw][oc]
+  add(w + c->off_w[2], pk + c->pk_c2d, kC1 * 9LL * kC2, 3, 3, kC2, 9, 3, 1, kC1 * 9LL, 0);
+  // linear dgrad: dst [p][c][n] <- [n][c*P + p]
+  add(w + c->off_w[3], pk + c->pk_fcd, static_cast<long long>(flat) * kHid, kC2, kHid, 1, 1, P, flat, 0, 0);
+  if (int rc = launch_permute_reduce(j, n, s)) return rc;
+  // heads dgrad: dst [k][j] <- padded [j][k] (second launch: reads the rows packed above)
+  PermuteJob t{pk + c->pk_hdf, pk + c->pk_hdd, static_cast<long long>(kHid) * kHeadLd, kHeadLd, 1, 1,
+               1, kHid, 0, 0, 0, 1, 0};
+  return launch_permute_reduce(&t, 1, s);
+}
+
+static Gather conv_gather(const void *src, const int32_t *idx, int H, int W, int C, int OH, int OW,
+                          int stride, int KH, int KW) {
+  Gather g;
+  std::memset(&g, 0, sizeof(g));
+  g.src = src; g.idx = idx;
+  g.img_stride = static_cast<long long>(H) * W * C;
+  g.H = H; g.W = W; g.C = C;
+  g.OHW = OH * OW; g.OW = OW;
+  g.div_img = make_fastdiv(g.OHW); g.div_row = make_fastdiv(OW);
+  g.sy = g.sx = stride;
+  g.nseg = KH; g.seglen = KW * C; g.check = 0;
+  for (int kh = 0; kh < KH; ++kh) { g.seg_off[kh] = kh * W * C; g.seg_dy[kh] = kh; g.seg_dx[kh] = 0; }
+  return g;
+}
+
+static Gather rows_gather(const void *src, int width) {  // plain [rows][width] matrix
+  Gather g;
+  std::memset(&g, 0, sizeof(g));
+  g.src = src; g.img_stride = width; g.H = g.W = 1; g.C = width;
+  g.OHW = 1; g.OW = 1; g.div_img = make_fastdiv(1); g.div_row = make_fastdiv(1);
+  g.sy = g.sx = 1; g.nseg = 1; g.seglen = width;
+  return g;
+}
+
+// dgrad rows = pixels (y', x') of one parity class of the conv input; taps (a, b) read the
+// output-gradient pixel (y'-a, x'-b)
+static Gather dgrad_gather(const void *dy, int H, int W, int C, int OH, int OW, int TA, int TB) {
+  Gather g;
+  std::memset(&g, 0, sizeof(g));
+  g.src = dy; g.img_stride = static_cast<long long>(H) * W * C;
+  g.H = H; g.W = W; g.C = C;
+  g.OHW = OH * OW; g.OW = OW;
+  g.div_img = make_fastdiv(g.OHW); g.div_row = make_fastdiv(OW);
+  g.sy = g.sx = 1; g.nseg = TA * TB; g.seglen = C; g.check = 1;
+  for (int a = 0; a < TA; ++a)
+    for (int b = 0; b < TB; ++b) {
+      const int s = a * TB + b;
+      g.seg_off[s] = (-a * W - b) * C; g.seg_dy[s] = static_cast<int8_t>(-a); g.seg_dx[s] = static_cast<int8_t>(-b);
+    }
+  return g;
+}
+
+static NTArgs nt_args(const Gather &g, const float *Wp, const float *bias, float *out, int ldc,
+                      long long M, int N, int K) {
+  NTArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.g = g; a.Wp = Wp; a.bias = bias; a.out = out; a.ldc = ldc;
+  a.M = static_cast<int>(M); a.N = N; a.K = K; a.ksplit = 1;
+  return a;
+}
+
+// One launch (one profiler row) of the network.  Forward = stages ST_CONV0_FWD..ST_HEADS_FWD,
+// backward = ST_HEADS_WGRAD..ST_FINALIZE in enum order.
+static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is_u8,
+                     const int32_t *sample_idx, int B, const Plan &plan, hipStream_t s) {
+  const float *w = c->params;
+  const float *pk = c->packed;
+  const int IC0 = c->in_c, A = c->num_actions, flat = c->flat, P = c->h2 * c->w2;
+  const long long M0 = static_cast<long long>(B) * c->h0 * c->w0, M1 = static_cast<long long>(B) * c->h1 * c->w1,
+                  M2 = static_cast<long long>(B) * P;
+  auto tn = [&](int layer, const Gather &g, const float *G, int ldg, long long M, int N, int K, bool u8) {
+    TNArgs t;
+    std::memset(&t, 0, sizeof(t));
+    t.g = g; t.G = G; t.ldg = ldg;
+    t.slab = c->slabs + plan.s[layer].w_off; t.bias_slab = c->slabs + plan.s[layer].b_off;
+    t.M = static_cast<int>(M); t.N = N; t.K = K;
+    t.msplit = plan.s[layer].msplit; t.mper = plan.s[layer].mper;
+    return launch_tn(t, u8, stage, s);
+  };
+  NTArgs a;
+  switch (stage) {
+    case ST_CONV0_FWD:
+      a = nt_args(conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), pk + c->pk_c0f,
+                  w + c->off_b[0], c->y0, kC0, M0, kC0, 64 * IC0);
+      return launch_nt(a, obs_is_u8 != 0, EPI_BIAS_RELU, stage, s);
+    case ST_CONV1_FWD:
+      a = nt_args(conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), pk + c->pk_c1f,
+                  w + c->off_b[1], c->y1, kC1, M1, kC1, 16 * kC0);
+      return launch_nt(a, false, EPI_BIAS_RELU, stage, s);
+    case ST_CONV2_FWD:
+      a = nt_args(conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), pk + c->pk_c2f,
+                  w + c->off_b[2], c->y2, kC2, M2, kC2, 9 * kC1);
+      return launch_nt(a, false, EPI_BIAS_RELU, stage, s);
+    case ST_FC_FWD:
+      a = nt_args(rows_gather(c->y2, flat), pk + c->pk_fcf, w + c->off_b[3], c->hid, kHid, B, kHid, flat);
+      return launch_nt(a, false, EPI_BIAS, stage, s);
+    case ST_HEADS_FWD:
+      a = nt_args(rows_gather(c->hid, kHid), pk + c->pk_hdf, pk + c->pk_hdb, c->head, kHeadLd, B, kHeadLd, kHid);
+      return launch_nt(a, false, EPI_BIAS, stage, s);
+    case ST_HEADS_WGRAD:
+      return tn(L_HD, rows_gather(c->hid, kHid), c->dhead, kHeadLd, B, kHeadLd, kHid, false);
+    case ST_HEADS_DGRAD:
+      a = nt_args(rows_gather(c->dhead, kHeadLd), pk + c->pk_hdd, nullptr, c->dhid, kHid, B, kHid, kHeadLd);
+      return launch_nt(a, false, EPI_NONE, stage, s);
+    case ST_FC_WGRAD:
+      return tn(L_FC, rows_gather(c->y2, flat), c->dhid, kHid, B, kHid, flat, false);
+    case ST_FC_DGRAD:
+      a = nt_args(rows_gather(c->dhid, kHid), pk + c->pk_fcd, nullptr, c->dy2, flat, B, flat, kHid);
+      a.mask_src = c->y2;
+      return launch_nt(a, false, EPI_MASK, stage, s);
+    case ST_CONV2_WGRAD:
+      return tn(L_C2, conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), c->dy2, kC2, M2,
+                kC2, 9 * kC1, false);
+    case ST_CONV2_DGRAD:
+      a = nt_args(dgrad_gather(c->dy2, c->h2, c->w2, kC2, c->h1, c->w1, 3, 3), pk + c->pk_c2d, nullptr,
+                  c->dy1, kC1, M1, kC1, 9 * kC2);
+      a.mask_src = c->y1;
+      return launch_nt(a, false, EPI_MASK, stage, s);
+    case ST_CONV1_WGRAD:
+      return tn(L_C1, conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), c->dy1, kC1, M1,
+                kC1, 16 * kC0, false);
+    case ST_CONV1_DGRAD:
+      // 4x4 stride-2 conv: one launch per parity class (py,px) of the input pixels
+      for (int p = 0; p < 4; ++p) {
+        const int py = p >> 1, px = p & 1;
+        const int OHp = (c->h0 - py + 1) / 2, OWp = (c->w0 - px + 1) / 2;
+        if (OHp <= 0 || OWp <= 0) continue;
+        a = nt_args(dgrad_gather(c->dy1, c->h1, c->w1, kC1, OHp, OWp, 2, 2), pk + c->pk_c1d[p], nullptr,
+                    c->dy0, kC0, static_cast<long long>(B) * OHp * OWp, kC0, 4 * kC1);
+        a.mask_src = c->y0;
+        a.om.enabled = 1;
+        a.om.OHW = OHp * OWp; a.om.OW = OWp;
+        a.om.div_img = make_fastdiv(a.om.OHW); a.om.div_row = make_fastdiv(OWp);
+        a.om.OUT_H = c->h0; a.om.OUT_W = c->w0; a.om.osy = a.om.osx = 2; a.om.ody = py; a.om.odx = px;
+        if (int rc = launch_nt(a, false, EPI_MASK, stage, s)) return rc;
+      }
+      return DX_OK;
+    case ST_CONV0_WGRAD:
+      return tn(L_C0, conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), c->dy0, kC0,
+                M0, kC0, 64 * IC0, obs_is_u8 != 0);
+    case ST_FINALIZE: {
+      // slabs -> canonical gradients
+      PermuteJob j[kMaxJobs];
+      int n = 0;
+      float *g = c->grads;
+      auto addw = [&](int layer, long long off_dst, long long total, int D1, int D2, int D3, long long s0,
+                      long long s1, long long s2, long long s3, long long off, int N, int K) {
+        j[n++] = PermuteJob{c->slabs + plan.s[layer].w_off, g + off_dst, total, D1, D2, D3, s0, s1, s2, s3,
+                            off, plan.s[layer].msplit, static_cast<long long>(N) * K};
+      };
+      auto addb = [&](int layer, long long off_dst, long long total, long long off, int N) {
+        j[n++] = PermuteJob{c->slabs + plan.s[layer].b_off, g + off_dst, total, 1, 1, 1, 1, 0, 0, 0, off,
+                            plan.s[layer].msplit, N};
+      };
+      // conv: canonical (oc, ic, kh, kw) <- slab [oc][(kh*KW + kw)*IC + ic]
+      addw(L_C0, c->off_w[0], kC0 * 64LL * IC0, IC0, 8, 8, 64LL * IC0, 1, 8 * IC0, IC0, 0, kC0, 64 * IC0);
+      addw(L_C1, c->off_w[1], kC1 * 16LL * kC0, kC0, 4, 4, 16LL * kC0, 1, 4 * kC0, kC0, 0, kC1, 16 * kC0);
+      addw(L_C2, c->off_w[2], kC2 * 9LL * kC1, kC1, 3, 3, 9LL * kC1, 1, 3 * kC1, kC1, 0, kC2, 9 * kC1);
+      // linear: canonical (n, c, p) <- slab [n][p*64 + c]
+      addw(L_FC, c->off_w[3], static_cast<long long>(kHid) * flat, kC2, P, 1, flat, 1, kC2, 0, 0, kHid, flat);
+      addw(L_HD, c->off_w[4], static_cast<long long>(A) * kHid, kHid, 1, 1, kHid, 1, 0, 0, 0, kHeadLd, kHid);
+      addw(L_HD, c->off_w[5], kHid, kHid, 1, 1, kHid, 1, 0, 0, static_cast<long long>(A) * kHid, kHeadLd, kHid);
+      addb(L_C0, c->off_b[0], kC0, 0, kC0);
+      addb(L_C1, c->off_b[1], kC1, 0, kC1);
+      addb(L_C2, c->off_b[2], kC2, 0, kC2);
+      addb(L_FC, c->off_b[3], kHid, 0, kHid);
+      addb(L_HD, c->off_b[4], A, 0, kHeadLd);
+      addb(L_HD, c->off_b[5], 1, A, kHeadLd);
+      return launch_permute_reduce(j, n, s);
+    }
+    default:
+      return fail(DX_EINVAL, "dx_cnn: unknown stage %d", stage);
+  }
+}
+
+// observations (B,H,W,4) uint8 or float32 NHWC [optionally gathered by sample_idx] ->
+// ctx->head (B,32): columns 0..A-1 logits, column A value.  Keeps y0,y1,y2,hid for backward.
+int dx_cnn_forward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const int32_t *sample_idx,
+                   int B, void *stream) {
+  if (int rc = check_ctx(c, "dx_cnn_forward", B, false)) return rc;
+  DX_REQUIRE(obs != nullptr, "dx_cnn_forward: null observations");
+  const Plan plan = make_plan(c, B);
+  for (int st = ST_CONV0_FWD; st <= ST_HEADS_FWD; ++st)
+    if (int rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, as_stream(stream))) return rc;
+  return DX_OK;
+}
+
+// ctx->dhead (B,32) -> ctx->grads (canonical layout), using the activations kept by
+// dx_cnn_forward on the SAME observations / sample_idx.
+int dx_cnn_backward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const int32_t *sample_idx,
+                    int B, void *stream) {
+  if (int rc = check_ctx(c, "dx_cnn_backward", B, true)) return rc;
+  DX_REQUIRE(obs != nullptr, "dx_cnn_backward: null observations");
+  const Plan plan = make_plan(c, B);
+  for (int st = ST_HEADS_WGRAD; st <= ST_FINALIZE; ++st)
+    if (int rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, as_stream(stream))) return rc;
+  return DX_OK;
+}
+
+// A single stage, for per-kernel timing (bench.py roofline) and layer-level tests.
+int dx_cnn_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is_u8,
+                 const int32_t *sample_idx, int B, void *stream) {
+  if (int rc = check_ctx(c, "dx_cnn_stage", B, stage >= ST_HEADS_WGRAD)) return rc;
+  DX_REQUIRE(obs != nullptr, "dx_cnn_stage: null observations");
+  const Plan plan = make_plan(c, B);
+  return run_stage(c, stage, obs, obs_is_u8, sample_idx, B, plan, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+// Distribution heads and fused loss forward+backward (gfx950).
+//
+// Categorical head on the padded head output `out[b][0..31]` (columns 0..A-1 logits,
+// column A the value; produced by the heads GEMM): one half-wave (32 lanes) per row, lane j
+// owns column j, softmax reductions by cross-lane shuffles.
+//   rollout : sample by inverse CDF from a uniform, log_prob, value
+//             (derl/policies.py:61-80 -- ActorCriticPolicy.act, Categorical)
+//   training: PPO clipped-ratio / clipped-value loss with entropy bonus, or A2C loss, and
+//             their gradient w.r.t. logits and value in the same pass
+//             (derl/alg/ppo.py:45-64,82-98,104; derl/alg/a2c.py:32-33,57,74; closed forms
+//             in SURVEY.md Appendix A.1-A.5)
+// Diagonal-Gaussian head for the MLP policy: thread per row (derl/policies.py:40-42,66).
+#include "common.hpp"
+
+namespace {
+
+constexpr int kHeadLd = 32;  // padded head width
+
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// counter-based uniform in [0,1): 2 rounds of a 64-bit mix (splitmix64 finaliser) of
+// (seed, counter, row); 24 random bits -> exactly representable float
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t counter, uint64_t row) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter * 0x100000001B3ull + row + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return static_cast<float>(z >> 40) * (1.0f / 16777216.0f);
+}
+
+struct Softmax {
+  float logp, p, lse;
+};
+
+// lane j < A holds logit j; returns this lane's log-prob / prob (0 for padding lanes)
+__device__ __forceinline__ Softmax half_softmax(float logit, bool is_logit) {
+  const float mx = half_max(is_logit ? logit : -INFINITY);
+  const float e = is_logit ? expf(logit - mx) : 0.f;
+  const float s = half_sum(e);
+  Softmax r;
+  r.lse = mx + logf(s);
+  r.logp = is_logit ? logit - r.lse : 0.f;
+  r.p = e / s;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void categorical_act_kernel(
+    const float *__restrict__ out, int B, int A, const float *__restrict__ uniforms, uint64_t seed,
+    uint64_t counter, int64_t *__restrict__ actions, float *__restrict__ log_prob,
+    float *__restrict__ values) {
+  const int col = threadIdx.x & 31;
+  const int half = threadIdx.x >> 5;  // 8 rows per 256-thread block
+  const int b = blockIdx.x * 8 + half;
+  const bool row_ok = b < B;
+  const float x = row_ok ? out[static_cast<long long>(b) * kHeadLd + col] : 0.f;
+  const bool is_logit = col < A;
+  const float mx = half_max(is_logit ? x : -INFINITY);
+  const float e = is_logit ? expf(x - mx) : 0.f;
+  // sequential float32 running sum in column order (matches the CPU statement of the rule)
+  float acc = 0.f, cdf = 0.f;
+  for (int k = 0; k < A; ++k) {
+    acc += __shfl(e, (threadIdx.x & 32) + k);
+    if (k == col) cdf = acc;
+  }
+  const float u = uniforms ? (row_ok ? uniforms[b] : 0.f) : uniform01(seed, counter, b);
+  const float thresh = u * acc;
+  const unsigned long long below = __ballot(is_logit && cdf <= thresh);
+  int a = __popcll((below >> (threadIdx.x & 32)) & 0xffffffffull);
+  if (a > A - 1) a = A - 1;
+  const float lse = mx + logf(acc);
+  const float la = __shfl(x, (threadIdx.x & 32) + a) - lse;
+  const float v = __shfl(x, (threadIdx.x & 32) + A);
+  if (row_ok && col == 0) {
+    actions[b] = a;
+    log_prob[b] = la;
+    values[b] = v;
+  }
+}
+
+struct LossArgs {
+  const float *out;        // [B][32] head outputs
+  const int64_t *actions;  // [B]
+  const float *old_log_prob, *advantages, *old_values, *value_targets;  // [B]
+  float *dout;             // [B][32] gradient w.r.t. head outputs (padding columns zero)
+  double *partials;        // [gridDim.x][8]
+  int B, A;
+  int mode;                // 0 = PPO, 1 = A2C
+  float cliprange;         // < 0: no clipping (cliprange=None)
+  float value_loss_coef, entropy_coef, inv_batch;
+};
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void categorical_loss_kernel(const LossArgs a) {
+  __shared__ double red[4][8];
+  const int col = threadIdx.x & 31;
+  const int half = threadIdx.x >> 5;
+  const int b = blockIdx.x * 8 + half;
+  const bool row_ok = b < a.B;
+  const long long o = static_cast<long long>(b) * kHeadLd + col;
+  const float x = row_ok ? a.out[o] : 0.f;
+  const bool is_logit = col < a.A;
+  const Softmax sm = half_softmax(x, is_logit);
+  const float ent = -half_sum(is_logit ? sm.p * sm.logp : 0.f);
+  const int act = row_ok ? static_cast<int>(a.actions[b]) : 0;
+  const int hbase = threadIdx.x & 32;
+  const float lp = __shfl(sm.logp, hbase + act);
+  const float v = __shfl(x, hbase + a.A);
+  const float adv = row_ok ? a.advantages[b] : 0.f;
+  const float vt = row_ok ? a.value_targets[b] : 0.f;
+  float pl, vl, dlp, dv;
+  if (a.mode == 0) {
+    const float old_lp = row_ok ? a.old_log_prob[b] : 0.f;
+    const float old_v = row_ok ? a.old_values[b] : 0.f;
+    const float ratio = expf(lp - old_lp);
+    const float l1 = -ratio * adv;
+    pl = l1;
+    bool active = true;
+    if (a.cliprange >= 0.f) {
+      const float lo = 1.f - a.cliprange, hi = 1.f + a.cliprange;
+      const float rc = fminf(fmaxf(ratio, lo), hi);
+      const float l2 = -rc * adv;
+      pl = fmaxf(l1, l2);
+      active = (l1 > l2) || (ratio >= lo && ratio <= hi);
+    }
+    dlp = active ? -adv * ratio * a.inv_batch : 0.f;
+    const float d = v - vt;
+    const float e1 = d * d;
+    vl = e1;
+    bool vactive = true;
+    if (a.cliprange >= 0.f) {
+      const float dvo = v - old_v;
+      const float vc = old_v + fminf(fmaxf(dvo, -a.cliprange), a.cliprange);
+      const float e2 = (vc - vt) * (vc - vt);
+      vl = fmaxf(e1, e2);
+      vactive = (e1 > e2) || (fabsf(dvo) <= a.cliprange);
+    }
+    dv = vactive ? a.value_loss_coef * 2.f * d * a.inv_batch : 0.f;
+  } else {
+    pl = -lp * adv;
+    dlp = -adv * a.inv_batch;
+    const float d = v - vt;
+    vl = d * d;
+    dv = a.value_loss_coef * 2.f * d * a.inv_batch;
+  }
+  // dL/dlogit_j = dlp*(1[j=a] - p_j) + (-c_H/B) * (-p_j*(logp_j + H))
+  float g = 0.f;
+  if (is_logit)
+    g = dlp * ((col == act ? 1.f : 0.f) - sm.p) + a.entropy_coef * a.inv_batch * sm.p * (sm.logp + ent);
+  else if (col == a.A)
+    g = dv;
+  if (row_ok) a.dout[o] = g;
+
+  // block partial sums (float64): policy term, entropy, value term, adv, v, vt, (v-vt)^2, v^2
+  const bool lead = row_ok && col == 0;
+  double s[8] = {lead ? pl : 0.0, lead ? ent : 0.0, lead ? vl : 0.0, lead ? adv : 0.0,
+                 lead ? v : 0.0,  lead ? vt : 0.0,  lead ? (double)(v - vt) * (v - vt) : 0.0,
+                 lead ? (double)v * v : 0.0};
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    s[i] = wave_sum_d(s[i]);
+    if (lane == 0) red[wave][i] = s[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8)
+    a.partials[blockIdx.x * 8 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[0]=loss, [1]=policy_loss, [2]=entropy, [3]=value_loss, [4]=mean adv, [5]=mean value,
+// [6]=mean value target, [7]=r_squared (alg/common.py:9-12 with ppo.py:94's argument order)
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partials, int nblocks,
+                                                          double count, float value_loss_coef,
+                                                          float entropy_coef, float *out) {
+  __shared__ double red[4][8];
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += partials[i * 8 + j];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] = wave_sum_d(s[j]);
+    if (lane == 0) red[wave][j] = s[j];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[8];
+    for (int j = 0; j < 8; ++j) t[j] = (red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+    const float policy = static_cast<float>(t[0] / count);
+    const float ent = static_cast<float>(t[1] / count);
+    const float value = static_cast<float>(t[2] / count);
+    out[0] = (policy - entropy_coef * ent) + value_loss_coef * value;
+    out[1] = policy;
+    out[2] = ent;
+    out[3] = value;
+    out[4] = static_cast<float>(t[3] / count);
+    out[5] = static_cast<float>(t[4] / count);
+    out[6] = static_cast<float>(t[5] / count);
+    const double mean_v = t[4] / count;
+    const double var_v = count > 1 ? (t[7] - count * mean_v * mean_v) / (count - 1) : 0.0;  // torch .std(): unbiased
+    out[7] = static_cast<float>(1.0 - (t[6] / count) / var_v);
+  }
+}
+
+}  // namespace
+
+extern "C" int dx_categorical_act_f32(const float *head_out, int B, int A, const float *uniforms,
+                                      uint64_t seed, uint64_t counter, int64_t *actions,
+                                      float *log_prob, float *values, void *stream) {
+  DX_REQUIRE(B >= 0 && A >= 1 && A <= 31, "dx_categorical_act_f32: need 1 <= A <= 31 (A=%d)", A);
+  if (B == 0) return DX_OK;
+  DX_REQUIRE(head_out && actions && log_prob && values, "dx_categorical_act_f32: null pointer");
+  hipLaunchKernelGGL(categorical_act_kernel, dim3(dx::cdiv(B, 8)), dim3(256), 0, dx::as_stream(stream),
+                     head_out, B, A, uniforms, seed, counter, actions, log_prob, values);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_categorical_loss_f32(const float *head_out, const int64_t *actions,
+                                       const float *old_log_prob, const float *advantages,
+                                       const float *old_values, const float *value_targets, int B,
+                                       int A, int mode, float cliprange, float value_loss_coef,
+                                       float entropy_coef, long long global_batch, float *dhead_out,
+                                       double *partials, int partials_capacity, float *loss_out,
+                                       void *stream) {
+  DX_REQUIRE(B >= 1 && A >= 1 && A <= 31, "dx_categorical_loss_f32: need B >= 1 and 1 <= A <= 31");
+  DX_REQUIRE(mode == 0 || mode == 1, "dx_categorical_loss_f32: mode must be 0 (PPO) or 1 (A2C)");
+  DX_REQUIRE(head_out && actions && advantages && value_targets && dhead_out && partials && loss_out,
+             "dx_categorical_loss_f32: null pointer");
+  DX_REQUIRE(mode == 1 || (old_log_prob && old_values), "dx_categorical_loss_f32: PPO needs old_log_prob/old_values");
+  const int blocks = dx::cdiv(B, 8);
+  DX_REQUIRE(partials_capacity >= blocks * 8, "dx_categorical_loss_f32: partials needs %d doubles", blocks * 8);
+  if (global_batch <= 0) global_batch = B;
+  LossArgs a{head_out, actions, old_log_prob, advantages, old_values, value_targets, dhead_out,
+             partials, B, A, mode, cliprange, value_loss_coef, entropy_coef,
+             1.0f / static_cast<float>(global_batch)};
+  hipStream_t s = dx::as_stream(stream);
+  hipLaunchKernelGGL(categorical_loss_kernel, dim3(blocks), dim3(256), 0, s, a);
+  DX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, partials, blocks,
+                     static_cast<double>(B), value_loss_coef, entropy_coef, loss_out);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}

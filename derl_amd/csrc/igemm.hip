@@ -1,0 +1,436 @@
+// fp32-MFMA implicit GEMM kernels (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma chain).
+//
+// igemm_nt : C[m][n]  = epi(sum_k A(m,k) Wp[n][k])       conv forward, dgrad, linear layers
+// igemm_tn : dW[n][k] = sum_m G[m][n] A(m,k)              wgrad, reduction split over M
+//
+// A 32x32x2 MFMA takes ONE float of A and ONE of B per lane (lane l: row/col l&31, k = l>>5),
+// and issues every 64 cycles per SIMD, so operand traffic is small: the kernels stage tiles
+// through LDS with a register prefetch of the next tile (global loads overlap the MFMAs).
+//   NT: LDS rows are K-contiguous, stride 36 floats; a lane reads 4 consecutive k of its
+//       row with one ds_read_b128 (conflict-free at stride 36) and feeds 4 MFMAs.
+//   TN: LDS rows are the reduction index m; a lane reads one float per MFMA, consecutive
+//       lanes -> consecutive banks.
+#include "igemm.hpp"
+
+namespace dx {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// uint8 -> float / 255, bit-identical to IEEE division for every byte value: q = x*r, one
+// fma residual step (checked exhaustively on the host in tests/test_host_logic.py).
+__device__ __forceinline__ float dequant_u8(uint32_t x) {
+  const float r = 1.0f / 255.0f;
+  const float xf = static_cast<float>(x);
+  const float q = xf * r;
+  const float e = __builtin_fmaf(-q, 255.0f, xf);
+  return __builtin_fmaf(e, r, q);
+}
+
+template <bool U8>
+__device__ __forceinline__ float4 load4(const void *base, long long off, bool ok) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    if (U8) {
+      const uint32_t w = *reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + off);
+      v.x = dequant_u8(w & 0xff);
+      v.y = dequant_u8((w >> 8) & 0xff);
+      v.z = dequant_u8((w >> 16) & 0xff);
+      v.w = dequant_u8(w >> 24);
+    } else {
+      v = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off);
+    }
+  }
+  return v;
+}
+
+struct RowPos {
+  long long base;  // element offset of the row's origin pixel (channel 0)
+  int y0, x0;
+  bool valid;
+};
+
+__device__ __forceinline__ RowPos decode_row(const Gather &g, int m, bool valid) {
+  RowPos r;
+  const uint32_t mm = valid ? static_cast<uint32_t>(m) : 0u;
+  uint32_t img = fdiv(mm, g.div_img);
+  const uint32_t rem = mm - img * g.OHW;
+  const uint32_t oy = fdiv(rem, g.div_row);
+  const uint32_t ox = rem - oy * g.OW;
+  if (g.idx) img = static_cast<uint32_t>(g.idx[img]);
+  r.y0 = static_cast<int>(oy) * g.sy;
+  r.x0 = static_cast<int>(ox) * g.sx;
+  r.base = static_cast<long long>(img) * g.img_stride +
+           static_cast<long long>(r.y0 * g.W + r.x0) * g.C;
+  r.valid = valid;
+  return r;
+}
+
+__device__ __forceinline__ bool seg_ok(const Gather &g, const RowPos &r, int s) {
+  if (!g.check) return r.valid;
+  const int yy = r.y0 + g.seg_dy[s], xx = r.x0 + g.seg_dx[s];
+  return r.valid && static_cast<unsigned>(yy) < static_cast<unsigned>(g.H) &&
+         static_cast<unsigned>(xx) < static_cast<unsigned>(g.W);
+}
+
+__device__ __forceinline__ long long map_out_row(const OutMap &om, int m) {
+  if (!om.enabled) return m;
+  const uint32_t mm = static_cast<uint32_t>(m);
+  const uint32_t img = fdiv(mm, om.div_img);
+  const uint32_t rem = mm - img * om.OHW;
+  const uint32_t oy = fdiv(rem, om.div_row);
+  const uint32_t ox = rem - oy * om.OW;
+  return (static_cast<long long>(img) * om.OUT_H + oy * om.osy + om.ody) * om.OUT_W +
+         ox * om.osx + om.odx;
+}
+
+// ------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------
+// TAG only names the instantiation: every network stage gets its own kernel symbol, so a
+// rocprofv3 --stats row is one stage (one shape), not a mix of layers.
+template <int TAG, int BM, int BN, int WM, int WN, bool AU8, int EPI>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(const NTArgs a) {
+  constexpr int NWN = BN / WN;
+  constexpr int NT = 64 * (BM / WM) * NWN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LD = 36;        // 32 k + 4 pad floats: conflict-free ds_read_b128
+  constexpr int RPP = NT / 8;   // tile rows filled per pass (8 lanes x 4 k per row)
+  static_assert(BM % RPP == 0, "BM must be a multiple of the rows per pass");
+  constexpr int APASS = BM / RPP;
+  constexpr int BPASS = (BN + RPP - 1) / RPP;
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LD];
+  float *As = smem;
+  float *Bs = smem + BM * LD;
+
+  const Gather &g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kper = a.K / a.ksplit;
+  const int kbeg = blockIdx.z * kper, kend = kbeg + kper;
+  const int l8 = tid & 7, lr = tid >> 3;
+
+  RowPos rows[APASS];
+#pragma unroll
+  for (int p = 0; p < APASS; ++p) {
+    const int m = m0 + p * RPP + lr;
+    rows[p] = decode_row(g, m, m < a.M);
+  }
+  const float *wrow[BPASS];
+  bool wvalid[BPASS];
+#pragma unroll
+  for (int p = 0; p < BPASS; ++p) {
+    const int nr = p * RPP + lr;
+    wvalid[p] = nr < BN && (n0 + nr) < a.N;
+    wrow[p] = a.Wp + static_cast<long long>(wvalid[p] ? n0 + nr : 0) * a.K + 4 * l8;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int seg = kbeg / g.seglen, q = kbeg - seg * g.seglen;
+  float4 areg[APASS], breg[BPASS];
+  auto fetch = [&](int kt) {
+    const long long so = static_cast<long long>(g.seg_off[seg]) + q + 4 * l8;
+#pragma unroll
+    for (int p = 0; p < APASS; ++p)
+      areg[p] = load4<AU8>(g.src, rows[p].base + so, seg_ok(g, rows[p], seg));
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p)
+      breg[p] = wvalid[p] ? *reinterpret_cast<const float4 *>(wrow[p] + kt)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  fetch(kbeg);
+
+  for (int kt = kbeg; kt < kend; kt += 32) {
+    __syncthreads();  // everyone finished reading the previous tile
+#pragma unroll
+    for (int p = 0; p < APASS; ++p)
+      *reinterpret_cast<float4 *>(&As[(p * RPP + lr) * LD + 4 * l8]) = areg[p];
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p)
+      if (p * RPP + lr < BN) *reinterpret_cast<float4 *>(&Bs[(p * RPP + lr) * LD + 4 * l8]) = breg[p];
+    __syncthreads();
+    if (kt + 32 < kend) {  // prefetch the next tile; its latency hides under the MFMAs
+      q += 32;
+      if (q >= g.seglen) { q = 0; ++seg; }
+      fetch(kt + 32);
+    }
+    const int lrow = lane & 31, lk = 4 * (lane >> 5);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const float4 *>(&As[(wm0 + 32 * i + lrow) * LD + 8 * qd + lk]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const float4 *>(&Bs[(wn0 + 32 * j + lrow) * LD + 8 * qd + lk]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float *out = a.out + (a.ksplit > 1 ? blockIdx.z * a.slab_stride : 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= a.M) continue;
+      const long long orow = map_out_row(a.om, m);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + 32 * j + (lane & 31);
+        if (n >= a.N) continue;
+        float v = acc[i][j][r];
+        const long long o = orow * a.ldc + n;
+        if (a.ksplit == 1) {
+          if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) v += a.bias[n];
+          if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+          if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
+        }
+        out[o] = v;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// TN kernel (wgrad): reduction over M in steps of 32 rows
+// ------------------------------------------------------------------------------------
+template <int TAG, int BN, int BKO, int WN, int WK, bool AU8>
+__global__ __launch_bounds__(64 * (BN / WN) * (BKO / WK)) void igemm_tn_kernel(const TNArgs a) {
+  constexpr int NWK = BKO / WK;
+  constexpr int NT = 64 * (BN / WN) * NWK;
+  constexpr int TN = WN / 32, TK = WK / 32;
+  constexpr int BMS = 32;
+  constexpr int ATPR = BKO / 4;     // threads per A row
+  constexpr int ARPP = NT / ATPR;   // A rows per pass
+  static_assert(NT % ATPR == 0 && BMS % ARPP == 0, "A tile does not divide");
+  constexpr int APASS = BMS / ARPP;
+  constexpr int GTPR = BN / 4;
+  constexpr int GRPP = NT / GTPR;
+  static_assert(NT % GTPR == 0, "G tile does not divide");
+  constexpr int GPASS = (BMS + GRPP - 1) / GRPP;
+  __shared__ __attribute__((aligned(16))) float smem[BMS * (BN + BKO)];
+  float *Gs = smem;
+  float *As = smem + BMS * BN;
+
+  const Gather &g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn0 = (wave / NWK) * WN, wk0 = (wave % NWK) * WK;
+  const int k0 = blockIdx.x * BKO, n0 = blockIdx.y * BN;
+  const int mbeg = blockIdx.z * a.mper;
+  const int mend = min(a.M, mbeg + a.mper);
+
+  // this thread's fixed k position (4 consecutive k inside one run)
+  const int akq = tid % ATPR, arow = tid / ATPR;
+  const int k = k0 + 4 * akq;
+  const bool kvalid = k < a.K;
+  const int seg = kvalid ? k / g.seglen : 0;
+  const long long segoff = static_cast<long long>(g.seg_off[seg]) + (kvalid ? k - seg * g.seglen : 0);
+  const int gnq = tid % GTPR, grow = tid / GTPR;
+  const bool nvalid = (n0 + 4 * gnq) < a.N;
+
+  f32x16 acc[TN][TK];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bias_acc = 0.f;
+
+  float4 areg[APASS], greg[GPASS];
+  auto fetch = [&](int ms) {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      const int m = ms + p * ARPP + arow;
+      const RowPos r = decode_row(g, m, m < mend && kvalid);
+      areg[p] = load4<AU8>(g.src, r.base + segoff, seg_ok(g, r, seg));
+    }
+#pragma unroll
+    for (int p = 0; p < GPASS; ++p) {
+      const int mr = p * GRPP + grow;
+      const int m = ms + mr;
+      greg[p] = (mr < BMS && m < mend && nvalid)
+                    ? *reinterpret_cast<const float4 *>(a.G + static_cast<long long>(m) * a.ldg + n0 + 4 * gnq)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (mbeg < mend) fetch(mbeg);
+
+  for (int ms = mbeg; ms < mend; ms += BMS) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < APASS; ++p)
+      *reinterpret_cast<float4 *>(&As[(p * ARPP + arow) * BKO + 4 * akq]) = areg[p];
+#pragma unroll
+    for (int p = 0; p < GPASS; ++p)
+      if (p * GRPP + grow < BMS)
+        *reinterpret_cast<float4 *>(&Gs[(p * GRPP + grow) * BN + 4 * gnq]) = greg[p];
+    __syncthreads();
+    if (ms + BMS < mend) fetch(ms + BMS);
+    if (a.bias_slab && blockIdx.x == 0 && tid < BN) {
+#pragma unroll 8
+      for (int r = 0; r < BMS; ++r) bias_acc += Gs[r * BN + tid];
+    }
+    const int lcol = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < BMS / 2; ++e) {
+      float gf[TN], af[TK];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) gf[i] = Gs[(2 * e + lh) * BN + wn0 + 32 * i + lcol];
+#pragma unroll
+      for (int j = 0; j < TK; ++j) af[j] = As[(2 * e + lh) * BKO + wk0 + 32 * j + lcol];
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  float *slab = a.slab + static_cast<long long>(blockIdx.z) * a.N * a.K;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int j = 0; j < TK; ++j) {
+        const int kk = k0 + wk0 + 32 * j + (lane & 31);
+        if (kk < a.K) slab[static_cast<long long>(n) * a.K + kk] = acc[i][j][r];
+      }
+    }
+  if (a.bias_slab && blockIdx.x == 0 && tid < BN && n0 + tid < a.N)
+    a.bias_slab[static_cast<long long>(blockIdx.z) * a.N + n0 + tid] = bias_acc;
+}
+
+// ------------------------------------------------------------------------------------
+// strided permute + slab reduction (weight packing, gradient finalisation)
+// ------------------------------------------------------------------------------------
+struct JobTable {
+  PermuteJob jobs[kMaxJobs];
+};
+
+__global__ __launch_bounds__(256) void permute_reduce_kernel(const JobTable t) {
+  const PermuteJob &j = t.jobs[blockIdx.y];
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < j.total;
+       i += stride) {
+    long long rest = i;
+    const long long d3 = rest % j.D3; rest /= j.D3;
+    const long long d2 = rest % j.D2; rest /= j.D2;
+    const long long d1 = rest % j.D1; rest /= j.D1;
+    const long long s = j.off + rest * j.s0 + d1 * j.s1 + d2 * j.s2 + d3 * j.s3;
+    float v = 0.f;
+    for (int z = 0; z < j.nslab; ++z) v += j.src[z * j.slab_stride + s];
+    j.dst[i] = v;
+  }
+}
+
+template <int TAG, int BM, int BN, int WM, int WN, bool AU8, int EPI>
+int launch_nt_as(const NTArgs &a, hipStream_t stream) {
+  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.ksplit);
+  dim3 block(64 * (BM / WM) * (BN / WN));
+  hipLaunchKernelGGL((igemm_nt_kernel<TAG, BM, BN, WM, WN, AU8, EPI>), grid, block, 0, stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+template <int TAG, int BN, int BKO, int WN, int WK, bool AU8>
+int launch_tn_as(const TNArgs &a, hipStream_t stream) {
+  dim3 grid(cdiv(a.K, BKO), cdiv(a.N, BN), a.msplit);
+  hipLaunchKernelGGL((igemm_tn_kernel<TAG, BN, BKO, WN, WK, AU8>), grid,
+                     dim3(64 * (BN / WN) * (BKO / WK)), 0, stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+}  // namespace
+
+// tile shape per stage: N <= 32 -> 256x32 block tile (4 waves of 64x32); otherwise 128x64
+// (4 waves of 64x32).  wgrad: N <= 32 -> [32 x 256] output tile, else [64 x 128].
+int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream) {
+  DX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "igemm_nt: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  DX_REQUIRE(a.g.seglen % 32 == 0 && a.g.nseg * a.g.seglen == a.K && a.g.nseg <= kMaxSeg,
+             "igemm_nt: K=%d must be nseg(%d) x seglen(%d), seglen %% 32 == 0", a.K, a.g.nseg,
+             a.g.seglen);
+  DX_REQUIRE(a.ksplit >= 1 && a.K % (32 * a.ksplit) == 0, "igemm_nt: K=%d not divisible by 32*ksplit(%d)",
+             a.K, a.ksplit);
+  DX_REQUIRE(a.g.src && a.Wp && a.out, "igemm_nt: null pointer");
+  DX_REQUIRE(a.M < (1 << 30), "igemm_nt: M too large");
+  switch (stage) {
+    case ST_CONV0_FWD:
+      DX_REQUIRE(epi == EPI_BIAS_RELU && a.N <= 32, "igemm_nt: conv0 forward needs bias+relu, N <= 32");
+      return a_u8 ? launch_nt_as<ST_CONV0_FWD, 256, 32, 64, 32, true, EPI_BIAS_RELU>(a, stream)
+                  : launch_nt_as<ST_CONV0_FWD, 256, 32, 64, 32, false, EPI_BIAS_RELU>(a, stream);
+    case ST_CONV1_FWD: return launch_nt_as<ST_CONV1_FWD, 128, 64, 64, 32, false, EPI_BIAS_RELU>(a, stream);
+    case ST_CONV2_FWD: return launch_nt_as<ST_CONV2_FWD, 128, 64, 64, 32, false, EPI_BIAS_RELU>(a, stream);
+    case ST_FC_FWD: return launch_nt_as<ST_FC_FWD, 128, 64, 64, 32, false, EPI_BIAS>(a, stream);
+    case ST_HEADS_FWD: return launch_nt_as<ST_HEADS_FWD, 256, 32, 64, 32, false, EPI_BIAS>(a, stream);
+    case ST_HEADS_DGRAD: return launch_nt_as<ST_HEADS_DGRAD, 128, 64, 64, 32, false, EPI_NONE>(a, stream);
+    case ST_FC_DGRAD: return launch_nt_as<ST_FC_DGRAD, 128, 64, 64, 32, false, EPI_MASK>(a, stream);
+    case ST_CONV2_DGRAD: return launch_nt_as<ST_CONV2_DGRAD, 128, 64, 64, 32, false, EPI_MASK>(a, stream);
+    case ST_CONV1_DGRAD: return launch_nt_as<ST_CONV1_DGRAD, 256, 32, 64, 32, false, EPI_MASK>(a, stream);
+    default: return fail(DX_EINVAL, "igemm_nt: unknown stage %d", stage);
+  }
+}
+
+int launch_tn(const TNArgs &a, bool a_u8, int stage, hipStream_t stream) {
+  DX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "igemm_tn: empty problem");
+  DX_REQUIRE(a.g.seglen % 4 == 0 && a.g.nseg * a.g.seglen == a.K && a.g.nseg <= kMaxSeg,
+             "igemm_tn: bad K decomposition");
+  DX_REQUIRE(a.mper % 32 == 0 && a.msplit >= 1 && static_cast<long long>(a.mper) * a.msplit >= a.M,
+             "igemm_tn: bad M split (mper=%d msplit=%d M=%d)", a.mper, a.msplit, a.M);
+  DX_REQUIRE(a.g.src && a.G && a.slab, "igemm_tn: null pointer");
+  DX_REQUIRE(a.N % 4 == 0 && a.ldg % 4 == 0, "igemm_tn: N and ldg must be multiples of 4");
+  switch (stage) {
+    case ST_HEADS_WGRAD: return launch_tn_as<ST_HEADS_WGRAD, 32, 256, 32, 64, false>(a, stream);
+    case ST_FC_WGRAD: return launch_tn_as<ST_FC_WGRAD, 64, 128, 64, 32, false>(a, stream);
+    case ST_CONV2_WGRAD: return launch_tn_as<ST_CONV2_WGRAD, 64, 128, 64, 32, false>(a, stream);
+    case ST_CONV1_WGRAD: return launch_tn_as<ST_CONV1_WGRAD, 64, 128, 64, 32, false>(a, stream);
+    case ST_CONV0_WGRAD:
+      return a_u8 ? launch_tn_as<ST_CONV0_WGRAD, 32, 256, 32, 64, true>(a, stream)
+                  : launch_tn_as<ST_CONV0_WGRAD, 32, 256, 32, 64, false>(a, stream);
+    default: return fail(DX_EINVAL, "igemm_tn: unknown stage %d", stage);
+  }
+}
+
+int launch_permute_reduce(const PermuteJob *jobs, int njobs, hipStream_t stream) {
+  DX_REQUIRE(njobs >= 0 && njobs <= kMaxJobs, "permute_reduce: %d jobs (max %d)", njobs, kMaxJobs);
+  if (njobs == 0) return DX_OK;
+  JobTable t;
+  long long biggest = 0;
+  for (int i = 0; i < njobs; ++i) {
+    DX_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].nslab >= 1 && jobs[i].D1 > 0 && jobs[i].D2 > 0 &&
+                   jobs[i].D3 > 0,
+               "permute_reduce: bad job %d", i);
+    t.jobs[i] = jobs[i];
+    if (jobs[i].total > biggest) biggest = jobs[i].total;
+  }
+  int bx = cdiv(biggest, 256 * 4);
+  if (bx > 2048) bx = 2048;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(permute_reduce_kernel, dim3(bx, njobs), dim3(256), 0, stream, t);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+}  // namespace dx

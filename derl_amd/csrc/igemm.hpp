@@ -1,0 +1,110 @@
+// Implicit-GEMM building blocks for the Nature-DQN conv stack on fp32 MFMA (gfx950).
+//
+// Activations are pixel-major NHWC ([img][y][x][c], fp32; the observation may be uint8),
+// so the K axis of every contraction is cut into `nseg` contiguous runs of `seglen`
+// elements: a forward conv row is KH runs of KW*IC elements, a dgrad row is one run of OC
+// elements per kernel tap, a linear layer is a single run.  Weights are read from packed
+// mirrors laid out [N][K] in that same K order (dx_permute_reduce builds them from the
+// canonical state_dict layout).
+#pragma once
+#include "common.hpp"
+
+namespace dx {
+
+// exact n / d for n < 2^31 (Granlund-Montgomery, N = 31): q = umulhi(n, magic) >> shift
+struct FastDiv {
+  uint32_t magic, shift, d;
+};
+
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f{0u, 0u, d};
+  if (d <= 1) return f;
+  uint32_t L = 0;
+  while ((1ull << L) < d) ++L;
+  f.magic = static_cast<uint32_t>((1ull << (31 + L)) / d + 1);
+  f.shift = L - 1;
+  return f;
+}
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
+  return f.d <= 1 ? n : (__umulhi(n, f.magic) >> f.shift);
+}
+
+constexpr int kMaxSeg = 16;
+
+// Row m of the implicit A matrix: m -> (img, oy, ox); run s starts at source pixel
+// (oy*sy + dy[s], ox*sx + dx[s]), channel coff[s], and is `seglen` contiguous elements.
+struct Gather {
+  const void *src;       // NHWC activations (float or uint8)
+  const int32_t *idx;    // optional image gather (minibatch by permutation), or nullptr
+  long long img_stride;  // H*W*C elements
+  int H, W, C;
+  FastDiv div_img, div_row;  // by OH*OW and by OW
+  int OHW, OW;
+  int sy, sx;
+  int nseg, seglen;
+  int check;             // runs may start outside the image -> zero fill
+  int seg_off[kMaxSeg];  // (dy*W + dx)*C + coff
+  int8_t seg_dy[kMaxSeg], seg_dx[kMaxSeg];
+};
+
+// Output row of GEMM row m (identity unless `enabled`): used by the strided dgrad, whose
+// rows are one parity class of the input pixels.
+struct OutMap {
+  int enabled;
+  FastDiv div_img, div_row;
+  int OHW, OW;
+  int OUT_H, OUT_W, osy, osx, ody, odx;
+};
+
+enum Epilogue { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3 };
+
+// C[m][n] = epi(sum_k A(m,k) * Wp[n][k])
+struct NTArgs {
+  Gather g;
+  OutMap om;
+  const float *Wp;        // [N][K]
+  const float *bias;      // [N]
+  const float *mask_src;  // EPI_MASK: zero where mask_src[out_row][n] <= 0
+  float *out;
+  int ldc;
+  int M, N, K;
+  int ksplit;             // > 1: raw partial sums into slabs out + z*slab_stride
+  long long slab_stride;
+};
+
+// slab[z][n][k] = sum_{m in slice z} G[m][n] * A(m,k);  bias_slab[z][n] = sum_m G[m][n]
+struct TNArgs {
+  Gather g;
+  const float *G;  // [M][ldg]
+  int ldg;
+  float *slab;     // [msplit][N][K]
+  float *bias_slab;  // [msplit][N] or nullptr
+  int M, N, K;
+  int msplit, mper;  // mper % 32 == 0
+};
+
+// network stages: one kernel instantiation (= one profiler row) each
+enum Stage {
+  ST_CONV0_FWD = 0, ST_CONV1_FWD, ST_CONV2_FWD, ST_FC_FWD, ST_HEADS_FWD,
+  ST_HEADS_WGRAD, ST_HEADS_DGRAD, ST_FC_WGRAD, ST_FC_DGRAD, ST_CONV2_WGRAD, ST_CONV2_DGRAD,
+  ST_CONV1_WGRAD, ST_CONV1_DGRAD, ST_CONV0_WGRAD, ST_FINALIZE, ST_COUNT
+};
+
+int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream);
+int launch_tn(const TNArgs &a, bool a_u8, int stage, hipStream_t stream);
+
+// dst[i] = scale * sum_z src[z*slab_stride + off + d0*s0 + d1*s1 + d2*s2 + d3*s3], i = ((d0*D1+d1)*D2+d2)*D3+d3
+struct PermuteJob {
+  const float *src;
+  float *dst;
+  long long total;
+  int D1, D2, D3;
+  long long s0, s1, s2, s3, off;
+  int nslab;
+  long long slab_stride;
+};
+constexpr int kMaxJobs = 24;
+int launch_permute_reduce(const PermuteJob *jobs, int njobs, hipStream_t stream);
+
+}  // namespace dx

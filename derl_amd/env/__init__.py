@@ -1,0 +1,48 @@
+"""Environment construction with derl's entry point ``derl.env.make(env_id, nenvs, seed)``
+(derl/env/make_env.py:170-185).  The real Atari / MuJoCo wrapper stacks are outside this
+build's scope; ids of those families map to device-resident synthetic envs
+with the same observation / action contract, and CartPole-v1 is built in."""
+from .spaces import Box, Discrete, Space, is_box, is_discrete
+from .synthetic import SyntheticAtariEnv, SyntheticMuJoCoEnv
+from .cartpole import CartPoleBatch
+
+ATARI_ACTIONS = {"Breakout": 4, "SpaceInvaders": 6, "Pong": 6, "BeamRider": 9, "Qbert": 6,
+                 "Seaquest": 18, "Enduro": 9}
+MUJOCO_DIMS = {"HalfCheetah": (17, 6), "Hopper": (11, 3), "Walker2d": (17, 6), "Ant": (111, 8),
+               "Swimmer": (8, 2), "Reacher": (11, 2), "InvertedPendulum": (4, 1),
+               "InvertedDoublePendulum": (11, 1), "Humanoid": (376, 17)}
+
+
+def _base_name(env_id):
+  name = env_id[:env_id.rfind("-")] if "-" in env_id else env_id
+  for postfix in ("Deterministic", "NoFrameskip", "BulletEnv"):
+    if name.endswith(postfix):
+      name = name[:-len(postfix)]
+  return name
+
+
+def is_atari_id(env_id):
+  """derl/env/make_env.py:48-57 (game list reduced to the table above)."""
+  return _base_name(env_id) in ATARI_ACTIONS
+
+
+def is_mujoco_id(env_id):
+  """derl/env/make_env.py:60-66."""
+  return _base_name(env_id) in MUJOCO_DIMS
+
+
+def make(env_id, nenvs=None, seed=0, device="cuda", rank=0, **kwargs):
+  """Creates a batched env.  nenvs=None means one env (derl's unbatched case maps to a
+  batch of 1 here)."""
+  del kwargs
+  seed = 0 if seed is None else seed
+  if env_id.startswith("CartPole"):
+    return CartPoleBatch(nenvs or 1, seed)
+  if is_atari_id(env_id):
+    return SyntheticAtariEnv(nenvs or 1, ATARI_ACTIONS[_base_name(env_id)], seed,
+                             device=device, rank=rank)
+  if is_mujoco_id(env_id):
+    obs_dim, act_dim = MUJOCO_DIMS[_base_name(env_id)]
+    return SyntheticMuJoCoEnv(nenvs or 1, obs_dim, act_dim, seed, device=device, rank=rank)
+  raise ValueError(f"unknown env id {env_id!r}: this build provides CartPole-v1 and synthetic "
+                   f"stand-ins for {sorted(ATARI_ACTIONS)} / {sorted(MUJOCO_DIMS)}")

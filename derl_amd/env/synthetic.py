@@ -1,0 +1,92 @@
+"""Device-resident synthetic batched environments for the headline metric (SURVEY.md 8d:
+ALE / MuJoCo are absent, the metric is quoted on synthetic frames).
+
+They follow derl's batched-env contract (derl/env/env_batch.py:35-134): ``nenvs``,
+``observation_space`` / ``action_space`` of ONE env, ``reset() -> obs``,
+``step(actions) -> (obs, rewards, resets, infos)`` with auto-reset.  Observations, rewards
+and resets are produced on the GPU from a counter-based generator and never visit the
+host; ``step(..., out=slot)`` writes the next frame batch straight into a rollout-buffer
+slot."""
+import numpy as np
+import torch
+
+from .. import _lib
+from .spaces import Box, Discrete
+
+
+class SyntheticAtariEnv:
+  """uint8 (nenvs, 84, 84, 4) frames i.i.d. uniform 0..255; rewards sign(n)*[u<0.1] in
+  {-1,0,1}; resets Bernoulli(0.01) (derl/env/make_env.py:132-133 obs contract,
+  derl/env/atari_wrappers.py:189-192 reward contract)."""
+
+  def __init__(self, nenvs, num_actions=4, seed=0, obs_shape=(84, 84, 4), p_reset=0.01,
+               device="cuda", rank=0):
+    self.nenvs = int(nenvs)
+    self.unwrapped = self
+    self.device = torch.device(device)
+    self.observation_space = Box(0, 255, obs_shape, np.uint8)
+    self.action_space = Discrete(num_actions)
+    self.p_reset = p_reset
+    self.seed = int(seed) * 1000003 + int(rank)
+    self.counter = 0
+
+  def _generate(self, out, rewards=None, resets=None):
+    shape = (self.nenvs,) + self.observation_space.shape
+    if out is None:
+      out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.uint8 or not out.is_contiguous():
+      raise ValueError(f"out must be a contiguous uint8 tensor of shape {shape}")
+    _lib.call("dx_synth_atari_step", _lib.ptr(out), out.numel(), _lib.ptr(rewards),
+              _lib.ptr(resets), self.nenvs, self.seed, self.counter, 0.1, float(self.p_reset),
+              _lib.stream_ptr(self.device))
+    self.counter += 1
+    return out
+
+  def reset(self, out=None):
+    return self._generate(out)
+
+  def step(self, actions, out=None, rewards_out=None, resets_out=None):
+    del actions  # the synthetic dynamics ignore the action
+    rewards = rewards_out if rewards_out is not None else torch.empty(
+        self.nenvs, dtype=torch.float32, device=self.device)
+    resets = resets_out if resets_out is not None else torch.empty(
+        self.nenvs, dtype=torch.bool, device=self.device)
+    obs = self._generate(out, rewards, resets)
+    return obs, rewards, resets, None
+
+
+class SyntheticMuJoCoEnv:
+  """float32 (nenvs, obs_dim) N(0,1) observations clipped to +-10 (the range
+  derl/env/mujoco_wrappers.py:64-124 Normalize produces), rewards N(0,1), resets
+  Bernoulli(0.001)."""
+
+  def __init__(self, nenvs, obs_dim=17, act_dim=6, seed=0, p_reset=0.001, device="cuda", rank=0):
+    self.nenvs = int(nenvs)
+    self.unwrapped = self
+    self.device = torch.device(device)
+    self.observation_space = Box(-10., 10., (obs_dim,), np.float32)
+    self.action_space = Box(-1., 1., (act_dim,), np.float32)
+    self.p_reset = p_reset
+    self.generator = torch.Generator(device=self.device)
+    self.generator.manual_seed(int(seed) * 1000003 + int(rank))
+
+  def _obs(self, out=None):
+    shape = (self.nenvs,) + self.observation_space.shape
+    if out is None:
+      out = torch.empty(shape, dtype=torch.float32, device=self.device)
+    out.normal_(generator=self.generator).clamp_(-10., 10.)
+    return out
+
+  def reset(self, out=None):
+    return self._obs(out)
+
+  def step(self, actions, out=None, rewards_out=None, resets_out=None):
+    del actions
+    obs = self._obs(out)
+    rewards = torch.randn(self.nenvs, device=self.device, generator=self.generator)
+    resets = torch.rand(self.nenvs, device=self.device, generator=self.generator) < self.p_reset
+    if rewards_out is not None:
+      rewards = rewards_out.copy_(rewards)
+    if resets_out is not None:
+      resets = resets_out.copy_(resets)
+    return obs, rewards, resets, None

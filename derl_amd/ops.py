@@ -46,3 +46,119 @@ def gae(rewards, resets, values, last_values, gamma, lambda_, out_advantages=Non
             _lib.ptr(last_values), T, N, float(gamma), float(lambda_), _lib.ptr(adv),
             _lib.ptr(vt), _lib.stream_ptr(rewards.device))
   return adv, vt
+
+
+def adv_normalize(advantages, epsilon=1e-8, out=None, stats=None, stats_ready=False):
+  """(a - mean) / (std + eps) on the device (trajectory_transforms.py:89-92).  ``stats`` is a
+  float64[3] device tensor {sum, sumsq, count}; pass stats_ready=True to reuse reduced stats."""
+  _dev(advantages, "advantages", torch.float32)
+  out = torch.empty_like(advantages) if out is None else _dev(out, "out", torch.float32)
+  if stats is None:
+    stats = torch.empty(3, dtype=torch.float64, device=advantages.device)
+  _lib.call("dx_adv_normalize_f32", _lib.ptr(advantages), _lib.ptr(out), advantages.numel(),
+            float(epsilon), _lib.ptr(stats), int(stats_ready), _lib.stream_ptr(advantages.device))
+  return out
+
+
+def adv_stats(advantages, stats=None):
+  _dev(advantages, "advantages", torch.float32)
+  if stats is None:
+    stats = torch.empty(3, dtype=torch.float64, device=advantages.device)
+  _lib.call("dx_adv_stats_f32", _lib.ptr(advantages), advantages.numel(), _lib.ptr(stats),
+            _lib.stream_ptr(advantages.device))
+  return stats
+
+
+NORM_PARTIALS = 256
+
+
+def grad_sumsq(grads, partials=None):
+  _dev(grads, "grads", torch.float32)
+  if partials is None:
+    partials = torch.empty(NORM_PARTIALS, dtype=torch.float64, device=grads.device)
+  _lib.call("dx_grad_sumsq_f32", _lib.ptr(grads), grads.numel(), _lib.ptr(partials),
+            partials.numel(), _lib.stream_ptr(grads.device))
+  return partials
+
+
+def clip_adam_step(params, grads, exp_avg, exp_avg_sq, partials, max_norm, lr, step,
+                   beta1=0.9, beta2=0.999, eps=1e-8, norm_out=None):
+  for name, t in (("params", params), ("grads", grads), ("exp_avg", exp_avg),
+                  ("exp_avg_sq", exp_avg_sq)):
+    _dev(t, name, torch.float32)
+  _lib.call("dx_clip_adam_step_f32", _lib.ptr(params), _lib.ptr(grads), _lib.ptr(exp_avg),
+            _lib.ptr(exp_avg_sq), params.numel(), _lib.ptr(partials),
+            0 if partials is None else partials.numel(),
+            float(max_norm) if max_norm is not None else 0.0, float(lr), float(beta1),
+            float(beta2), float(eps), int(step), _lib.ptr(norm_out),
+            _lib.stream_ptr(params.device))
+
+
+def clip_rmsprop_step(params, grads, square_avg, partials, max_norm, lr, alpha=0.99, eps=1e-8,
+                      norm_out=None):
+  for name, t in (("params", params), ("grads", grads), ("square_avg", square_avg)):
+    _dev(t, name, torch.float32)
+  _lib.call("dx_clip_rmsprop_step_f32", _lib.ptr(params), _lib.ptr(grads), _lib.ptr(square_avg),
+            params.numel(), _lib.ptr(partials), 0 if partials is None else partials.numel(),
+            float(max_norm) if max_norm is not None else 0.0, float(lr), float(alpha), float(eps),
+            _lib.ptr(norm_out), _lib.stream_ptr(params.device))
+
+
+def gather_rows(src, idx, out=None):
+  """out[i] = src[idx[i]] along dim 0 (idx int32 on the device)."""
+  _dev(src, "src")
+  _dev(idx, "idx", torch.int32)
+  n = idx.numel()
+  out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device) if out is None else out
+  row_bytes = src.element_size()
+  for d in src.shape[1:]:
+    row_bytes *= d
+  _lib.call("dx_gather_rows", _lib.ptr(src), _lib.ptr(idx), _lib.ptr(out), n, row_bytes,
+            _lib.stream_ptr(src.device))
+  return out
+
+
+def categorical_act(head_out, num_actions, uniforms=None, seed=0, counter=0, out=None):
+  """Sample / log_prob / value from the padded head output (B, 32) (policies.py:61-80).
+  ``out`` = (actions int64 (B,), log_prob f32 (B,), values f32 (B,)) to write in place."""
+  _dev(head_out, "head_out", torch.float32)
+  B = head_out.shape[0]
+  dev = head_out.device
+  if out is not None:
+    actions, log_prob, values = out
+    _dev(actions, "actions", torch.int64)
+    _dev(log_prob, "log_prob", torch.float32)
+    _dev(values, "values", torch.float32)
+    if actions.numel() != B or log_prob.numel() != B or values.numel() != B:
+      raise ValueError("categorical_act: output buffers must hold B elements")
+  else:
+    actions = torch.empty(B, dtype=torch.int64, device=dev)
+    log_prob = torch.empty(B, dtype=torch.float32, device=dev)
+    values = torch.empty(B, dtype=torch.float32, device=dev)
+  if uniforms is not None:
+    _dev(uniforms, "uniforms", torch.float32)
+  _lib.call("dx_categorical_act_f32", _lib.ptr(head_out), B, int(num_actions), _lib.ptr(uniforms),
+            int(seed), int(counter), _lib.ptr(actions), _lib.ptr(log_prob), _lib.ptr(values),
+            _lib.stream_ptr(dev))
+  return actions, log_prob, values
+
+
+def categorical_loss(head_out, actions, old_log_prob, advantages, old_values, value_targets,
+                     num_actions, mode, cliprange, value_loss_coef, entropy_coef, dhead_out,
+                     global_batch=0, partials=None, loss_out=None):
+  """Fused PPO (mode 0) / A2C (mode 1) loss + gradient w.r.t. the head output."""
+  _dev(head_out, "head_out", torch.float32)
+  B = head_out.shape[0]
+  dev = head_out.device
+  need = 8 * ((B + 7) // 8)
+  if partials is None or partials.numel() < need:
+    partials = torch.empty(need, dtype=torch.float64, device=dev)
+  if loss_out is None:
+    loss_out = torch.empty(8, dtype=torch.float32, device=dev)
+  _lib.call("dx_categorical_loss_f32", _lib.ptr(head_out), _lib.ptr(actions),
+            _lib.ptr(old_log_prob), _lib.ptr(advantages), _lib.ptr(old_values),
+            _lib.ptr(value_targets), B, int(num_actions), int(mode),
+            -1.0 if cliprange is None else float(cliprange), float(value_loss_coef),
+            float(entropy_coef), int(global_batch), _lib.ptr(dhead_out), _lib.ptr(partials),
+            partials.numel(), _lib.ptr(loss_out), _lib.stream_ptr(dev))
+  return loss_out

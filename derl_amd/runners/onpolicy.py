@@ -1,0 +1,111 @@
+"""On-policy runner wrappers (derl/runners/onpolicy.py:11-82)."""
+import numpy as np
+import torch
+
+from .env_runner import EnvRunner, RunnerWrapper
+from .summary import PeriodicSummaries
+from .trajectory_transforms import GAE, MergeTimeBatch, NormalizeAdvantages
+from .. import ops
+from ..models import GatheredRows
+
+# arrays whose rows are at least this big are referenced by index instead of copied
+LAZY_ROW_BYTES = 4096
+
+
+class TransformInteractions(RunnerWrapper):
+  """Transforms interactions by applying a list of callables (onpolicy.py:11-30).  Lists
+  from the generic runner are stacked (``np.asarray`` / ``torch.stack``); the
+  device-resident runner already yields whole ``(T, N, ...)`` buffers."""
+  def __init__(self, runner, transforms=None, asarray=True):
+    super().__init__(runner)
+    self.transforms = transforms or []
+    self.asarray = asarray
+
+  def run(self, obs=None):
+    for interactions in self.runner.run(obs=obs):
+      if self.asarray:
+        for key, val in interactions.items():
+          if key == "state" or not isinstance(val, list):
+            continue
+          try:
+            if val and isinstance(val[0], torch.Tensor):
+              interactions[key] = torch.stack(val)
+            else:
+              interactions[key] = np.asarray(val)
+          except ValueError:
+            raise ValueError(
+                f"cannot convert value under key '{key}' to np.ndarray")
+      for transform in self.transforms:
+        transform(interactions)
+      yield interactions
+
+
+class IterateWithMinibatches(RunnerWrapper):
+  """Iterates over interactions with minibatches for a given number of epochs
+  (onpolicy.py:33-62).
+
+  The reference shuffles every array in place before each epoch (the shuffles compose) and
+  then copies minibatch slices.  Here the composed permutation is kept as an index vector:
+  small per-sample arrays are gathered on the device, arrays with big rows (frames) are
+  yielded as ``GatheredRows(base, index)`` and gathered inside the conv loader -- same
+  samples in the same order (``np.random.permutation`` stream as the reference), no copies
+  of the frame buffers."""
+  def __init__(self, runner, num_epochs=3, num_minibatches=4, shuffle_before_epoch=True):
+    super().__init__(runner)
+    self.num_epochs = num_epochs
+    self.num_minibatches = num_minibatches
+    self.shuffle_before_epoch = shuffle_before_epoch
+
+  @staticmethod
+  def _select(val, index_dev, index_host):
+    if isinstance(val, torch.Tensor) and val.is_cuda:
+      row_bytes = val.element_size() * int(np.prod(val.shape[1:], dtype=np.int64))
+      if row_bytes >= LAZY_ROW_BYTES:
+        return GatheredRows(val, index_dev)
+      return ops.gather_rows(val.contiguous(), index_dev)
+    if isinstance(val, torch.Tensor):
+      return val[torch.from_numpy(index_host.astype(np.int64))]
+    if isinstance(val, np.ndarray):
+      return val[index_host]
+    return val
+
+  def run(self, obs=None):
+    for interactions in self.runner.run(obs=obs):
+      sample_size = interactions["observations"].shape[0]
+      order = np.arange(sample_size)
+      device = None
+      for val in interactions.values():
+        if isinstance(val, torch.Tensor) and val.is_cuda:
+          device = val.device
+          break
+      for _ in range(self.num_epochs):
+        if self.shuffle_before_epoch:
+          order = order[np.random.permutation(sample_size)]
+        order_dev = (torch.from_numpy(order.astype(np.int32)).to(device)
+                     if device is not None else None)
+        mbsize = sample_size // self.num_minibatches
+        for start in range(0, sample_size, mbsize):
+          stop = min(start + mbsize, sample_size)
+          index_host = order[start:stop]
+          index_dev = order_dev[start:stop] if order_dev is not None else None
+          yield dict((key, self._select(val, index_dev, index_host)) if key != "state"
+                     else (key, val) for key, val in interactions.items())
+
+
+def ppo_runner_wrap(runner, gamma=0.99, lambda_=0.95, num_epochs=3, num_minibatches=4):
+  """Wraps given runner for PPO training (onpolicy.py:65-75)."""
+  env, policy = runner.env, runner.policy
+  transforms = [GAE(policy, gamma=gamma, lambda_=lambda_, normalize=False)]
+  if not policy.is_recurrent() and getattr(env.unwrapped, "nenvs", None):
+    transforms.append(MergeTimeBatch())
+  runner = TransformInteractions(runner, transforms)
+  runner = IterateWithMinibatches(runner, num_epochs, num_minibatches)
+  runner = TransformInteractions(runner, [NormalizeAdvantages()])
+  return runner
+
+
+def make_ppo_runner(env, policy, horizon, nsteps, nlogs=1e5, **wrap_kwargs):
+  """Creates and wraps env runner for PPO training (onpolicy.py:78-82)."""
+  runner = EnvRunner(env, policy, horizon, nsteps)
+  runner = PeriodicSummaries.make_with_nlogs(runner, nlogs)
+  return ppo_runner_wrap(runner, **wrap_kwargs)

@@ -59,6 +59,132 @@ int dx_gae_f32(const float *rewards, const uint8_t *resets, const float *values,
                const float *last_values, int T, int N, float gamma, float lambda,
                float *advantages, float *value_targets, void *stream);
 
+
+/* ---------------------------------------------------------------------------------
+ * Advantage normalisation -- replaces derl/runners/trajectory_transforms.py:89-92
+ * (NormalizeAdvantages): out = (a - mean) / (std + eps), population std.
+ * `stats` = 3 doubles {sum, sum of squares, count}.  With stats_ready = 0 they are
+ * computed here; with stats_ready = 1 the caller supplies them (e.g. after summing the
+ * per-GPU shards' stats with one small all-reduce).
+ * Algorithmic traffic: 4 B read + 4 B written per element (+ one read for the stats).
+ * --------------------------------------------------------------------------------- */
+int dx_adv_stats_f32(const float *advantages, long long n, double *stats, void *stream);
+int dx_adv_normalize_f32(const float *advantages, float *out, long long n, float eps,
+                         double *stats, int stats_ready, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Global gradient norm, clipping and the optimizer step -- replaces
+ * derl/alg/common.py:56-64,76 (Trainer.preprocess_gradients = torch clip_grad_norm_,
+ * optimizer.step) for the optimizers configured in derl/factory/ppo.py:78-81 (Adam,
+ * eps=1e-5) and derl/factory/a2c.py:68-73 (RMSprop alpha=.99, eps=1e-5), over the FLAT
+ * parameter / gradient buffers (reference state_dict order).
+ *   dx_grad_sumsq_f32: partials[i] = float64 partial sums of g^2 (npartials blocks);
+ *   step kernels     : coef = min(1, max_norm / (sqrt(sum partials) + 1e-6)) (max_norm <= 0:
+ *                      no clipping); g <- g*coef is written back (clip is in place);
+ *                      Adam   m,v update, p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps);
+ *                      RMSprop s update,  p -= lr * g / (sqrt(s) + eps);
+ *                      norm_out (optional) receives the pre-clip norm.
+ * Algorithmic traffic: Adam 28 B / parameter (read p,g,m,v; write p,m,v) + 4 B (g write).
+ * --------------------------------------------------------------------------------- */
+int dx_grad_sumsq_f32(const float *grads, long long n, double *partials, int npartials,
+                      void *stream);
+int dx_clip_adam_step_f32(float *params, float *grads, float *exp_avg, float *exp_avg_sq,
+                          long long n, const double *sumsq_partials, int npartials,
+                          double max_norm, double lr, double beta1, double beta2, double eps,
+                          long long step, float *norm_out, void *stream);
+int dx_clip_rmsprop_step_f32(float *params, float *grads, float *square_avg, long long n,
+                             const double *sumsq_partials, int npartials, double max_norm,
+                             double lr, double alpha, double eps, float *norm_out, void *stream);
+
+/* Row gather dst[i] = src[idx[i]] (rows of row_bytes bytes) -- the minibatch selection of
+ * derl/runners/onpolicy.py:44-49,59-62 for the small per-sample arrays (frames are
+ * gathered by index inside the conv loader instead of being copied). */
+int dx_gather_rows(const void *src, const int32_t *idx, void *dst, long long nrows,
+                   long long row_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Categorical head -- replaces the distribution part of derl/policies.py:61-80
+ * (ActorCriticPolicy.act with torch Categorical) and derl/alg/ppo.py:24-108 (PPOLoss) /
+ * derl/alg/a2c.py:19-79 (A2CLoss) including their backward w.r.t. the head outputs.
+ * `head_out` is (B, 32) row-major: columns 0..A-1 logits, column A the value (the padded
+ * output of dx_cnn_forward).
+ *   act : action = inverse-CDF sample from uniforms[b] (or, if uniforms == NULL, from a
+ *         counter-based generator keyed by (seed, counter, b)), log_prob, value.
+ *   loss: mode 0 = PPO (clipped ratio + clipped value, cliprange < 0 means None),
+ *         mode 1 = A2C.  Writes dL/dhead_out (B, 32) and loss_out[8] =
+ *         {loss, policy_loss, entropy, value_loss, mean adv, mean value, mean target, r^2}.
+ *         Means are over B; gradients are scaled by 1/global_batch (global_batch <= 0: B)
+ *         so that sharded batches sum to the single-process gradient after all-reduce.
+ *         `partials` is scratch of >= 8 * ceil(B/8) doubles.
+ * --------------------------------------------------------------------------------- */
+int dx_categorical_act_f32(const float *head_out, int B, int A, const float *uniforms,
+                           uint64_t seed, uint64_t counter, int64_t *actions, float *log_prob,
+                           float *values, void *stream);
+int dx_categorical_loss_f32(const float *head_out, const int64_t *actions,
+                            const float *old_log_prob, const float *advantages,
+                            const float *old_values, const float *value_targets, int B, int A,
+                            int mode, float cliprange, float value_loss_coef,
+                            float entropy_coef, long long global_batch, float *dhead_out,
+                            double *partials, int partials_capacity, float *loss_out,
+                            void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Nature-DQN actor-critic network -- replaces derl/models.py:94-124 (NatureCNNBase.forward)
+ * + :198-214 (NatureCNNModel.forward, output_units=[A, 1]) and the autograd backward of
+ * derl/alg/common.py:70, as fp32-MFMA implicit GEMMs over NHWC activations.
+ *
+ * The caller fills the geometry fields and struct_bytes, calls dx_cnn_init (host only) to
+ * get the derived sizes / offsets, allocates the device buffers and stores their pointers.
+ * params/grads are flat in the reference's state_dict order and layout:
+ *   base.conv-0.weight (32,C,8,8) .bias, conv-1 (64,32,4,4), conv-2 (64,64,3,3),
+ *   base.linear (512, flat), output_layers.0 (A,512), output_layers.1 (1,512)
+ * at element offsets off_w[i], off_b[i].  dx_cnn_pack must run after every parameter change.
+ * --------------------------------------------------------------------------------- */
+typedef struct dx_cnn_ctx {
+  int struct_bytes;                 /* = sizeof(dx_cnn_ctx), checked */
+  int in_h, in_w, in_c;             /* observation (84, 84, 4), NHWC */
+  int num_actions;                  /* A <= 31 */
+  int max_batch;                    /* capacity of the activation buffers */
+  /* ---- derived by dx_cnn_init ---- */
+  int h0, w0, h1, w1, h2, w2, flat; /* 20,20, 9,9, 7,7, 3136 for 84x84 */
+  int reserved0;
+  long long off_w[6], off_b[6];     /* conv0, conv1, conv2, linear, policy head, value head */
+  long long param_count;
+  long long pk_c0f, pk_c1f, pk_c2f, pk_fcf, pk_hdf, pk_hdb, pk_c1d[4], pk_c2d, pk_fcd, pk_hdd;
+  long long packed_count, slab_count;
+  long long y0_count, y1_count, y2_count, hid_count, head_count;  /* floats per buffer */
+  /* ---- device buffers (caller-allocated, fp32) ---- */
+  float *params, *grads;            /* param_count */
+  float *packed;                    /* packed_count */
+  float *y0, *y1, *y2, *hid, *head; /* activations kept for backward */
+  float *dy0, *dy1, *dy2, *dhid, *dhead; /* same sizes as the activations */
+  float *slabs;                     /* slab_count: split-reduction partials of wgrad */
+} dx_cnn_ctx;
+
+int dx_cnn_init(dx_cnn_ctx *ctx);
+int dx_cnn_pack(const dx_cnn_ctx *ctx, void *stream);
+/* obs: (B, in_h, in_w, in_c) uint8 (dequantised x/255 exactly) or float32; sample_idx
+ * (optional) selects obs[sample_idx[b]] -- the minibatch permutation. */
+int dx_cnn_forward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
+                   const int32_t *sample_idx, int B, void *stream);
+int dx_cnn_backward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
+                    const int32_t *sample_idx, int B, void *stream);
+/* One launch of the network (one profiler row), for per-kernel timing and layer tests.
+ * Stages in execution order: 0 conv0_fwd, 1 conv1_fwd, 2 conv2_fwd, 3 fc_fwd, 4 heads_fwd,
+ * 5 heads_wgrad, 6 heads_dgrad, 7 fc_wgrad, 8 fc_dgrad, 9 conv2_wgrad, 10 conv2_dgrad,
+ * 11 conv1_wgrad, 12 conv1_dgrad, 13 conv0_wgrad, 14 finalize (slabs -> gradients).
+ * forward = 0..4, backward = 5..14. */
+int dx_cnn_stage(const dx_cnn_ctx *ctx, int stage, const void *obs, int obs_is_u8,
+                 const int32_t *sample_idx, int B, void *stream);
+
+/* Synthetic Atari-shaped environment step (measurement input only; the
+ * reference's env stack derl/env/ is out of scope): fills `frames` (nenvs x 84x84x4 uint8,
+ * any byte count that is a multiple of 16) with uniform bytes, rewards in {-1,0,1} with
+ * P(!=0) = p_reward, resets Bernoulli(p_reset), all hashed from (seed, counter, position). */
+int dx_synth_atari_step(void *frames, long long frame_bytes_total, float *rewards,
+                        uint8_t *resets, int nenvs, uint64_t seed, uint64_t counter,
+                        float p_reward, float p_reset, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

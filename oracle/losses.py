@@ -118,9 +118,21 @@ def a2c_head_grads(logits, actions, values, advantages, value_targets,
   return dlogits, dv
 
 
-def _leaf_params(params):
+def _leaf_params(params, dtype=torch.float32):
   return {k: torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v)
-          .detach().clone().requires_grad_(True) for k, v in params.items()}
+          .detach().to(dtype).clone().requires_grad_(True) for k, v in params.items()}
+
+
+def _cast_data(data, dtype):
+  if dtype == torch.float32:
+    return data
+  out = dict(data)
+  for key in ("log_prob", "advantages", "values", "value_targets"):
+    if key in out:
+      out[key] = torch.as_tensor(out[key]).to(dtype)
+  if torch.as_tensor(out["actions"]).is_floating_point():
+    out["actions"] = torch.as_tensor(out["actions"]).to(dtype)
+  return out
 
 
 def _forward_dist(params, data, kind):
@@ -130,16 +142,21 @@ def _forward_dist(params, data, kind):
   else:
     mean, std, values = mujoco_forward(params, data["observations"])
     log_prob, entropy = diag_normal_log_prob_entropy(
-        mean, std, torch.as_tensor(data["actions"]).float())
+        mean, std, torch.as_tensor(data["actions"]).to(mean.dtype))
   return log_prob, entropy, values
 
 
 def ppo_loss_and_grads(params, data, kind="cnn", cliprange=0.1, value_loss_coef=0.25,
-                       entropy_coef=0.01):
+                       entropy_coef=0.01, dtype=torch.float32):
   """Full model forward + PPOLoss + autograd backward on CPU (ppo.py:100-108,
   common.py:68-70).  ``data`` holds observations, actions, log_prob, advantages,
-  values (B,1), value_targets (B,1).  Returns (terms, grads dict keyed like params)."""
-  leaf = _leaf_params(params)
+  values (B,1), value_targets (B,1).  Returns (terms, grads dict keyed like params).
+
+  ``dtype=torch.float64`` evaluates the same algorithm in double precision: the ground
+  truth for batches >= ~128, where torch-CPU's float32 conv weight-gradient (oneDNN NCHW
+  path) is itself off by ~1e-4 relative (measured against float64)."""
+  leaf = _leaf_params(params, dtype)
+  data = _cast_data(data, dtype)
   log_prob, entropy, values = _forward_dist(leaf, data, kind)
   terms = ppo_loss_terms(log_prob, entropy, values, data["log_prob"], data["advantages"],
                          data["values"], data["value_targets"], cliprange,
@@ -150,9 +167,11 @@ def ppo_loss_and_grads(params, data, kind="cnn", cliprange=0.1, value_loss_coef=
   return {k: float(v.detach()) for k, v in terms.items()}, grads
 
 
-def a2c_loss_and_grads(params, data, kind="cnn", value_loss_coef=0.5, entropy_coef=0.01):
+def a2c_loss_and_grads(params, data, kind="cnn", value_loss_coef=0.5, entropy_coef=0.01,
+                       dtype=torch.float32):
   """Full model forward + A2CLoss + autograd backward on CPU (a2c.py:68-79)."""
-  leaf = _leaf_params(params)
+  leaf = _leaf_params(params, dtype)
+  data = _cast_data(data, dtype)
   log_prob, entropy, values = _forward_dist(leaf, data, kind)
   terms = a2c_loss_terms(log_prob, entropy, values, data["advantages"],
                          data["value_targets"], value_loss_coef, entropy_coef)

@@ -32,7 +32,9 @@ def nature_cnn_forward(params, observations):
   x = x.permute(0, 3, 1, 2)
   if x.dtype == torch.uint8:
     x = x.float() / 255
-  x = x.contiguous()
+  # float64 parameters select the high-precision evaluation used as ground truth for
+  # large batches (the float32 dequantisation above is kept: it is part of the semantics)
+  x = x.to(_t(params["base.conv-0.weight"]).dtype).contiguous()
   for i, stride in enumerate((4, 2, 1)):
     x = F.relu(F.conv2d(x, _t(params[f"base.conv-{i}.weight"]),
                         _t(params[f"base.conv-{i}.bias"]), stride=stride))
@@ -74,7 +76,7 @@ def mlp_forward(params, prefix, x, nlayers=3):
 def mujoco_forward(params, observations):
   """(mean, std, values...) of MuJoCoModel (models.py:261-271): independent MLPs per
   output, std = exp(logstd) repeated over the batch; inputs cast to the model dtype."""
-  x = _t(observations).to(torch.float32)
+  x = _t(observations).to(_t(params["logstd"]).dtype)  # collocate_inputs(): model dtype
   outs = []
   i = 0
   while f"module_list.{i}.0.weight" in params:

@@ -1,0 +1,178 @@
+"""GPU parity of the Nature-DQN forward / backward (dx_cnn_*, through the C-ABI) and of the
+fused categorical loss against the reference's golden vectors and the CPU oracle.
+
+Tolerances (fp32 MFMA is a k-ordered fma chain, the CPU reference sums in another order):
+forward outputs rtol 1e-4 / atol 2e-5 (golden fixtures themselves carry 1e-5..1e-6 from
+the reference's tests, alg/ppo_test.py:22-28), gradients rtol 1e-4 / atol 1e-5."""
+import os
+
+import numpy as np
+import numpy.testing as nt
+import pytest
+import torch
+
+import inputs as gi
+import oracle
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def make_engine(num_actions, weights, max_batch=64):
+  from derl_amd.cnn_engine import CnnEngine
+  eng = CnnEngine(num_actions, max_batch=max_batch, device=DEV)
+  eng.load_state_dict(weights)
+  return eng
+
+
+@pytest.mark.parametrize("num_actions,seed", [(4, 21), (6, 22)])
+def test_forward_matches_reference_golden(num_actions, seed):
+  weights = gi.nature_cnn_weights(num_actions, seed)
+  obs = gi.frames(32, seed + 100)
+  eng = make_engine(num_actions, weights)
+  head = eng.forward(torch.from_numpy(obs).to(DEV))
+  torch.cuda.synchronize()
+  head = head.cpu().numpy()
+  tag = f"cnn_a{num_actions}"
+  with np.load(os.path.join(G, "act.npz")) as g:
+    nt.assert_allclose(head[:, :num_actions], g[f"{tag}.raw_logits"], rtol=1e-4, atol=2e-5)
+    nt.assert_allclose(head[:, num_actions:num_actions + 1], g[f"{tag}.values"], rtol=1e-4, atol=2e-5)
+    nt.assert_array_equal(head[:, num_actions + 1:], 0)
+    nt.assert_allclose(eng.hid[:32 * 512].view(32, 512).cpu().numpy(), g[f"{tag}.hidden"],
+                       rtol=1e-4, atol=2e-5)
+
+
+def oracle_activations(weights, obs):
+  import torch.nn.functional as F
+  x = torch.from_numpy(obs).permute(0, 3, 1, 2)
+  x = (x.float() / 255 if x.dtype == torch.uint8 else x).contiguous()
+  acts = []
+  for i, s in enumerate((4, 2, 1)):
+    x = F.relu(F.conv2d(x, torch.from_numpy(weights[f"base.conv-{i}.weight"]),
+                        torch.from_numpy(weights[f"base.conv-{i}.bias"]), stride=s))
+    acts.append(x.permute(0, 2, 3, 1).contiguous().numpy())  # NHWC like the engine
+  return acts
+
+
+@pytest.mark.parametrize("batch", [1, 3, 33, 129, 256])
+def test_forward_layers_and_ragged_batches(batch):
+  weights = gi.nature_cnn_weights(4, 7)
+  obs = gi.frames(batch, 5 + batch)
+  eng = make_engine(4, weights, max_batch=256)
+  head = eng.forward(torch.from_numpy(obs).to(DEV))
+  torch.cuda.synchronize()
+  ref = oracle_activations(weights, obs)
+  for name, r in zip(("y0", "y1", "y2"), ref):
+    got = getattr(eng, name)[:r.size].cpu().numpy().reshape(r.shape)
+    nt.assert_allclose(got, r, rtol=1e-4, atol=2e-5, err_msg=name)
+  logits, values = oracle.nature_cnn_forward(weights, obs)
+  nt.assert_allclose(head[:, :4].cpu().numpy(), logits.numpy(), rtol=1e-4, atol=2e-5)
+  nt.assert_allclose(head[:, 4:5].cpu().numpy(), values.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_forward_float_observations_upstream_fixture():
+  """models_test.py:41-45: NatureCNNBase on torch.rand(32,84,84,4) float input."""
+  torch.manual_seed(0)
+  convs = [torch.nn.Conv2d(4, 32, 8, 4), torch.nn.Conv2d(32, 64, 4, 2), torch.nn.Conv2d(64, 64, 3, 1)]
+  linear = torch.nn.Linear(3136, 512)
+  weights = {}
+  for i, c in enumerate(convs):
+    weights[f"base.conv-{i}.weight"] = c.weight.detach().numpy()
+    weights[f"base.conv-{i}.bias"] = c.bias.detach().numpy()
+  weights["base.linear.weight"] = linear.weight.detach().numpy()
+  weights["base.linear.bias"] = linear.bias.detach().numpy()
+  weights["output_layers.0.weight"] = np.zeros((4, 512), np.float32)
+  weights["output_layers.0.bias"] = np.zeros(4, np.float32)
+  weights["output_layers.1.weight"] = np.zeros((1, 512), np.float32)
+  weights["output_layers.1.bias"] = np.zeros(1, np.float32)
+  inputs = torch.rand(32, 84, 84, 4)
+  eng = make_engine(4, weights)
+  eng.forward(inputs.to(DEV))
+  torch.cuda.synchronize()
+  hidden = eng.hid[:32 * 512].view(32, 512).cpu().numpy()
+  nt.assert_allclose(hidden, om.nature_cnn_hidden(weights, inputs).numpy(), rtol=1e-4, atol=1e-5)
+  expected = np.load(os.path.join(G, "upstream", "dqn-base-outputs.npy"))
+  if np.allclose(om.nature_cnn_hidden(weights, inputs).numpy(), expected, atol=1e-5):
+    nt.assert_allclose(hidden, expected, atol=1e-5)
+
+
+def test_forward_with_sample_index_gather():
+  weights = gi.nature_cnn_weights(4, 9)
+  obs = gi.frames(40, 77)
+  idx = np.random.RandomState(0).permutation(40)[:24].astype(np.int32)
+  eng = make_engine(4, weights)
+  head = eng.forward(torch.from_numpy(obs).to(DEV), torch.from_numpy(idx).to(DEV)).clone()
+  direct = eng.forward(torch.from_numpy(obs[idx]).to(DEV))
+  torch.cuda.synchronize()
+  nt.assert_array_equal(head.cpu().numpy(), direct.cpu().numpy())
+
+
+def run_loss_and_backward(eng, data, mode, cliprange, vcoef, ecoef, num_actions, sample_idx=None):
+  from derl_amd import ops
+  t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+  obs = t(data["observations"])
+  head = eng.forward(obs, sample_idx)
+  eng._ensure_backward()
+  B = head.shape[0]
+  dhead = eng.dhead[:B * 32].view(B, 32)
+  loss = ops.categorical_loss(
+      head, t(data["actions"]), t(data["log_prob"]) if mode == 0 else None,
+      t(data["advantages"]), t(data["values"].reshape(-1)) if mode == 0 else None,
+      t(data["value_targets"].reshape(-1)), num_actions, mode, cliprange, vcoef, ecoef, dhead)
+  eng.backward(obs, sample_idx)
+  torch.cuda.synchronize()
+  return loss.cpu().numpy(), eng.named_views(eng.grads)
+
+
+@pytest.mark.parametrize("name", ["ppo_step_cnn", "a2c_step_cnn"])
+def test_loss_and_gradients_match_reference_golden(name):
+  from tests.test_oracle_golden import oracle_step_case, _check_summary
+  cfg, g, params, names, data = oracle_step_case(name)
+  eng = make_engine(cfg["num_actions"], params)
+  mode = 0 if cfg["alg"] == "ppo" else 1
+  loss, grads = run_loss_and_backward(eng, data, mode, cfg.get("cliprange"), cfg["value_loss_coef"],
+                                      cfg["entropy_coef"], cfg["num_actions"])
+  nt.assert_allclose(loss[0], g["loss0"], rtol=1e-5, atol=1e-5)  # alg/ppo_test.py:28 tolerance
+  for k in names:
+    _check_summary(grads[k].cpu().numpy(), g, f"grad0.{k}", rtol=1e-4, atol=1e-5)
+  # every gradient tensor in full against the oracle's autograd
+  if mode == 0:
+    terms, ograds = oracle.ppo_loss_and_grads(params, data, "cnn", cfg["cliprange"],
+                                              cfg["value_loss_coef"], cfg["entropy_coef"])
+  else:
+    terms, ograds = oracle.a2c_loss_and_grads(params, data, "cnn", cfg["value_loss_coef"],
+                                              cfg["entropy_coef"])
+  nt.assert_allclose(loss[1], terms["policy_loss"], rtol=1e-4, atol=1e-5)
+  nt.assert_allclose(loss[2], terms["entropy"], rtol=1e-5, atol=1e-6)
+  nt.assert_allclose(loss[3], terms["value_loss"], rtol=1e-4, atol=1e-5)
+  for k in names:
+    scale = np.abs(ograds[k]).max()
+    nt.assert_allclose(grads[k].cpu().numpy(), ograds[k], rtol=1e-4, atol=1e-5 + 1e-5 * scale,
+                       err_msg=k)
+
+
+@pytest.mark.parametrize("batch", [1, 5, 37, 130])
+def test_backward_ragged_batches_with_gather(batch):
+  rs = np.random.RandomState(batch)
+  A = 6
+  weights = gi.nature_cnn_weights(A, 31)
+  pool = gi.frames(batch + 7, 1000 + batch)
+  idx = rs.permutation(batch + 7)[:batch].astype(np.int32)
+  data = dict(observations=pool, actions=rs.randint(0, A, batch).astype(np.int64),
+              log_prob=(rs.standard_normal(batch) * 0.1 - 1.7).astype(np.float32),
+              advantages=rs.standard_normal(batch).astype(np.float32),
+              values=rs.standard_normal((batch, 1)).astype(np.float32) * 0.2,
+              value_targets=rs.standard_normal((batch, 1)).astype(np.float32))
+  eng = make_engine(A, weights, max_batch=256)
+  loss, grads = run_loss_and_backward(eng, data, 0, 0.1, 0.25, 0.01, A,
+                                      torch.from_numpy(idx).to(DEV))
+  odata = dict(data, observations=pool[idx])
+  # float64 evaluation of the oracle: torch-CPU float32 conv wgrad is itself ~1e-4 off at B>=128
+  terms, ograds = oracle.ppo_loss_and_grads(weights, odata, "cnn", 0.1, 0.25, 0.01,
+                                            dtype=torch.float64)
+  nt.assert_allclose(loss[0], terms["loss"], rtol=1e-4, atol=1e-5)
+  for k, og in ograds.items():
+    scale = np.abs(og).max()
+    nt.assert_allclose(grads[k].cpu().numpy(), og, rtol=1e-4, atol=1e-5 + 1e-5 * scale, err_msg=k)

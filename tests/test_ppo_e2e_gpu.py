@@ -1,0 +1,201 @@
+"""End-to-end GPU checks through derl's API surface: the reference's golden training
+trajectories (three Trainer.steps), the device-resident runner's contract, and a short
+PPOFactory run."""
+import os
+
+import numpy as np
+import numpy.testing as nt
+import pytest
+import torch
+
+import inputs as gi
+import oracle
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+class FakeRunner:
+  def __init__(self, policy, step_count):
+    self.policy, self.step_count = policy, step_count
+
+
+def build_case(name):
+  import derl_amd as derl
+  from derl_amd.optim import Adam, RMSprop
+  from tests.test_oracle_golden import oracle_step_case
+  cfg, g, params, names, data = oracle_step_case(name)
+  data["advantages"] = gi.cnn_minibatch(cfg["batch"], cfg["num_actions"], cfg["seed"] + 50)["advantages"]
+  model = derl.NatureCNNModel([cfg["num_actions"], 1], max_batch=64)
+  model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+  policy = derl.ActorCriticPolicy(model)
+  lr = derl.LinearAnneal(cfg["lr"], cfg["num_train_steps"], name="lr")
+  if cfg["alg"] == "ppo":
+    derl.NormalizeAdvantages()(data)
+    optimizer = Adam(model, lr=lr.get_tensor(), eps=cfg["optimizer_epsilon"])
+    trainer = derl.Trainer(optimizer, anneals=[lr], max_grad_norm=cfg["max_grad_norm"])
+    alg = derl.PPO(FakeRunner(policy, cfg["step_count"]), trainer, cliprange=cfg["cliprange"],
+                   value_loss_coef=cfg["value_loss_coef"], entropy_coef=cfg["entropy_coef"])
+  else:
+    optimizer = RMSprop(model, lr.get_tensor(), alpha=cfg["optimizer_alpha"],
+                        eps=cfg["optimizer_epsilon"])
+    trainer = derl.Trainer(optimizer, anneals=[lr], max_grad_norm=cfg["max_grad_norm"])
+    alg = derl.A2C(FakeRunner(policy, cfg["step_count"]), trainer,
+                   value_loss_coef=cfg["value_loss_coef"], entropy_coef=cfg["entropy_coef"])
+  return cfg, g, names, data, model, alg, lr
+
+
+@pytest.mark.parametrize("name", ["ppo_step_cnn", "a2c_step_cnn"])
+def test_trainer_steps_match_reference_golden(name):
+  """alg/test.py:35-69 style: gradients after loss.backward(), then consecutive alg.step
+  losses, learning rates and post-step parameters against the reference's own run."""
+  from tests.test_oracle_golden import _check_summary
+  import derl_amd as derl
+  derl.summary.stop_recording()
+  cfg, g, names, data, model, alg, lr = build_case(name)
+  if cfg["alg"] == "ppo":
+    nt.assert_allclose(data["advantages"].cpu().numpy(), g["normalized_advantages"], rtol=1e-5, atol=1e-6)
+  assert [k for k, _ in model.named_parameters()] == list(g["param_names"])
+  loss = alg.loss(data)
+  loss.backward()
+  nt.assert_allclose(loss.item(), g["loss0"], rtol=1e-5, atol=1e-5)
+  for k, p in model.named_parameters():
+    _check_summary(p.grad.cpu().numpy(), g, f"grad0.{k}", rtol=1e-4, atol=1e-5)
+  alg.loss_fn.call_count = 0
+  for step in range(cfg["nsteps"]):
+    if step == 2:
+      alg.runner.step_count += 4096
+    loss = alg.step(data)
+    loose = name == "a2c_step_cnn" and step > 0  # RMSprop's first step is a sign step
+    nt.assert_allclose(loss.item(), g["losses"][step], rtol=5e-3 if loose else 1e-5, atol=1e-5)
+    nt.assert_equal(np.float32(lr.get_tensor().item()), g[f"lr.{step}"])
+    for k, p in model.named_parameters():
+      _check_summary(p.detach().cpu().numpy(), g, f"param{step}.{k}", rtol=1e-5,
+                     atol=3e-4 if loose else 2e-6)
+  assert alg.trainer.step_count == cfg["nsteps"]
+
+
+def test_loss_shape_and_key_errors():
+  import derl_amd as derl
+  cfg, g, names, data, model, alg, lr = build_case("ppo_step_cnn")
+  bad = dict(data)
+  del bad["advantages"]
+  with pytest.raises(ValueError, match="advantages"):
+    alg.loss(bad)
+  bad = dict(data, value_targets=data["value_targets"].reshape(-1))
+  with pytest.raises(ValueError, match="mismatched shapes"):
+    alg.loss(bad)
+  bad = dict(data, advantages=np.zeros((cfg["batch"], 1), np.float32))
+  with pytest.raises(ValueError, match="mismatched shapes"):
+    alg.loss(bad)
+  policy = alg.runner.policy
+  with pytest.raises(NotImplementedError):
+    policy.act(data["observations"], state=object())
+
+
+def test_policy_act_contract_and_broadcast():
+  import derl_amd as derl
+  model = derl.NatureCNNModel([6, 1])
+  policy = derl.ActorCriticPolicy(model)
+  obs = gi.frames(5, 3)
+  act = policy.act(obs)  # host input -> NumPy outputs (policies.py:78-80)
+  assert list(act.keys()) == ["actions", "log_prob", "values"]
+  assert act["actions"].shape == (5,) and act["actions"].dtype == np.int64
+  assert act["log_prob"].shape == (5,) and act["log_prob"].dtype == np.float32
+  assert act["values"].shape == (5, 1)
+  one = policy.act(obs[0])  # unbatched input: batch dimension stripped (models_test.py:76-81)
+  assert one["actions"].shape == () and one["values"].shape == (1,)
+  dev = policy.act(torch.from_numpy(obs).to(DEV))
+  assert dev["actions"].is_cuda
+  train = policy.act(dict(observations=obs), training=True)
+  assert list(train.keys()) == ["distribution", "values"]
+  logits, values = oracle.nature_cnn_forward({k: v.detach().cpu() for k, v in model.state_dict().items()}, obs)
+  nt.assert_allclose(train["values"].cpu().numpy(), values.numpy(), rtol=1e-4, atol=1e-5)
+  lp, ent, _ = oracle.categorical_log_prob_entropy(logits, act["actions"])
+  nt.assert_allclose(train["distribution"].log_prob(act["actions"]).cpu().numpy(), lp.numpy(), rtol=1e-4, atol=1e-5)
+  nt.assert_allclose(act["log_prob"], lp.numpy(), rtol=1e-4, atol=1e-5)
+  outs = model(obs[0])  # (84,84,4) -> (A,), (1,)
+  assert outs[0].shape == (6,) and outs[1].shape == (1,)
+
+
+def test_model_init_matches_reference_seeded_init():
+  import derl_amd as derl
+  torch.manual_seed(0)
+  model = derl.NatureCNNModel([6, 1])
+  ref = oracle.init_nature_cnn((6, 1), seed=0)
+  for k, v in model.state_dict().items():
+    nt.assert_array_equal(v.cpu().numpy(), ref[k].numpy())
+  assert sum(p.numel() for p in model.parameters()) == 1_687_719  # A = 6
+  for name, p in model.named_parameters():
+    if name.endswith("bias"):
+      assert float(p.abs().max()) == 0.0
+
+
+def test_device_runner_contract_and_ppo_factory_iterations():
+  import derl_amd as derl
+  derl.summary.stop_recording()
+  torch.manual_seed(0)
+  np.random.seed(0)
+  env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=16, seed=0)
+  kwargs = derl.PPOFactory.get_kwargs()
+  kwargs.update(nenvs=16, num_runner_steps=8, num_train_steps=16 * 8 * 3)
+  alg = derl.PPOFactory(**kwargs).make(env)
+  runner = alg.runner
+  assert runner.nenvs == 16 and runner.horizon == 8 and len(runner) == 384
+  seen = 0
+  losses = []
+  for data in runner.run():
+    assert set(data.keys()) == {"observations", "actions", "log_prob", "values", "rewards", "resets",
+                                "infos", "next_observations", "state", "advantages", "value_targets"}
+    assert data["actions"].shape == (32,) and data["advantages"].shape == (32,)
+    assert data["values"].shape == (32, 1) and data["value_targets"].shape == (32, 1)
+    assert isinstance(data["observations"], derl.GatheredRows) and data["observations"].shape == (32, 84, 84, 4)
+    adv = data["advantages"].cpu().numpy()
+    assert abs(adv.mean()) < 1e-5 and abs(adv.std() - 1) < 1e-3
+    losses.append(alg.step(data).item())
+    seen += 1
+  assert seen == 3 * 3 * 4 and runner.step_count == 384 and runner.is_exhausted()
+  assert all(np.isfinite(losses))
+  # rewards / resets of the synthetic env honour the contract
+  buf = runner.unwrapped._buffers
+  assert set(np.unique(buf["rewards"].cpu().numpy())) <= {-1.0, 0.0, 1.0}
+  assert buf["resets"].dtype == torch.bool
+  # GAE on the runner's buffers equals the oracle's recursion
+  T, N = 8, 16
+  last = alg.runner.policy.act(buf["obs"][T])["values"].cpu().numpy()
+  adv_ref, _ = oracle.gae_advantages(buf["rewards"].cpu().numpy(), buf["resets"].cpu().numpy(),
+                                     buf["values"].cpu().numpy(), last, 0.99, 0.95)
+  traj = dict(rewards=buf["rewards"], resets=buf["resets"], values=buf["values"],
+              state=dict(latest_observations=buf["obs"][T]))
+  adv, vt = derl.GAE(alg.runner.policy, normalize=False)(traj)
+  nt.assert_allclose(adv.cpu().numpy(), adv_ref, rtol=1e-5, atol=1e-5)
+  with pytest.raises(ValueError, match="advantages"):
+    derl.GAE(alg.runner.policy)(traj)
+
+
+def test_minibatch_order_matches_reference():
+  """Composed shuffles: same sample order as the reference's in-place shuffling."""
+  import derl_amd as derl
+
+  class R:
+    env = policy = None
+    horizon = nsteps = step_count = 0
+    nenvs = 1
+
+    def __init__(self, n):
+      self.n = n
+
+    def run(self, obs=None):
+      yield dict(observations=torch.arange(self.n, device=DEV)[:, None].float(),
+                 index=torch.arange(self.n, device=DEV), state=dict(latest_observations=None))
+
+  with np.load(os.path.join(G, "minibatch_order.npz")) as g:
+    for tag, (n, epochs, nmb) in dict(even=(1024, 3, 4), remainder=(1030, 2, 4)).items():
+      np.random.seed(1234)
+      it = derl.IterateWithMinibatches(R(n), num_epochs=epochs, num_minibatches=nmb)
+      count = 0
+      for i, mb in enumerate(it.run()):
+        nt.assert_array_equal(mb["index"].cpu().numpy(), g[f"{tag}.{i}"])
+        count += 1
+      assert f"{tag}.{count}" not in g.files
