@@ -1,0 +1,130 @@
+"""CPU tests of host-side logic that needs no GPU: the API mirror's argument handling,
+factory bookkeeping, LR schedule, parsers, the dequantisation rule and the fast-division
+constants the kernels rely on."""
+import numpy as np
+import numpy.testing as nt
+import pytest
+
+
+def test_u8_dequant_rule_is_exact_for_every_byte():
+  """igemm.hip dequant_u8: q = x*r, e = fma(-q, 255, x), q' = fma(e, r, q) must equal the
+  IEEE float32 division x/255 for all 256 byte values (models.py:121: x.float() / 255)."""
+  x = np.arange(256, dtype=np.float32)
+  r = np.float32(1.0) / np.float32(255.0)
+  q = x * r
+  e = (x.astype(np.float64) - q.astype(np.float64) * 255.0).astype(np.float32)  # exact fma
+  q2 = (q.astype(np.float64) + e.astype(np.float64) * np.float64(r)).astype(np.float32)
+  nt.assert_array_equal(q2, x / np.float32(255))
+
+
+def test_fastdiv_constants_are_exact():
+  """igemm.hpp make_fastdiv: q = umulhi(n, magic) >> shift is exact for n < 2^31."""
+  rs = np.random.RandomState(0)
+  for d in [2, 3, 7, 9, 10, 20, 49, 81, 100, 400, 1023, 1024, 1025, 6370, 65537]:
+    L = int(np.ceil(np.log2(d)))
+    magic = (1 << (31 + L)) // d + 1
+    assert magic < (1 << 32)
+    n = np.concatenate([rs.randint(0, 2 ** 31 - 1, size=20000, dtype=np.int64),
+                        np.arange(0, 5 * d), np.array([2 ** 31 - 1, 2 ** 31 - d, 2 ** 31 - d - 1])])
+    q = ((n * magic) >> 32) >> (L - 1)
+    nt.assert_array_equal(q, n // d)
+
+
+def test_linear_anneal_closed_form_and_errors():
+  import derl_amd as derl
+  with np.load("tests/golden/anneal.npz") as g:
+    for tag, (start, nsteps) in dict(atari=(2.5e-4, 10e6), mujoco=(3e-4, 1e6)).items():
+      lr = derl.LinearAnneal(start, nsteps, name="lr")
+      for count, expected in zip(g[f"{tag}.counts"], g[f"{tag}.values"]):
+        lr.step_to(int(count))
+        nt.assert_equal(np.float32(lr.get_tensor().item()), expected)
+      with pytest.raises(ValueError):
+        lr.step_to(0)
+  # the per-step path agrees with the closed form
+  a, b = derl.LinearAnneal(1.0, 10), derl.LinearAnneal(1.0, 10)
+  for _ in range(7):
+    a.step()
+  b.step_to(7)
+  assert a.get_tensor().item() == b.get_tensor().item() and a.step_count == b.step_count == 7
+  assert derl.LinearAnneal(1.0, 10, name="lr").name == "lr" and derl.LinearAnneal(1.0, 10).name == "linear_anneal"
+
+
+def test_factory_kwargs_accounting():
+  import derl_amd as derl
+  kwargs = derl.PPOFactory.get_kwargs()
+  assert kwargs["num_runner_steps"] == 128 and kwargs["cliprange"] == 0.1 and kwargs["nenvs"] == 8
+  mj = derl.PPOFactory.get_kwargs("mujoco")
+  assert mj["num_epochs"] == 10 and mj["num_minibatches"] == 32 and mj["nenvs"] is None
+  a2c = derl.A2CFactory.get_kwargs()
+  assert a2c["lambda_"] == 1.0 and a2c["normalize_gae"] is False and a2c["optimizer_alpha"] == 0.99
+  kd = derl.KwargsDict(a=1, b=2)
+  assert kd.get_arg("a") == 1 and kd.unused == {"b"}
+  with pytest.raises(ValueError, match="not all custom kwargs"):
+    with kd.override_context(c=3):
+      pass
+  kd = derl.KwargsDict(a=1, b=2)
+  with kd.override_context(c=3):
+    assert kd.get_arg("c") == 3
+  assert "c" not in kd.kwargs
+  kd.reset_unused()
+  assert kd.unused == {"a", "b"}
+
+
+def test_parsers_and_env_ids(tmp_path):
+  import derl_amd as derl
+  assert derl.env.is_atari_id("BreakoutNoFrameskip-v4") and not derl.env.is_atari_id("CartPole-v1")
+  assert derl.env.is_mujoco_id("HalfCheetah-v3") and derl.env.is_mujoco_id("HalfCheetahBulletEnv-v0")
+  args = derl.get_args(atari_defaults=derl.PPOFactory.get_parser_defaults("atari"),
+                       mujoco_defaults=derl.PPOFactory.get_parser_defaults("mujoco"),
+                       args=["--env-id", "BreakoutNoFrameskip-v4", "--logdir", str(tmp_path),
+                             "--nenvs", "256", "--lr", "1e-3"])
+  assert args.nenvs == 256 and args.lr == 1e-3 and args.num_epochs == 3
+  assert (tmp_path / "args.txt").read_text().count("\n") >= 10
+  args = derl.get_args(atari_defaults=derl.PPOFactory.get_parser_defaults("atari"),
+                       mujoco_defaults=derl.PPOFactory.get_parser_defaults("mujoco"),
+                       args=["--env-id", "CartPole-v1", "--logdir", str(tmp_path), "--defaults", "atari"])
+  assert args.defaults == "atari" and args.num_minibatches == 4
+  with pytest.raises(SystemExit):
+    derl.get_args(atari_defaults={}, mujoco_defaults={},
+                  args=["--env-id", "CartPole-v1", "--logdir", str(tmp_path)])
+  with pytest.raises(ValueError):
+    derl.env.make("NoSuchEnv-v0")
+
+
+def test_cartpole_batch_contract():
+  import derl_amd as derl
+  env = derl.env.make("CartPole-v1", nenvs=8, seed=1)
+  obs = env.reset()
+  assert obs.shape == (8, 4) and obs.dtype == np.float32 and env.action_space.n == 2
+  total_done = 0
+  for t in range(300):
+    obs, rew, done, infos = env.step(np.full(8, t % 2))
+    assert obs.shape == (8, 4) and rew.shape == (8,) and done.dtype == bool and len(infos) == 8
+    total_done += done.sum()
+    assert np.all(np.abs(obs[:, 0]) <= 2.5)  # auto-reset keeps states in range
+  assert total_done > 0
+
+
+def test_env_runner_generic_contract_matches_reference():
+  """The generic (list-building) runner path against the reference's recorded run
+  (tests/golden/runner_contract.npz)."""
+  import derl_amd as derl
+  from generate_stub_env import CountingEnv, CountingPolicy
+  env, policy = CountingEnv(4), CountingPolicy()
+  runner = derl.EnvRunner(env, policy, horizon=6, nsteps=48)
+  with np.load("tests/golden/runner_contract.npz") as g:
+    n = 0
+    for i, inter in enumerate(runner.run()):
+      assert list(inter.keys()) == list(g[f"{i}.keys"])
+      assert runner.step_count == int(g[f"{i}.step_count"])
+      for key in ("observations", "actions", "log_prob", "values", "rewards", "resets", "next_observations"):
+        nt.assert_array_equal(np.asarray(inter[key]), g[f"{i}.{key}"])
+      nt.assert_array_equal(inter["state"]["latest_observations"], g[f"{i}.latest_observations"])
+      n += 1
+    assert n == int(g["niters"]) and len(runner) == int(g["len"])
+  with pytest.raises(TypeError):
+    derl.EnvRunner(env, policy, 6, 48, time_limit=10)
+  wrapped = derl.TransformInteractions(runner)
+  assert wrapped.horizon == 6 and wrapped.nenvs == 4
+  with pytest.raises(AttributeError):
+    wrapped.no_such_attribute  # pylint: disable=pointless-statement
