@@ -23,9 +23,10 @@ int conv_out(int n, int k, int s) { return (n - k) / s + 1; }
 
 int roundup(long long v, int m) { return static_cast<int>((v + m - 1) / m * m); }
 
-// reduction split of a wgrad over its M rows: enough blocks to fill 256 CUs, >= 256 rows each
+// reduction split of a wgrad over its M rows: ~5 workgroups per CU (2 per CU measured 41 %
+// MFMA utilisation: both resident waves of a SIMD wait at the same time), >= 256 rows each
 void pick_msplit(long long M, int blocks_kn, int *msplit, int *mper) {
-  long long ms = 512 / blocks_kn;
+  long long ms = 1280 / blocks_kn;
   if (ms < 1) ms = 1;
   long long cap = (M + 255) / 256;
   if (ms > cap) ms = cap;
@@ -230,7 +231,7 @@ static Gather dgrad_gather(const void *dy, int H, int W, int C, int OH, int OW, 
   for (int a = 0; a < TA; ++a)
     for (int b = 0; b < TB; ++b) {
       const int s = a * TB + b;
-      g.seg_off[s] = (-a * W - b) * C; g.seg_dy[s] = static_cast<int8_t>(-a); g.seg_dx[s] = static_cast<int8_t>(-b);
+      g.seg_off[s] = (-a * W - b) * C; g.seg_dy[s] = -a; g.seg_dx[s] = -b;
     }
   return g;
 }
@@ -304,22 +305,21 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     case ST_CONV1_WGRAD:
       return tn(L_C1, conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), c->dy1, kC1, M1,
                 kC1, 16 * kC0, false);
-    case ST_CONV1_DGRAD:
-      // 4x4 stride-2 conv: one launch per parity class (py,px) of the input pixels
-      for (int p = 0; p < 4; ++p) {
-        const int py = p >> 1, px = p & 1;
-        const int OHp = (c->h0 - py + 1) / 2, OWp = (c->w0 - px + 1) / 2;
-        if (OHp <= 0 || OWp <= 0) continue;
-        a = nt_args(dgrad_gather(c->dy1, c->h1, c->w1, kC1, OHp, OWp, 2, 2), pk + c->pk_c1d[p], nullptr,
-                    c->dy0, kC0, static_cast<long long>(B) * OHp * OWp, kC0, 4 * kC1);
-        a.mask_src = c->y0;
-        a.om.enabled = 1;
-        a.om.OHW = OHp * OWp; a.om.OW = OWp;
-        a.om.div_img = make_fastdiv(a.om.OHW); a.om.div_row = make_fastdiv(OWp);
-        a.om.OUT_H = c->h0; a.om.OUT_W = c->w0; a.om.osy = a.om.osx = 2; a.om.ody = py; a.om.odx = px;
-        if (int rc = launch_nt(a, false, EPI_MASK, stage, s)) return rc;
-      }
-      return DX_OK;
+    case ST_CONV1_DGRAD: {
+      // 4x4 stride-2 conv: input pixel (2y'+py, 2x'+px) receives taps kh = py+2a, kw = px+2b from
+      // output-gradient pixel (y'-a, x'-b) for every parity (py,px), so the four parity classes
+      // share one gathered A matrix: one GEMM with N = 4 x 32 columns [(py,px)][ic], scattered
+      // to the 2x2 pixel block by the output map.
+      const int OHp = (c->h0 + 1) / 2, OWp = (c->w0 + 1) / 2;
+      a = nt_args(dgrad_gather(c->dy1, c->h1, c->w1, kC1, OHp, OWp, 2, 2), pk + c->pk_c1d[0], nullptr,
+                  c->dy0, kC0, static_cast<long long>(B) * OHp * OWp, 4 * kC0, 4 * kC1);
+      a.mask_src = c->y0;
+      a.om.enabled = 1;
+      a.om.OHW = OHp * OWp; a.om.OW = OWp;
+      a.om.div_img = make_fastdiv(a.om.OHW); a.om.div_row = make_fastdiv(OWp);
+      a.om.OUT_H = c->h0; a.om.OUT_W = c->w0; a.om.osy = a.om.osx = 2; a.om.chan = kC0;
+      return launch_nt(a, false, EPI_MASK, stage, s);
+    }
     case ST_CONV0_WGRAD:
       return tn(L_C0, conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), c->dy0, kC0,
                 M0, kC0, 64 * IC0, obs_is_u8 != 0);

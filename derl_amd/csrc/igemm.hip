@@ -27,27 +27,34 @@ __device__ __forceinline__ float dequant_u8(uint32_t x) {
   return __builtin_fmaf(e, r, q);
 }
 
+// Loads are unconditional (an invalid element reads offset 0 of the buffer and is zeroed by a
+// select when the tile is written to LDS) and keep the RAW words in registers: conversion and
+// masking happen one K-step later, after the MFMAs the load latency hides under.  A
+// conditional load compiles to a branch with an immediate vmcnt(0), which serialises every
+// load and leaves nothing in flight during the MFMAs.
+template <bool U8> struct Raw { using type = float4; };
+template <> struct Raw<true> { using type = uint32_t; };
+
 template <bool U8>
-__device__ __forceinline__ float4 load4(const void *base, long long off, bool ok) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (ok) {
-    if (U8) {
-      const uint32_t w = *reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + off);
-      v.x = dequant_u8(w & 0xff);
-      v.y = dequant_u8((w >> 8) & 0xff);
-      v.z = dequant_u8((w >> 16) & 0xff);
-      v.w = dequant_u8(w >> 24);
-    } else {
-      v = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off);
-    }
-  }
-  return v;
+__device__ __forceinline__ typename Raw<U8>::type load_raw(const void *base, long long off) {
+  if constexpr (U8)
+    return *reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + off);
+  else
+    return *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off);
+}
+
+__device__ __forceinline__ float4 to_float4(float4 v) { return v; }
+__device__ __forceinline__ float4 to_float4(uint32_t w) {
+  return make_float4(dequant_u8(w & 0xff), dequant_u8((w >> 8) & 0xff), dequant_u8((w >> 16) & 0xff),
+                     dequant_u8(w >> 24));
+}
+__device__ __forceinline__ float4 masked(float4 v, bool ok) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
 struct RowPos {
-  long long base;  // element offset of the row's origin pixel (channel 0)
-  int y0, x0;
-  bool valid;
+  long long base;   // element offset of the row's origin pixel (channel 0)
+  uint32_t okmask;  // bit s: run s of this row lies inside the image (all runs if !check)
 };
 
 __device__ __forceinline__ RowPos decode_row(const Gather &g, int m, bool valid) {
@@ -58,30 +65,20 @@ __device__ __forceinline__ RowPos decode_row(const Gather &g, int m, bool valid)
   const uint32_t oy = fdiv(rem, g.div_row);
   const uint32_t ox = rem - oy * g.OW;
   if (g.idx) img = static_cast<uint32_t>(g.idx[img]);
-  r.y0 = static_cast<int>(oy) * g.sy;
-  r.x0 = static_cast<int>(ox) * g.sx;
-  r.base = static_cast<long long>(img) * g.img_stride +
-           static_cast<long long>(r.y0 * g.W + r.x0) * g.C;
-  r.valid = valid;
+  const int y0 = static_cast<int>(oy) * g.sy, x0 = static_cast<int>(ox) * g.sx;
+  r.base = static_cast<long long>(img) * g.img_stride + static_cast<long long>(y0 * g.W + x0) * g.C;
+  uint32_t mask = 0xffffffffu;
+  if (g.check) {  // uniform branch, prologue / once per row
+    mask = 0;
+    for (int s = 0; s < g.nseg; ++s) {
+      const int yy = y0 + g.seg_dy[s], xx = x0 + g.seg_dx[s];
+      const bool in = static_cast<unsigned>(yy) < static_cast<unsigned>(g.H) &&
+                      static_cast<unsigned>(xx) < static_cast<unsigned>(g.W);
+      mask |= (in ? 1u : 0u) << s;
+    }
+  }
+  r.okmask = valid ? mask : 0u;
   return r;
-}
-
-__device__ __forceinline__ bool seg_ok(const Gather &g, const RowPos &r, int s) {
-  if (!g.check) return r.valid;
-  const int yy = r.y0 + g.seg_dy[s], xx = r.x0 + g.seg_dx[s];
-  return r.valid && static_cast<unsigned>(yy) < static_cast<unsigned>(g.H) &&
-         static_cast<unsigned>(xx) < static_cast<unsigned>(g.W);
-}
-
-__device__ __forceinline__ long long map_out_row(const OutMap &om, int m) {
-  if (!om.enabled) return m;
-  const uint32_t mm = static_cast<uint32_t>(m);
-  const uint32_t img = fdiv(mm, om.div_img);
-  const uint32_t rem = mm - img * om.OHW;
-  const uint32_t oy = fdiv(rem, om.div_row);
-  const uint32_t ox = rem - oy * om.OW;
-  return (static_cast<long long>(img) * om.OUT_H + oy * om.osy + om.ody) * om.OUT_W +
-         ox * om.osx + om.odx;
 }
 
 // ------------------------------------------------------------------------------------
@@ -135,16 +132,21 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   int seg = kbeg / g.seglen, q = kbeg - seg * g.seglen;
-  float4 areg[APASS], breg[BPASS];
+  typename Raw<AU8>::type araw[APASS];
+  float4 braw[BPASS];
+  uint32_t aok = 0;  // bit p: pass p of the tile in flight holds real data
   auto fetch = [&](int kt) {
-    const long long so = static_cast<long long>(g.seg_off[seg]) + q + 4 * l8;
+    const int sseg = __builtin_amdgcn_readfirstlane(seg);
+    const long long so = static_cast<long long>(g.seg_off[sseg]) + q + 4 * l8;
+    aok = 0;
 #pragma unroll
-    for (int p = 0; p < APASS; ++p)
-      areg[p] = load4<AU8>(g.src, rows[p].base + so, seg_ok(g, rows[p], seg));
+    for (int p = 0; p < APASS; ++p) {
+      const bool ok = (rows[p].okmask >> sseg) & 1u;
+      aok |= (ok ? 1u : 0u) << p;
+      araw[p] = load_raw<AU8>(g.src, ok ? rows[p].base + so : 0);
+    }
 #pragma unroll
-    for (int p = 0; p < BPASS; ++p)
-      breg[p] = wvalid[p] ? *reinterpret_cast<const float4 *>(wrow[p] + kt)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < BPASS; ++p) braw[p] = *reinterpret_cast<const float4 *>(wrow[p] + kt);
   };
   fetch(kbeg);
 
@@ -152,10 +154,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
     __syncthreads();  // everyone finished reading the previous tile
 #pragma unroll
     for (int p = 0; p < APASS; ++p)
-      *reinterpret_cast<float4 *>(&As[(p * RPP + lr) * LD + 4 * l8]) = areg[p];
+      *reinterpret_cast<float4 *>(&As[(p * RPP + lr) * LD + 4 * l8]) =
+          masked(to_float4(araw[p]), (aok >> p) & 1u);
 #pragma unroll
     for (int p = 0; p < BPASS; ++p)
-      if (p * RPP + lr < BN) *reinterpret_cast<float4 *>(&Bs[(p * RPP + lr) * LD + 4 * l8]) = breg[p];
+      if (p * RPP + lr < BN)
+        *reinterpret_cast<float4 *>(&Bs[(p * RPP + lr) * LD + 4 * l8]) = masked(braw[p], wvalid[p]);
     __syncthreads();
     if (kt + 32 < kend) {  // prefetch the next tile; its latency hides under the MFMAs
       q += 32;
@@ -186,23 +190,41 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
 
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float *out = a.out + (a.ksplit > 1 ? blockIdx.z * a.slab_stride : 0);
+  const OutMap &om = a.om;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (m >= a.M) continue;
-      const long long orow = map_out_row(a.om, m);
+      uint32_t img = 0, oy = 0, ox = 0;
+      if (om.enabled) {
+        img = fdiv(static_cast<uint32_t>(m), om.div_img);
+        const uint32_t rem = static_cast<uint32_t>(m) - img * om.OHW;
+        oy = fdiv(rem, om.div_row);
+        ox = rem - oy * om.OW;
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn0 + 32 * j + (lane & 31);
         if (n >= a.N) continue;
+        long long o;
+        if (om.enabled) {
+          const int g = n / om.chan, c = n - g * om.chan;
+          const int yy = static_cast<int>(oy) * om.osy + g / om.osx;
+          const int xx = static_cast<int>(ox) * om.osx + g % om.osx;
+          if (yy >= om.OUT_H || xx >= om.OUT_W) continue;
+          o = ((static_cast<long long>(img) * om.OUT_H + yy) * om.OUT_W + xx) * a.ldc + c;
+        } else {
+          o = static_cast<long long>(m) * a.ldc + n;
+        }
         float v = acc[i][j][r];
-        const long long o = orow * a.ldc + n;
         if (a.ksplit == 1) {
           if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) v += a.bias[n];
           if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
           if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
+        } else if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && blockIdx.z == 0) {
+          v += a.bias[n];  // split-K partials: the bias rides on slab 0 (no activation allowed)
         }
         out[o] = v;
       }
@@ -255,21 +277,26 @@ __global__ __launch_bounds__(64 * (BN / WN) * (BKO / WK)) void igemm_tn_kernel(c
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bias_acc = 0.f;
 
-  float4 areg[APASS], greg[GPASS];
+  typename Raw<AU8>::type araw[APASS];
+  float4 graw[GPASS];
+  uint32_t aok = 0, gok = 0;
   auto fetch = [&](int ms) {
+    aok = gok = 0;
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
       const int m = ms + p * ARPP + arow;
-      const RowPos r = decode_row(g, m, m < mend && kvalid);
-      areg[p] = load4<AU8>(g.src, r.base + segoff, seg_ok(g, r, seg));
+      const bool ok = m < mend && kvalid;
+      const RowPos r = decode_row(g, m, ok);
+      aok |= (ok ? 1u : 0u) << p;
+      araw[p] = load_raw<AU8>(g.src, ok ? r.base + segoff : 0);
     }
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
       const int mr = p * GRPP + grow;
       const int m = ms + mr;
-      greg[p] = (mr < BMS && m < mend && nvalid)
-                    ? *reinterpret_cast<const float4 *>(a.G + static_cast<long long>(m) * a.ldg + n0 + 4 * gnq)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = mr < BMS && m < mend && nvalid;
+      gok |= (ok ? 1u : 0u) << p;
+      graw[p] = *reinterpret_cast<const float4 *>(a.G + (ok ? static_cast<long long>(m) * a.ldg + n0 + 4 * gnq : 0));
     }
   };
   if (mbeg < mend) fetch(mbeg);
@@ -278,11 +305,12 @@ __global__ __launch_bounds__(64 * (BN / WN) * (BKO / WK)) void igemm_tn_kernel(c
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < APASS; ++p)
-      *reinterpret_cast<float4 *>(&As[(p * ARPP + arow) * BKO + 4 * akq]) = areg[p];
+      *reinterpret_cast<float4 *>(&As[(p * ARPP + arow) * BKO + 4 * akq]) =
+          masked(to_float4(araw[p]), (aok >> p) & 1u);
 #pragma unroll
     for (int p = 0; p < GPASS; ++p)
       if (p * GRPP + grow < BMS)
-        *reinterpret_cast<float4 *>(&Gs[(p * GRPP + grow) * BN + 4 * gnq]) = greg[p];
+        *reinterpret_cast<float4 *>(&Gs[(p * GRPP + grow) * BN + 4 * gnq]) = masked(graw[p], (gok >> p) & 1u);
     __syncthreads();
     if (ms + BMS < mend) fetch(ms + BMS);
     if (a.bias_slab && blockIdx.x == 0 && tid < BN) {
@@ -365,8 +393,14 @@ int launch_tn_as(const TNArgs &a, hipStream_t stream) {
 
 }  // namespace
 
-// tile shape per stage: N <= 32 -> 256x32 block tile (4 waves of 64x32); otherwise 128x64
-// (4 waves of 64x32).  wgrad: N <= 32 -> [32 x 256] output tile, else [64 x 128].
+// Tile shapes.  Big problems (training minibatches) use 64x64 wave tiles -- 64 MFMAs between
+// barrier pairs -- small ones (rollout batches) smaller tiles so that >= 256 workgroups exist.
+//   N <= 32 : 512x32 (4 waves of 128x32)  |  256x32 (4 waves of 64x32)
+//   N >= 64 : 256x64 (4 waves of 64x64)   |  128x64 (4 waves of 64x32)  |  64x64 (4 waves of 32x32)
+#define DX_NT_N64(ST, EPI)                                                            \
+  if (a.M >= 8192) return launch_nt_as<ST, 128, 64, 64, 32, false, EPI>(a, stream);   \
+  return launch_nt_as<ST, 64, 64, 32, 32, false, EPI>(a, stream)
+
 int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream) {
   DX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "igemm_nt: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   DX_REQUIRE(a.g.seglen % 32 == 0 && a.g.nseg * a.g.seglen == a.K && a.g.nseg <= kMaxSeg,
@@ -374,24 +408,29 @@ int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream
              a.g.seglen);
   DX_REQUIRE(a.ksplit >= 1 && a.K % (32 * a.ksplit) == 0, "igemm_nt: K=%d not divisible by 32*ksplit(%d)",
              a.K, a.ksplit);
+  DX_REQUIRE(a.ksplit == 1 || epi == EPI_NONE || epi == EPI_BIAS,
+             "igemm_nt: split-K partial sums cannot carry epilogue %d", epi);
   DX_REQUIRE(a.g.src && a.Wp && a.out, "igemm_nt: null pointer");
   DX_REQUIRE(a.M < (1 << 30), "igemm_nt: M too large");
+  DX_REQUIRE(!a.om.enabled || (a.om.chan > 0 && a.om.chan % 32 == 0),
+             "igemm_nt: output map needs a channel count that is a multiple of 32");
   switch (stage) {
     case ST_CONV0_FWD:
       DX_REQUIRE(epi == EPI_BIAS_RELU && a.N <= 32, "igemm_nt: conv0 forward needs bias+relu, N <= 32");
       return a_u8 ? launch_nt_as<ST_CONV0_FWD, 256, 32, 64, 32, true, EPI_BIAS_RELU>(a, stream)
                   : launch_nt_as<ST_CONV0_FWD, 256, 32, 64, 32, false, EPI_BIAS_RELU>(a, stream);
-    case ST_CONV1_FWD: return launch_nt_as<ST_CONV1_FWD, 128, 64, 64, 32, false, EPI_BIAS_RELU>(a, stream);
-    case ST_CONV2_FWD: return launch_nt_as<ST_CONV2_FWD, 128, 64, 64, 32, false, EPI_BIAS_RELU>(a, stream);
-    case ST_FC_FWD: return launch_nt_as<ST_FC_FWD, 128, 64, 64, 32, false, EPI_BIAS>(a, stream);
+    case ST_CONV1_FWD: DX_NT_N64(ST_CONV1_FWD, EPI_BIAS_RELU);
+    case ST_CONV2_FWD: DX_NT_N64(ST_CONV2_FWD, EPI_BIAS_RELU);
+    case ST_FC_FWD: DX_NT_N64(ST_FC_FWD, EPI_BIAS);
     case ST_HEADS_FWD: return launch_nt_as<ST_HEADS_FWD, 256, 32, 64, 32, false, EPI_BIAS>(a, stream);
     case ST_HEADS_DGRAD: return launch_nt_as<ST_HEADS_DGRAD, 128, 64, 64, 32, false, EPI_NONE>(a, stream);
-    case ST_FC_DGRAD: return launch_nt_as<ST_FC_DGRAD, 128, 64, 64, 32, false, EPI_MASK>(a, stream);
-    case ST_CONV2_DGRAD: return launch_nt_as<ST_CONV2_DGRAD, 128, 64, 64, 32, false, EPI_MASK>(a, stream);
-    case ST_CONV1_DGRAD: return launch_nt_as<ST_CONV1_DGRAD, 256, 32, 64, 32, false, EPI_MASK>(a, stream);
+    case ST_FC_DGRAD: DX_NT_N64(ST_FC_DGRAD, EPI_MASK);
+    case ST_CONV2_DGRAD: DX_NT_N64(ST_CONV2_DGRAD, EPI_MASK);
+    case ST_CONV1_DGRAD: DX_NT_N64(ST_CONV1_DGRAD, EPI_MASK);
     default: return fail(DX_EINVAL, "igemm_nt: unknown stage %d", stage);
   }
 }
+#undef DX_NT_N64
 
 int launch_tn(const TNArgs &a, bool a_u8, int stage, hipStream_t stream) {
   DX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "igemm_tn: empty problem");
@@ -401,6 +440,7 @@ int launch_tn(const TNArgs &a, bool a_u8, int stage, hipStream_t stream) {
              "igemm_tn: bad M split (mper=%d msplit=%d M=%d)", a.mper, a.msplit, a.M);
   DX_REQUIRE(a.g.src && a.G && a.slab, "igemm_tn: null pointer");
   DX_REQUIRE(a.N % 4 == 0 && a.ldg % 4 == 0, "igemm_tn: N and ldg must be multiples of 4");
+  DX_REQUIRE(!a.g.check, "igemm_tn: bounds-checked gathers are not supported in wgrad");
   switch (stage) {
     case ST_HEADS_WGRAD: return launch_tn_as<ST_HEADS_WGRAD, 32, 256, 32, 64, false>(a, stream);
     case ST_FC_WGRAD: return launch_tn_as<ST_FC_WGRAD, 64, 128, 64, 32, false>(a, stream);

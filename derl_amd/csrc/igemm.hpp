@@ -27,7 +27,8 @@ inline FastDiv make_fastdiv(uint32_t d) {
 }
 
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
-  return f.d <= 1 ? n : (__umulhi(n, f.magic) >> f.shift);
+  const uint32_t q = __umulhi(n, f.magic) >> f.shift;  // computed unconditionally: no branch
+  return f.d <= 1 ? n : q;
 }
 
 constexpr int kMaxSeg = 16;
@@ -45,16 +46,19 @@ struct Gather {
   int nseg, seglen;
   int check;             // runs may start outside the image -> zero fill
   int seg_off[kMaxSeg];  // (dy*W + dx)*C + coff
-  int8_t seg_dy[kMaxSeg], seg_dx[kMaxSeg];
+  int seg_dy[kMaxSeg], seg_dx[kMaxSeg];  // dwords: read with scalar loads
 };
 
-// Output row of GEMM row m (identity unless `enabled`): used by the strided dgrad, whose
-// rows are one parity class of the input pixels.
+// Output address of GEMM element (m, n); identity (m*ldc + n) unless `enabled`.  Enabled:
+// row m -> (img, oy, ox) and column n -> (group g = n / chan, channel n % chan) with
+// g -> (py, px) = (g / osx, g % osx); the element goes to pixel (oy*osy + py, ox*osx + px) of
+// an (OUT_H, OUT_W, ldc) image if that pixel exists.  This is the strided-conv dgrad: all
+// osy*osx parity classes of the input pixels share one gathered A matrix.
 struct OutMap {
   int enabled;
   FastDiv div_img, div_row;
   int OHW, OW;
-  int OUT_H, OUT_W, osy, osx, ody, odx;
+  int OUT_H, OUT_W, osy, osx, chan;
 };
 
 enum Epilogue { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3 };
