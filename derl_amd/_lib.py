@@ -39,6 +39,7 @@ SIGNATURES = {
     "dx_cnn_forward": [P, P, c_int, P, c_int, P],
     "dx_cnn_backward": [P, P, c_int, P, c_int, P],
     "dx_cnn_stage": [P, c_int, P, c_int, P, c_int, P],
+    "dx_cnn_act": [P, P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
 }
 
 
@@ -52,9 +53,10 @@ class CnnCtx(ctypes.Structure):
       + [(n, ctypes.c_longlong) for n in ("pk_c0f", "pk_c1f", "pk_c2f", "pk_fcf", "pk_hdf", "pk_hdb")]
       + [("pk_c1d", ctypes.c_longlong * 4)]
       + [(n, ctypes.c_longlong) for n in ("pk_c2d", "pk_fcd", "pk_hdd", "packed_count", "slab_count",
-                                          "y0_count", "y1_count", "y2_count", "hid_count", "head_count")]
+                                          "y0_count", "y1_count", "y2_count", "hid_count", "head_count",
+                                          "hid_slab_count")]
       + [(n, c_void_p) for n in ("params", "grads", "packed", "y0", "y1", "y2", "hid", "head",
-                                 "dy0", "dy1", "dy2", "dhid", "dhead", "slabs")])
+                                 "dy0", "dy1", "dy2", "dhid", "dhead", "slabs", "hid_slabs")])
 _RESTYPES = {"dx_last_error": c_char_p}
 
 _lib = None

@@ -44,7 +44,8 @@ class CnnEngine:
     self.y2 = torch.empty(ctx.y2_count, **f32)
     self.hid = torch.empty(ctx.hid_count, **f32)
     self.head = torch.empty(ctx.head_count, **f32)
-    for name in ("y0", "y1", "y2", "hid", "head"):
+    self.hid_slabs = torch.empty(ctx.hid_slab_count, **f32)
+    for name in ("y0", "y1", "y2", "hid", "head", "hid_slabs"):
       setattr(ctx, name, getattr(self, name).data_ptr())
 
   def _ensure_backward(self):
@@ -137,6 +138,15 @@ class CnnEngine:
     _lib.call("dx_cnn_forward", ctypes.byref(self.ctx), _lib.ptr(obs), is_u8,
               _lib.ptr(sample_idx), batch, _lib.stream_ptr(self.device))
     return self.head[:batch * 32].view(batch, 32)
+
+  def act(self, obs, actions, log_prob, values, uniforms=None, seed=0, counter=0):
+    """Rollout step: forward + both heads + sampling in the fused path (dx_cnn_act); writes
+    actions (B,) int64, log_prob (B,) f32, values (B,) f32 in place."""
+    batch, is_u8 = self._obs_args(obs, None)
+    self.pack()
+    _lib.call("dx_cnn_act", ctypes.byref(self.ctx), _lib.ptr(obs), is_u8, batch,
+              _lib.ptr(uniforms), int(seed), int(counter), _lib.ptr(actions), _lib.ptr(log_prob),
+              _lib.ptr(values), _lib.stream_ptr(self.device))
 
   def backward(self, obs, sample_idx=None):
     """Consumes self.dhead (B, 32) and fills self.grads (same obs / sample_idx as forward)."""

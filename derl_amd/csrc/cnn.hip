@@ -137,6 +137,12 @@ int dx_cnn_init(dx_cnn_ctx *c) {
   c->y2_count = mb * d.flat;
   c->hid_count = mb * kHid;
   c->head_count = mb * kHeadLd;
+  // rollout path: [ksplit][B][512] partial slabs, ksplit = 14 (B <= 128), 7 (B <= 1024), else 1
+  long long hs = mb;
+  const long long small = mb < 128 ? mb : 128, mid = mb < 1024 ? mb : 1024;
+  if (hs < 14 * small) hs = 14 * small;
+  if (hs < 7 * mid) hs = 7 * mid;
+  c->hid_slab_count = hs * kHid;
   return DX_OK;
 }
 
@@ -380,6 +386,35 @@ int dx_cnn_backward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const i
   for (int st = ST_HEADS_WGRAD; st <= ST_FINALIZE; ++st)
     if (int rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, as_stream(stream))) return rc;
   return DX_OK;
+}
+
+// split of the 3136-deep linear layer over K for small batches (98 K-steps = 2 x 7 x 7)
+static int fc_ksplit(int B, int flat) {
+  const int steps = flat / 32;
+  int ks = B <= 128 ? 14 : (B <= 1024 ? 7 : 1);
+  while (ks > 1 && steps % ks) --ks;
+  return ks;
+}
+
+int dx_cnn_act(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B, const float *uniforms,
+               uint64_t seed, uint64_t counter, int64_t *actions, float *log_prob, float *values,
+               void *stream) {
+  if (int rc = check_ctx(c, "dx_cnn_act", B, false)) return rc;
+  DX_REQUIRE(obs != nullptr && c->hid_slabs != nullptr, "dx_cnn_act: null observations / hid_slabs");
+  hipStream_t s = as_stream(stream);
+  const Plan plan = make_plan(c, B);
+  for (int st = ST_CONV0_FWD; st <= ST_CONV2_FWD; ++st)
+    if (int rc = run_stage(c, st, obs, obs_is_u8, nullptr, B, plan, s)) return rc;
+  const int ks = fc_ksplit(B, c->flat);
+  DX_REQUIRE(static_cast<long long>(ks) * B * kHid <= c->hid_slab_count, "dx_cnn_act: hid_slabs too small");
+  NTArgs a = nt_args(rows_gather(c->y2, c->flat), c->packed + c->pk_fcf, c->params + c->off_b[3],
+                     c->hid_slabs, kHid, B, kHid, c->flat);
+  a.ksplit = ks;
+  a.slab_stride = static_cast<long long>(B) * kHid;
+  if (int rc = launch_nt(a, false, EPI_BIAS, ST_FC_FWD, s)) return rc;
+  return launch_heads_act_fused(c->hid_slabs, ks, a.slab_stride, c->packed + c->pk_hdf,
+                                c->packed + c->pk_hdb, B, c->num_actions, uniforms, seed, counter,
+                                actions, log_prob, values, s);
 }
 
 // A single stage, for per-kernel timing (bench.py roofline) and layer-level tests.

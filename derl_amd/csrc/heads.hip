@@ -86,6 +86,76 @@ __global__ __launch_bounds__(256) void categorical_act_kernel(
   }
 }
 
+// Rollout heads fused with sampling: hid (B,512) arrives as `nslab` split-K partial slabs of
+// the 3136->512 linear layer (bias already on slab 0); one wave per row sums them, forms the
+// A+1 head dot products (policy logits, value) with a 64-lane reduce-scatter, and samples.
+// Replaces two GEMM launches (reduce + heads) and the act launch of the rollout step.
+__global__ __launch_bounds__(256) void heads_act_fused_kernel(
+    const float *__restrict__ hid_slabs, int nslab, long long slab_stride,
+    const float *__restrict__ Wh, const float *__restrict__ bh, int B, int A,
+    const float *__restrict__ uniforms, uint64_t seed, uint64_t counter,
+    int64_t *__restrict__ actions, float *__restrict__ log_prob, float *__restrict__ values) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;  // whole wave exits together
+  float h[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float *row = hid_slabs + static_cast<long long>(b) * 512 + lane * 8;
+  for (int z = 0; z < nslab; ++z) {
+    const float4 u = *reinterpret_cast<const float4 *>(row + z * slab_stride);
+    const float4 w = *reinterpret_cast<const float4 *>(row + z * slab_stride + 4);
+    h[0] += u.x; h[1] += u.y; h[2] += u.z; h[3] += u.w;
+    h[4] += w.x; h[5] += w.y; h[6] += w.z; h[7] += w.w;
+  }
+  float v[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    v[j] = 0.f;
+    if (j <= A) {  // uniform
+      const float4 u = *reinterpret_cast<const float4 *>(Wh + j * 512 + lane * 8);
+      const float4 w = *reinterpret_cast<const float4 *>(Wh + j * 512 + lane * 8 + 4);
+      v[j] = h[0] * u.x + h[1] * u.y + h[2] * u.z + h[3] * u.w + h[4] * w.x + h[5] * w.y +
+             h[6] * w.z + h[7] * w.w;
+    }
+  }
+  // reduce-scatter: after the steps lane l holds the sum over its 32-lane half of output l&31
+#pragma unroll
+  for (int step = 0; step < 5; ++step) {
+    const int off = 16 >> step, cnt = 16 >> step;
+    const bool upper = lane & off;
+#pragma unroll
+    for (int jj = 0; jj < cnt; ++jj) {
+      const float keep = upper ? v[jj + cnt] : v[jj];
+      const float send = upper ? v[jj] : v[jj + cnt];
+      v[jj] = keep + __shfl_xor(send, off);
+    }
+  }
+  float x = v[0] + __shfl_xor(v[0], 32);
+  const int col = lane & 31;
+  x += bh[col];
+  // from here: the half-wave categorical head (see categorical_act_kernel)
+  const bool is_logit = col < A;
+  const float mx = half_max(is_logit ? x : -INFINITY);
+  const float e = is_logit ? expf(x - mx) : 0.f;
+  float acc = 0.f, cdf = 0.f;
+  for (int k = 0; k < A; ++k) {
+    acc += __shfl(e, k);
+    if (k == col) cdf = acc;
+  }
+  const float u = uniforms ? uniforms[b] : uniform01(seed, counter, b);
+  const float thresh = u * acc;
+  const unsigned long long below = __ballot(is_logit && cdf <= thresh);
+  int a = __popcll(below & 0xffffffffull);
+  if (a > A - 1) a = A - 1;
+  const float lse = mx + logf(acc);
+  const float la = __shfl(x, a) - lse;
+  const float val = __shfl(x, A);
+  if (lane == 0) {
+    actions[b] = a;
+    log_prob[b] = la;
+    values[b] = val;
+  }
+}
+
 struct LossArgs {
   const float *out;        // [B][32] head outputs
   const int64_t *actions;  // [B]
@@ -257,3 +327,17 @@ extern "C" int dx_categorical_loss_f32(const float *head_out, const int64_t *act
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
+
+namespace dx {
+int launch_heads_act_fused(const float *hid_slabs, int nslab, long long slab_stride, const float *Wh,
+                           const float *bh, int B, int A, const float *uniforms, uint64_t seed,
+                           uint64_t counter, int64_t *actions, float *log_prob, float *values,
+                           hipStream_t stream) {
+  DX_REQUIRE(B >= 1 && A >= 1 && A <= 31 && nslab >= 1, "heads_act: bad shape B=%d A=%d nslab=%d", B, A, nslab);
+  DX_REQUIRE(hid_slabs && Wh && bh && actions && log_prob && values, "heads_act: null pointer");
+  hipLaunchKernelGGL(heads_act_fused_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, hid_slabs, nslab,
+                     slab_stride, Wh, bh, B, A, uniforms, seed, counter, actions, log_prob, values);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+}  // namespace dx

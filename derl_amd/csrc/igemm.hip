@@ -357,19 +357,28 @@ struct JobTable {
   PermuteJob jobs[kMaxJobs];
 };
 
+// Each output element is summed by a team of `team` consecutive lanes (1..64, power of two):
+// lane t of the team adds slabs z = t, t+team, ... and the team combines by shuffles, so a
+// layer with few outputs but many slabs (conv0: 8192 outputs x 1280 slabs) still fills the chip.
 __global__ __launch_bounds__(256) void permute_reduce_kernel(const JobTable t) {
   const PermuteJob &j = t.jobs[blockIdx.y];
-  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
-  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < j.total;
-       i += stride) {
-    long long rest = i;
+  const int team = j.team;
+  const int tl = threadIdx.x & (team - 1);
+  const long long per_block = blockDim.x / team;
+  const long long stride = static_cast<long long>(gridDim.x) * per_block;
+  // uniform trip count per team (shuffles need the whole team active)
+  for (long long i0 = static_cast<long long>(blockIdx.x) * per_block; i0 < j.total; i0 += stride) {
+    const long long i = i0 + threadIdx.x / team;
+    const bool active = i < j.total;
+    long long rest = active ? i : 0;
     const long long d3 = rest % j.D3; rest /= j.D3;
     const long long d2 = rest % j.D2; rest /= j.D2;
     const long long d1 = rest % j.D1; rest /= j.D1;
     const long long s = j.off + rest * j.s0 + d1 * j.s1 + d2 * j.s2 + d3 * j.s3;
     float v = 0.f;
-    for (int z = 0; z < j.nslab; ++z) v += j.src[z * j.slab_stride + s];
-    j.dst[i] = v;
+    for (int z = tl; z < j.nslab; z += team) v += j.src[z * j.slab_stride + s];
+    for (int o = team >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (active && tl == 0) j.dst[i] = v;
   }
 }
 
@@ -398,7 +407,7 @@ int launch_tn_as(const TNArgs &a, hipStream_t stream) {
 //   N <= 32 : 512x32 (4 waves of 128x32)  |  256x32 (4 waves of 64x32)
 //   N >= 64 : 256x64 (4 waves of 64x64)   |  128x64 (4 waves of 64x32)  |  64x64 (4 waves of 32x32)
 #define DX_NT_N64(ST, EPI)                                                            \
-  if (a.M >= 8192) return launch_nt_as<ST, 128, 64, 64, 32, false, EPI>(a, stream);   \
+  if (a.M >= 65536) return launch_nt_as<ST, 128, 64, 64, 32, false, EPI>(a, stream);  \
   return launch_nt_as<ST, 64, 64, 32, 32, false, EPI>(a, stream)
 
 int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream) {
@@ -463,7 +472,11 @@ int launch_permute_reduce(const PermuteJob *jobs, int njobs, hipStream_t stream)
                    jobs[i].D3 > 0,
                "permute_reduce: bad job %d", i);
     t.jobs[i] = jobs[i];
-    if (jobs[i].total > biggest) biggest = jobs[i].total;
+    // team size: enough lanes in flight (~256k) without exceeding the slab count
+    int team = 1;
+    while (team < 64 && team * 2 <= jobs[i].nslab && jobs[i].total * team < (1 << 18)) team *= 2;
+    t.jobs[i].team = team;
+    if (jobs[i].total * team > biggest) biggest = jobs[i].total * team;
   }
   int bx = cdiv(biggest, 256 * 4);
   if (bx > 2048) bx = 2048;

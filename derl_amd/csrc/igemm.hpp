@@ -107,8 +107,13 @@ struct PermuteJob {
   long long s0, s1, s2, s3, off;
   int nslab;
   long long slab_stride;
+  int team;  // set by launch_permute_reduce
 };
 constexpr int kMaxJobs = 24;
 int launch_permute_reduce(const PermuteJob *jobs, int njobs, hipStream_t stream);
+int launch_heads_act_fused(const float *hid_slabs, int nslab, long long slab_stride, const float *Wh,
+                           const float *bh, int B, int A, const float *uniforms, uint64_t seed,
+                           uint64_t counter, int64_t *actions, float *log_prob, float *values,
+                           hipStream_t stream);
 
 }  // namespace dx

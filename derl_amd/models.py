@@ -181,8 +181,13 @@ def _cnn_policy_act(model, policy, inputs, training):
   squeeze = observations.ndim == 3
   if squeeze:
     observations = observations[None]
-  head = model.head(observations)
-  actions, log_prob, values = ops.categorical_act(head, A, None, policy.seed, policy.act_counter)
+  batch = observations.shape[0]
+  model.reserve(batch)
+  dev = model.engine.device
+  actions = torch.empty(batch, dtype=torch.int64, device=dev)
+  log_prob = torch.empty(batch, dtype=torch.float32, device=dev)
+  values = torch.empty(batch, dtype=torch.float32, device=dev)
+  model.engine.act(observations, actions, log_prob, values, None, policy.seed, policy.act_counter)
   policy.act_counter += 1
   values = values[:, None]
   if squeeze:
@@ -194,9 +199,9 @@ def _cnn_policy_act(model, policy, inputs, training):
 
 
 def _cnn_policy_act_into(model, policy, observations, actions_out, log_prob_out, values_out):
-  head = model.head(observations)
-  ops.categorical_act(head, model.engine.num_actions, None, policy.seed, policy.act_counter,
-                      out=(actions_out, log_prob_out, values_out))
+  model.reserve(observations.shape[0])
+  model.engine.act(observations, actions_out, log_prob_out, values_out.view(-1), None, policy.seed,
+                   policy.act_counter)
   policy.act_counter += 1
 
 

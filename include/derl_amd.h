@@ -153,12 +153,14 @@ typedef struct dx_cnn_ctx {
   long long pk_c0f, pk_c1f, pk_c2f, pk_fcf, pk_hdf, pk_hdb, pk_c1d[4], pk_c2d, pk_fcd, pk_hdd;
   long long packed_count, slab_count;
   long long y0_count, y1_count, y2_count, hid_count, head_count;  /* floats per buffer */
+  long long hid_slab_count;         /* split-K partials of the linear layer (rollout path) */
   /* ---- device buffers (caller-allocated, fp32) ---- */
   float *params, *grads;            /* param_count */
   float *packed;                    /* packed_count */
   float *y0, *y1, *y2, *hid, *head; /* activations kept for backward */
   float *dy0, *dy1, *dy2, *dhid, *dhead; /* same sizes as the activations */
   float *slabs;                     /* slab_count: split-reduction partials of wgrad */
+  float *hid_slabs;                 /* hid_slab_count */
 } dx_cnn_ctx;
 
 int dx_cnn_init(dx_cnn_ctx *ctx);
@@ -169,6 +171,14 @@ int dx_cnn_forward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
                    const int32_t *sample_idx, int B, void *stream);
 int dx_cnn_backward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
                     const int32_t *sample_idx, int B, void *stream);
+/* Rollout step of the policy -- replaces derl/policies.py:61-80 for one batch of observations:
+ * conv stack, the 3136->512 linear layer as split-K partial slabs (so that a 256-row batch
+ * still fills the chip) and ONE fused launch for both heads + Categorical sampling
+ * (uniforms == NULL: counter-based generator keyed by (seed, counter, row)).
+ * Outputs: actions int64 (B), log_prob f32 (B), values f32 (B).  ctx->head is not written. */
+int dx_cnn_act(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8, int B,
+               const float *uniforms, uint64_t seed, uint64_t counter, int64_t *actions,
+               float *log_prob, float *values, void *stream);
 /* One launch of the network (one profiler row), for per-kernel timing and layer tests.
  * Stages in execution order: 0 conv0_fwd, 1 conv1_fwd, 2 conv2_fwd, 3 fc_fwd, 4 heads_fwd,
  * 5 heads_wgrad, 6 heads_dgrad, 7 fc_wgrad, 8 fc_dgrad, 9 conv2_wgrad, 10 conv2_dgrad,

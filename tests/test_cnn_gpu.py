@@ -176,3 +176,32 @@ def test_backward_ragged_batches_with_gather(batch):
   for k, og in ograds.items():
     scale = np.abs(og).max()
     nt.assert_allclose(grads[k].cpu().numpy(), og, rtol=1e-4, atol=1e-5 + 1e-5 * scale, err_msg=k)
+
+
+@pytest.mark.parametrize("batch,A", [(1, 4), (7, 6), (128, 4), (256, 4), (300, 18), (1500, 6)])
+def test_fused_rollout_act_matches_unfused_path(batch, A):
+  """dx_cnn_act (split-K linear layer + fused heads/sampling launch) against the plain
+  forward + dx_categorical_act_f32 path and the oracle, with supplied uniforms."""
+  from derl_amd import ops
+  weights = gi.nature_cnn_weights(A, 40 + A)
+  obs_np = gi.frames(batch, 9 + batch)
+  obs = torch.from_numpy(obs_np).to(DEV)
+  eng = make_engine(A, weights, max_batch=max(batch, 64))
+  u = torch.rand(batch, device=DEV)
+  head = eng.forward(obs)
+  a_ref, lp_ref, v_ref = ops.categorical_act(head, A, u)
+  actions = torch.empty(batch, dtype=torch.int64, device=DEV)
+  log_prob = torch.empty(batch, device=DEV)
+  values = torch.empty(batch, device=DEV)
+  eng.act(obs, actions, log_prob, values, uniforms=u)
+  torch.cuda.synchronize()
+  # different summation order in the linear layer (split K): tiny logit differences may flip a
+  # sample that sits on a CDF boundary
+  assert (actions != a_ref).float().mean().item() <= 2e-3
+  same = (actions == a_ref).cpu().numpy()
+  nt.assert_allclose(values.cpu().numpy(), v_ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+  nt.assert_allclose(log_prob.cpu().numpy()[same], lp_ref.cpu().numpy()[same], rtol=1e-4, atol=2e-5)
+  logits, vals = oracle.nature_cnn_forward(weights, obs_np)
+  lp, _, _ = oracle.categorical_log_prob_entropy(logits, actions.cpu().numpy())
+  nt.assert_allclose(log_prob.cpu().numpy(), lp.numpy(), rtol=1e-4, atol=2e-5)
+  nt.assert_allclose(values.cpu().numpy(), vals.numpy()[:, 0], rtol=1e-4, atol=2e-5)
