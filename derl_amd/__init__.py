@@ -7,6 +7,7 @@ from .alg import Alg, Loss, Trainer, PPO, PPOLoss, A2C, A2CLoss
 from .anneal import AnnealingVariable, LinearAnneal
 from .factory import Factory, KwargsDict, PPOFactory, A2CFactory
 from .models import NatureCNNBase, NatureCNNModel, make_model, GatheredRows
+from .mlp_models import MLP, MuJoCoModel, MLPCategoricalModel
 from .policies import Policy, ActorCriticPolicy
 from .runners import (EnvRunner, RunnerWrapper, TransformInteractions, IterateWithMinibatches,
                       ppo_runner_wrap, make_ppo_runner, PeriodicSummaries, GAE, MergeTimeBatch,

@@ -34,6 +34,13 @@ SIGNATURES = {
     "dx_categorical_loss_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float,
                                 c_float, c_longlong, P, P, c_int, P, P],
     "dx_synth_atari_step": [P, c_longlong, P, P, c_int, c_uint64, c_uint64, c_float, c_float, P],
+    "dx_mlp_init": [P],
+    "dx_mlp_pack": [P, P],
+    "dx_mlp_forward": [P, P, c_int, P],
+    "dx_mlp_backward": [P, c_int, P],
+    "dx_normal_act_f32": [P, P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
+    "dx_normal_loss_f32": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
+                           c_longlong, P, P, P, c_int, P, P],
     "dx_cnn_init": [P],
     "dx_cnn_pack": [P, P],
     "dx_cnn_forward": [P, P, c_int, P, c_int, P],
@@ -114,3 +121,19 @@ def stream_ptr(device=None):
   """The current torch HIP stream as void* (torch is the stream/memory plumbing)."""
   import torch
   return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class MlpCtx(ctypes.Structure):
+  """Mirror of ``dx_mlp_ctx`` (include/derl_amd.h); dx_mlp_init checks the size."""
+  _fields_ = (
+      [(n, c_int) for n in ("struct_bytes", "obs_dim", "policy_out", "has_logstd", "max_batch",
+                            "obs_pad", "reserved0", "reserved1")]
+      + [("off_logstd", ctypes.c_longlong), ("off_w", ctypes.c_longlong * 6),
+         ("off_b", ctypes.c_longlong * 6), ("param_count", ctypes.c_longlong),
+         ("pk_f0", ctypes.c_longlong * 2), ("pk_d2", ctypes.c_longlong * 2),
+         ("pk_d1", ctypes.c_longlong * 2)]
+      + [(n, ctypes.c_longlong) for n in ("packed_count", "slab_per_net", "slab_count", "x_count",
+                                          "h_count", "head_count")]
+      + [(n, c_void_p) for n in ("params", "grads", "packed", "xpad")]
+      + [("h1", c_void_p * 2), ("h2", c_void_p * 2)]
+      + [(n, c_void_p) for n in ("head", "dhead", "da", "db", "slabs")])

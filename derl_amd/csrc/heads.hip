@@ -287,6 +287,218 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partials
   }
 }
 
+// ---- diagonal Gaussian head (thread per row; P <= 31 action dimensions) -----------------
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;  // log(sqrt(2*pi))
+
+__device__ __forceinline__ float normal01(uint64_t seed, uint64_t counter, uint64_t idx) {
+  // Box-Muller from two counter-based uniforms; u1 in (0,1]
+  const float u1 = 1.0f - uniform01(seed, counter * 2, idx);
+  const float u2 = uniform01(seed ^ 0xA5A5A5A5A5A5A5A5ull, counter * 2 + 1, idx);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+__global__ __launch_bounds__(256) void normal_act_kernel(
+    const float *__restrict__ head, const float *__restrict__ logstd, int B, int P,
+    const float *__restrict__ normals, uint64_t seed, uint64_t counter, float *__restrict__ actions,
+    float *__restrict__ log_prob, float *__restrict__ values) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float *row = head + static_cast<long long>(b) * kHeadLd;
+  float lp = 0.f;
+  for (int d = 0; d < P; ++d) {
+    const float mu = row[d];
+    const float sigma = expf(logstd[d]);
+    const float eps = normals ? normals[static_cast<long long>(b) * P + d]
+                              : normal01(seed, counter, static_cast<uint64_t>(b) * 32 + d);
+    const float act = mu + sigma * eps;
+    actions[static_cast<long long>(b) * P + d] = act;
+    const float diff = act - mu;
+    lp += -(diff * diff) / (2.f * (sigma * sigma)) - logf(sigma) - kHalfLog2Pi;
+  }
+  log_prob[b] = lp;
+  values[b] = row[P];
+}
+
+struct NormalLossArgs {
+  const float *head, *logstd, *actions;  // (B,32), (P), (B,P)
+  const float *old_log_prob, *advantages, *old_values, *value_targets;
+  float *dhead;       // (B,32)
+  double *partials;   // [gridDim.x][40]: 8 loss sums + 32 dlogstd sums
+  int B, P, mode;
+  float cliprange, value_loss_coef, entropy_coef, inv_batch;
+};
+
+__global__ __launch_bounds__(256) void normal_loss_kernel(const NormalLossArgs a) {
+  __shared__ double red[4][40];
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool row_ok = b < a.B;
+  const long long ro = static_cast<long long>(row_ok ? b : 0) * kHeadLd;
+  float lp = 0.f, ent = 0.f;
+  for (int d = 0; d < a.P; ++d) {
+    const float sigma = expf(a.logstd[d]);
+    const float diff = a.actions[static_cast<long long>(row_ok ? b : 0) * a.P + d] - a.head[ro + d];
+    lp += -(diff * diff) / (2.f * (sigma * sigma)) - logf(sigma) - kHalfLog2Pi;
+    ent += 0.5f + kHalfLog2Pi + logf(sigma);
+  }
+  const float v = a.head[ro + a.P];
+  const float adv = row_ok ? a.advantages[b] : 0.f;
+  const float vt = row_ok ? a.value_targets[b] : 0.f;
+  float pl, vl, dlp, dv;
+  if (a.mode == 0) {
+    const float old_lp = row_ok ? a.old_log_prob[b] : 0.f;
+    const float old_v = row_ok ? a.old_values[b] : 0.f;
+    const float ratio = expf(lp - old_lp);
+    const float l1 = -ratio * adv;
+    pl = l1;
+    bool active = true;
+    if (a.cliprange >= 0.f) {
+      const float lo = 1.f - a.cliprange, hi = 1.f + a.cliprange;
+      const float l2 = -fminf(fmaxf(ratio, lo), hi) * adv;
+      pl = fmaxf(l1, l2);
+      active = (l1 > l2) || (ratio >= lo && ratio <= hi);
+    }
+    dlp = active ? -adv * ratio * a.inv_batch : 0.f;
+    const float dd = v - vt;
+    const float e1 = dd * dd;
+    vl = e1;
+    bool vactive = true;
+    if (a.cliprange >= 0.f) {
+      const float dvo = v - old_v;
+      const float vc = old_v + fminf(fmaxf(dvo, -a.cliprange), a.cliprange);
+      const float e2 = (vc - vt) * (vc - vt);
+      vl = fmaxf(e1, e2);
+      vactive = (e1 > e2) || (fabsf(dvo) <= a.cliprange);
+    }
+    dv = vactive ? a.value_loss_coef * 2.f * dd * a.inv_batch : 0.f;
+  } else {
+    pl = -lp * adv;
+    dlp = -adv * a.inv_batch;
+    const float dd = v - vt;
+    vl = dd * dd;
+    dv = a.value_loss_coef * 2.f * dd * a.inv_batch;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // dL/dmean_d = dlp * (a - mu)/sigma^2 ; dL/dlogstd_d = sum_b dlp*((a-mu)^2/sigma^2 - 1) - c_H
+  for (int d = 0; d < kHeadLd; ++d) {
+    float g = 0.f;
+    double dls = 0.0;
+    if (d < a.P) {
+      const float sigma = expf(a.logstd[d]);
+      const float diff = a.actions[static_cast<long long>(row_ok ? b : 0) * a.P + d] - a.head[ro + d];
+      const float var = sigma * sigma;
+      g = dlp * diff / var;
+      if (row_ok) dls = static_cast<double>(dlp) * (diff * diff / var - 1.f) - a.entropy_coef * a.inv_batch;
+    } else if (d == a.P) {
+      g = dv;
+    }
+    if (row_ok) a.dhead[ro + d] = g;
+    if (d < a.P) {
+      dls = wave_sum_d(dls);
+      if (lane == 0) red[wave][8 + d] = dls;
+    }
+  }
+  double s[8] = {row_ok ? pl : 0.0, row_ok ? ent : 0.0, row_ok ? vl : 0.0, row_ok ? adv : 0.0,
+                 row_ok ? v : 0.0,  row_ok ? vt : 0.0,  row_ok ? (double)(v - vt) * (v - vt) : 0.0,
+                 row_ok ? (double)v * v : 0.0};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    s[i] = wave_sum_d(s[i]);
+    if (lane == 0) red[wave][i] = s[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 + a.P)
+    a.partials[blockIdx.x * 40 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void dlogstd_reduce_kernel(const double *partials, int nblocks, int P,
+                                                            float *dlogstd) {
+  const int d = threadIdx.x;
+  if (d >= P) return;
+  double s = 0.0;
+  for (int i = 0; i < nblocks; ++i) s += partials[i * 40 + 8 + d];
+  dlogstd[d] = static_cast<float>(s);
+}
+
+// the categorical loss_reduce_kernel with a row stride of 40 doubles
+__global__ __launch_bounds__(256) void loss_reduce40_kernel(const double *partials, int nblocks,
+                                                            double count, float value_loss_coef,
+                                                            float entropy_coef, float *out) {
+  __shared__ double red[4][8];
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += partials[i * 40 + j];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] = wave_sum_d(s[j]);
+    if (lane == 0) red[wave][j] = s[j];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[8];
+    for (int j = 0; j < 8; ++j) t[j] = (red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+    const float policy = static_cast<float>(t[0] / count);
+    const float ent = static_cast<float>(t[1] / count);
+    const float value = static_cast<float>(t[2] / count);
+    out[0] = (policy - entropy_coef * ent) + value_loss_coef * value;
+    out[1] = policy; out[2] = ent; out[3] = value;
+    out[4] = static_cast<float>(t[3] / count);
+    out[5] = static_cast<float>(t[4] / count);
+    out[6] = static_cast<float>(t[5] / count);
+    const double mean_v = t[4] / count;
+    const double var_v = count > 1 ? (t[7] - count * mean_v * mean_v) / (count - 1) : 0.0;
+    out[7] = static_cast<float>(1.0 - (t[6] / count) / var_v);
+  }
+}
+
+}  // namespace
+
+extern "C" int dx_normal_act_f32(const float *head_out, const float *logstd, int B, int P,
+                                 const float *normals, uint64_t seed, uint64_t counter, float *actions,
+                                 float *log_prob, float *values, void *stream) {
+  DX_REQUIRE(B >= 0 && P >= 1 && P <= 31, "dx_normal_act_f32: need 1 <= P <= 31 (P=%d)", P);
+  if (B == 0) return DX_OK;
+  DX_REQUIRE(head_out && logstd && actions && log_prob && values, "dx_normal_act_f32: null pointer");
+  hipLaunchKernelGGL(normal_act_kernel, dim3(dx::cdiv(B, 256)), dim3(256), 0, dx::as_stream(stream),
+                     head_out, logstd, B, P, normals, seed, counter, actions, log_prob, values);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_normal_loss_f32(const float *head_out, const float *logstd, const float *actions,
+                                  const float *old_log_prob, const float *advantages,
+                                  const float *old_values, const float *value_targets, int B, int P,
+                                  int mode, float cliprange, float value_loss_coef, float entropy_coef,
+                                  long long global_batch, float *dhead_out, float *dlogstd_out,
+                                  double *partials, int partials_capacity, float *loss_out,
+                                  void *stream) {
+  DX_REQUIRE(B >= 1 && P >= 1 && P <= 31, "dx_normal_loss_f32: need B >= 1 and 1 <= P <= 31");
+  DX_REQUIRE(mode == 0 || mode == 1, "dx_normal_loss_f32: mode must be 0 (PPO) or 1 (A2C)");
+  DX_REQUIRE(head_out && logstd && actions && advantages && value_targets && dhead_out && dlogstd_out &&
+                 partials && loss_out,
+             "dx_normal_loss_f32: null pointer");
+  DX_REQUIRE(mode == 1 || (old_log_prob && old_values), "dx_normal_loss_f32: PPO needs old_log_prob/old_values");
+  const int blocks = dx::cdiv(B, 256);
+  DX_REQUIRE(partials_capacity >= blocks * 40, "dx_normal_loss_f32: partials needs %d doubles", blocks * 40);
+  if (global_batch <= 0) global_batch = B;
+  NormalLossArgs a{head_out, logstd, actions, old_log_prob, advantages, old_values, value_targets, dhead_out,
+                   partials, B, P, mode, cliprange, value_loss_coef, entropy_coef,
+                   1.0f / static_cast<float>(global_batch)};
+  hipStream_t s = dx::as_stream(stream);
+  hipLaunchKernelGGL(normal_loss_kernel, dim3(blocks), dim3(256), 0, s, a);
+  DX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_reduce40_kernel, dim3(1), dim3(256), 0, s, partials, blocks, static_cast<double>(B),
+                     value_loss_coef, entropy_coef, loss_out);
+  DX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dlogstd_reduce_kernel, dim3(1), dim3(64), 0, s, partials, blocks, P, dlogstd_out);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+namespace {
+// (re-open the anonymous namespace closed above for the definitions that follow)
 }  // namespace
 
 extern "C" int dx_categorical_act_f32(const float *head_out, int B, int A, const float *uniforms,

@@ -220,9 +220,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
         }
         float v = acc[i][j][r];
         if (a.ksplit == 1) {
-          if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) v += a.bias[n];
+          if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH) v += a.bias[n];
           if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+          if (EPI == EPI_BIAS_TANH) v = tanhf(v);
           if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
+          if (EPI == EPI_DTANH) { const float y = a.mask_src[o]; v *= 1.f - y * y; }
         } else if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && blockIdx.z == 0) {
           v += a.bias[n];  // split-K partials: the bias rides on slab 0 (no activation allowed)
         }
@@ -436,6 +438,9 @@ int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream
     case ST_FC_DGRAD: DX_NT_N64(ST_FC_DGRAD, EPI_MASK);
     case ST_CONV2_DGRAD: DX_NT_N64(ST_CONV2_DGRAD, EPI_MASK);
     case ST_CONV1_DGRAD: DX_NT_N64(ST_CONV1_DGRAD, EPI_MASK);
+    case ST_MLP_HIDDEN: DX_NT_N64(ST_MLP_HIDDEN, EPI_BIAS_TANH);
+    case ST_MLP_OUT: return launch_nt_as<ST_MLP_OUT, 64, 32, 32, 32, false, EPI_BIAS>(a, stream);
+    case ST_MLP_DGRAD: DX_NT_N64(ST_MLP_DGRAD, EPI_DTANH);
     default: return fail(DX_EINVAL, "igemm_nt: unknown stage %d", stage);
   }
 }
@@ -458,6 +463,8 @@ int launch_tn(const TNArgs &a, bool a_u8, int stage, hipStream_t stream) {
     case ST_CONV0_WGRAD:
       return a_u8 ? launch_tn_as<ST_CONV0_WGRAD, 32, 256, 32, 64, true>(a, stream)
                   : launch_tn_as<ST_CONV0_WGRAD, 32, 256, 32, 64, false>(a, stream);
+    case ST_MLP_WGRAD_HID: return launch_tn_as<ST_MLP_WGRAD_HID, 64, 128, 64, 32, false>(a, stream);
+    case ST_MLP_WGRAD_OUT: return launch_tn_as<ST_MLP_WGRAD_OUT, 32, 256, 32, 64, false>(a, stream);
     default: return fail(DX_EINVAL, "igemm_tn: unknown stage %d", stage);
   }
 }

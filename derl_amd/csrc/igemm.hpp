@@ -61,7 +61,8 @@ struct OutMap {
   int OUT_H, OUT_W, osy, osx, chan;
 };
 
-enum Epilogue { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3 };
+// EPI_MASK: relu' from the kept output; EPI_BIAS_TANH / EPI_DTANH: tanh and tanh' = 1 - y^2
+enum Epilogue { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3, EPI_BIAS_TANH = 4, EPI_DTANH = 5 };
 
 // C[m][n] = epi(sum_k A(m,k) * Wp[n][k])
 struct NTArgs {
@@ -92,7 +93,9 @@ struct TNArgs {
 enum Stage {
   ST_CONV0_FWD = 0, ST_CONV1_FWD, ST_CONV2_FWD, ST_FC_FWD, ST_HEADS_FWD,
   ST_HEADS_WGRAD, ST_HEADS_DGRAD, ST_FC_WGRAD, ST_FC_DGRAD, ST_CONV2_WGRAD, ST_CONV2_DGRAD,
-  ST_CONV1_WGRAD, ST_CONV1_DGRAD, ST_CONV0_WGRAD, ST_FINALIZE, ST_COUNT
+  ST_CONV1_WGRAD, ST_CONV1_DGRAD, ST_CONV0_WGRAD, ST_FINALIZE,
+  // two-net tanh MLP (derl/models.py:224-271)
+  ST_MLP_HIDDEN, ST_MLP_OUT, ST_MLP_DGRAD, ST_MLP_WGRAD_HID, ST_MLP_WGRAD_OUT, ST_COUNT
 };
 
 int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream);

@@ -1,0 +1,102 @@
+"""Device state of the two-net tanh MLP actor-critic (derl/models.py:224-271): flat
+parameter / gradient buffers in ``state_dict`` order, padded / transposed mirrors,
+activation and slab workspaces, and the calls into the C-ABI (dx_mlp_*)."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class MlpEngine:
+  """Policy net obs_dim -> 64 -> 64 -> P and value net -> 1, optional ``logstd`` (P)."""
+
+  def __init__(self, obs_dim, policy_out, has_logstd, max_batch=256, device="cuda"):
+    self.device = torch.device(device)
+    if self.device.type != "cuda":
+      raise _lib.NativeError("MlpEngine needs a HIP device; derl_amd has no CPU path")
+    ctx = _lib.MlpCtx()
+    ctx.struct_bytes = ctypes.sizeof(_lib.MlpCtx)
+    ctx.obs_dim, ctx.policy_out = int(obs_dim), int(policy_out)
+    ctx.has_logstd, ctx.max_batch = int(bool(has_logstd)), int(max_batch)
+    _lib.call("dx_mlp_init", ctypes.byref(ctx))
+    self.ctx = ctx
+    self.obs_dim, self.policy_out, self.has_logstd = int(obs_dim), int(policy_out), bool(has_logstd)
+    f32 = dict(dtype=torch.float32, device=self.device)
+    self.params = torch.zeros(ctx.param_count, **f32)
+    self.grads = torch.zeros(ctx.param_count, **f32)
+    self.packed = torch.zeros(ctx.packed_count, **f32)
+    ctx.params, ctx.grads, ctx.packed = (t.data_ptr() for t in (self.params, self.grads, self.packed))
+    self._allocate_workspaces()
+    self._packed_version = None
+
+  def _allocate_workspaces(self):
+    ctx = self.ctx
+    f32 = dict(dtype=torch.float32, device=self.device)
+    self.xpad = torch.empty(ctx.x_count, **f32)
+    self.h = [torch.empty(ctx.h_count, **f32) for _ in range(4)]
+    self.head = torch.zeros(ctx.head_count, **f32)  # columns beyond P+1 stay zero
+    self.dhead = torch.zeros(ctx.head_count, **f32)
+    self.da = torch.empty(ctx.h_count, **f32)
+    self.db = torch.empty(ctx.h_count, **f32)
+    self.slabs = torch.empty(ctx.slab_count, **f32)
+    ctx.xpad = self.xpad.data_ptr()
+    ctx.h1[0], ctx.h1[1] = self.h[0].data_ptr(), self.h[1].data_ptr()
+    ctx.h2[0], ctx.h2[1] = self.h[2].data_ptr(), self.h[3].data_ptr()
+    for name in ("head", "dhead", "da", "db", "slabs"):
+      setattr(ctx, name, getattr(self, name).data_ptr())
+
+  def reserve(self, max_batch):
+    if max_batch <= self.ctx.max_batch:
+      return
+    self.ctx.max_batch = int(max_batch)
+    _lib.call("dx_mlp_init", ctypes.byref(self.ctx))
+    self._allocate_workspaces()
+
+  def named_views(self, flat):
+    """state_dict-named views: logstd, module_list.{0,1}.{0,2,4}.{weight,bias}."""
+    c = self.ctx
+    out = {}
+    if self.has_logstd:
+      out["logstd"] = flat[c.off_logstd:c.off_logstd + self.policy_out]
+    for net in range(2):
+      outs = self.policy_out if net == 0 else 1
+      dims = [(64, self.obs_dim), (64, 64), (outs, 64)]
+      for layer, (no, ni) in enumerate(dims):
+        i = 3 * net + layer
+        out[f"module_list.{net}.{2 * layer}.weight"] = flat[c.off_w[i]:c.off_w[i] + no * ni].view(no, ni)
+        out[f"module_list.{net}.{2 * layer}.bias"] = flat[c.off_b[i]:c.off_b[i] + no]
+    return out
+
+  def load_state_dict(self, state):
+    with torch.no_grad():
+      for key, view in self.named_views(self.params).items():
+        view.copy_(torch.as_tensor(state[key]).to(self.device, torch.float32))
+    self.mark_dirty()
+
+  def mark_dirty(self):
+    self._packed_version = None
+
+  def pack(self, force=False):
+    version = self.params._version
+    if force or self._packed_version != version:
+      _lib.call("dx_mlp_pack", ctypes.byref(self.ctx), _lib.stream_ptr(self.device))
+      self._packed_version = version
+
+  def forward(self, obs):
+    """obs (B, obs_dim) float32 on the device -> padded head (B, 32)."""
+    if not obs.is_cuda or obs.dtype != torch.float32 or not obs.is_contiguous():
+      raise ValueError("observations must be a contiguous float32 GPU tensor")
+    if obs.ndim != 2 or obs.shape[1] != self.obs_dim:
+      raise ValueError(f"observations must be (B, {self.obs_dim}), got {tuple(obs.shape)}")
+    batch = obs.shape[0]
+    self.reserve(batch)
+    self.pack()
+    _lib.call("dx_mlp_forward", ctypes.byref(self.ctx), _lib.ptr(obs), batch,
+              _lib.stream_ptr(self.device))
+    return self.head[:batch * 32].view(batch, 32)
+
+  def backward(self, batch):
+    """Consumes self.dhead (B, 32) and fills self.grads (logstd is written by the loss)."""
+    _lib.call("dx_mlp_backward", ctypes.byref(self.ctx), int(batch), _lib.stream_ptr(self.device))
+    return self.grads

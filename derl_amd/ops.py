@@ -162,3 +162,43 @@ def categorical_loss(head_out, actions, old_log_prob, advantages, old_values, va
             float(entropy_coef), int(global_batch), _lib.ptr(dhead_out), _lib.ptr(partials),
             partials.numel(), _lib.ptr(loss_out), _lib.stream_ptr(dev))
   return loss_out
+
+
+def normal_act(head_out, logstd, normals=None, seed=0, counter=0, out=None):
+  """Diagonal-Gaussian sample / log_prob / value from the padded head (policies.py:66,76-77)."""
+  _dev(head_out, "head_out", torch.float32)
+  _dev(logstd, "logstd", torch.float32)
+  B, P = head_out.shape[0], logstd.numel()
+  dev = head_out.device
+  if out is not None:
+    actions, log_prob, values = out
+  else:
+    actions = torch.empty(B, P, dtype=torch.float32, device=dev)
+    log_prob = torch.empty(B, dtype=torch.float32, device=dev)
+    values = torch.empty(B, dtype=torch.float32, device=dev)
+  _lib.call("dx_normal_act_f32", _lib.ptr(head_out), _lib.ptr(logstd), B, P, _lib.ptr(normals),
+            int(seed), int(counter), _lib.ptr(actions), _lib.ptr(log_prob), _lib.ptr(values),
+            _lib.stream_ptr(dev))
+  return actions, log_prob, values
+
+
+def normal_loss(head_out, logstd, actions, old_log_prob, advantages, old_values, value_targets,
+                mode, cliprange, value_loss_coef, entropy_coef, dhead_out, dlogstd_out,
+                global_batch=0, partials=None, loss_out=None):
+  """Fused PPO / A2C loss + gradients for the diagonal-Gaussian head."""
+  _dev(head_out, "head_out", torch.float32)
+  _dev(actions, "actions", torch.float32)
+  B, P = head_out.shape[0], logstd.numel()
+  dev = head_out.device
+  need = 40 * ((B + 255) // 256)
+  if partials is None or partials.numel() < need:
+    partials = torch.empty(need, dtype=torch.float64, device=dev)
+  if loss_out is None:
+    loss_out = torch.empty(8, dtype=torch.float32, device=dev)
+  _lib.call("dx_normal_loss_f32", _lib.ptr(head_out), _lib.ptr(logstd), _lib.ptr(actions),
+            _lib.ptr(old_log_prob), _lib.ptr(advantages), _lib.ptr(old_values),
+            _lib.ptr(value_targets), B, P, int(mode),
+            -1.0 if cliprange is None else float(cliprange), float(value_loss_coef),
+            float(entropy_coef), int(global_batch), _lib.ptr(dhead_out), _lib.ptr(dlogstd_out),
+            _lib.ptr(partials), partials.numel(), _lib.ptr(loss_out), _lib.stream_ptr(dev))
+  return loss_out

@@ -187,6 +187,57 @@ int dx_cnn_act(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8, int B,
 int dx_cnn_stage(const dx_cnn_ctx *ctx, int stage, const void *obs, int obs_is_u8,
                  const int32_t *sample_idx, int B, void *stream);
 
+/* ---------------------------------------------------------------------------------
+ * Two-net tanh MLP actor-critic -- replaces derl/models.py:224-237 (MLP) + :240-271
+ * (MuJoCoModel.forward; also the vector-observation categorical policy of BASELINE config 1)
+ * and its autograd backward.  Flat params/grads in state_dict order:
+ *   [logstd (P) if has_logstd] module_list.0.{0,2,4}.{weight,bias} module_list.1.{0,2,4}.{...}
+ * with module_list.0 = policy net (obs_dim -> 64 -> 64 -> P), module_list.1 = value net
+ * (-> 1).  Head output (B, 32): columns 0..P-1 policy outputs (Gaussian mean or logits),
+ * column P the value.  dx_mlp_pack after every parameter change.
+ * --------------------------------------------------------------------------------- */
+typedef struct dx_mlp_ctx {
+  int struct_bytes;
+  int obs_dim, policy_out, has_logstd, max_batch;
+  /* ---- derived by dx_mlp_init ---- */
+  int obs_pad, reserved0, reserved1;
+  long long off_logstd;             /* -1 without logstd */
+  long long off_w[6], off_b[6];     /* net0 L0,L1,L2, net1 L0,L1,L2 */
+  long long param_count;
+  long long pk_f0[2], pk_d2[2], pk_d1[2];
+  long long packed_count, slab_per_net, slab_count;
+  long long x_count, h_count, head_count;
+  /* ---- device buffers ---- */
+  float *params, *grads, *packed;
+  float *xpad;                      /* x_count */
+  float *h1[2], *h2[2];             /* h_count each */
+  float *head, *dhead;              /* head_count each; head must start zeroed */
+  float *da, *db;                   /* h_count each (backward scratch) */
+  float *slabs;                     /* slab_count */
+} dx_mlp_ctx;
+
+int dx_mlp_init(dx_mlp_ctx *ctx);
+int dx_mlp_pack(const dx_mlp_ctx *ctx, void *stream);
+int dx_mlp_forward(const dx_mlp_ctx *ctx, const float *obs, int B, void *stream);
+int dx_mlp_backward(const dx_mlp_ctx *ctx, int B, void *stream);
+
+/* Diagonal-Gaussian head -- replaces Independent(Normal(mean, exp(logstd)), 1) of
+ * derl/policies.py:40-42,66,76-77 and the PPO/A2C loss on it (derl/alg/ppo.py:24-108) with
+ * its gradient w.r.t. mean, value and logstd.
+ *   act : a = mean + std*eps with eps ~ N(0,1) from `normals` (B, P) or, if NULL, a
+ *         counter-based Box-Muller generator; log_prob (B), values (B).
+ *   loss: as dx_categorical_loss_f32; additionally writes dL/dlogstd (P) to dlogstd_out
+ *         (scaled by 1/global_batch like the other gradients). */
+int dx_normal_act_f32(const float *head_out, const float *logstd, int B, int P,
+                      const float *normals, uint64_t seed, uint64_t counter, float *actions,
+                      float *log_prob, float *values, void *stream);
+int dx_normal_loss_f32(const float *head_out, const float *logstd, const float *actions,
+                       const float *old_log_prob, const float *advantages,
+                       const float *old_values, const float *value_targets, int B, int P,
+                       int mode, float cliprange, float value_loss_coef, float entropy_coef,
+                       long long global_batch, float *dhead_out, float *dlogstd_out,
+                       double *partials, int partials_capacity, float *loss_out, void *stream);
+
 /* Synthetic Atari-shaped environment step (measurement input only; the
  * reference's env stack derl/env/ is out of scope): fills `frames` (nenvs x 84x84x4 uint8,
  * any byte count that is a multiple of 16) with uniform bytes, rewards in {-1,0,1} with

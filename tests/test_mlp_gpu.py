@@ -1,0 +1,176 @@
+"""GPU parity of the MLP actor-critic path (MuJoCo Gaussian policy, vector-observation
+categorical policy) through the C-ABI: reference golden vectors (act, three PPO Trainer.steps),
+the reference's own ppo/pybullet fixture, and the CPU oracle."""
+import os
+
+import numpy as np
+import numpy.testing as nt
+import pytest
+import torch
+
+import inputs as gi
+import oracle
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def make_model(obs_dim, act_dim, weights):
+  import derl_amd as derl
+  model = derl.MuJoCoModel(obs_dim, [act_dim, 1])
+  model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()})
+  return model
+
+
+def test_mlp_act_matches_reference_golden():
+  import derl_amd as derl
+  from derl_amd import ops
+  weights = gi.mujoco_weights(17, 6, 23)
+  mb = gi.mlp_minibatch(64, 17, 6, 123)
+  model = make_model(17, 6, weights)
+  assert [k for k, _ in model.named_parameters()] == list(om.mujoco_keys(2))
+  assert sum(p.numel() for p in model.parameters()) == 11_085
+  policy = derl.ActorCriticPolicy(model)
+  act = policy.act(dict(observations=mb["observations"]), training=True)
+  with np.load(os.path.join(G, "act.npz")) as g:
+    dist = act["distribution"]
+    nt.assert_allclose(dist.mean.cpu().numpy(), g["mlp.mean"], rtol=1e-4, atol=1e-5)
+    nt.assert_allclose(dist.stddev.cpu().numpy(), g["mlp.std"], rtol=1e-6)
+    nt.assert_allclose(act["values"].cpu().numpy(), g["mlp.values"], rtol=1e-4, atol=1e-5)
+    nt.assert_allclose(dist.log_prob(mb["actions"]).cpu().numpy(), g["mlp.log_prob"], rtol=1e-4, atol=1e-4)
+    nt.assert_allclose(dist.entropy().cpu().numpy(), g["mlp.entropy"], rtol=1e-6)
+  # model(...) returns (mean, std, values); unbatched input strips the batch dim; float64 accepted
+  mean, std, values = model(mb["observations"][0].astype(np.float64))
+  assert mean.shape == (6,) and std.shape == (6,) and values.shape == (1,)
+  # rollout mode with supplied normals: a = mean + std * eps, log_prob of that action
+  head = model.head(model.prepare(mb["observations"]))
+  eps = torch.randn(64, 6, device=DEV)
+  actions, log_prob, vals = ops.normal_act(head, model.logstd.detach(), eps)
+  mean_o, std_o, val_o = oracle.mujoco_forward(weights, mb["observations"])
+  expect = mean_o.numpy() + std_o.numpy() * eps.cpu().numpy()
+  nt.assert_allclose(actions.cpu().numpy(), expect, rtol=1e-4, atol=1e-5)
+  lp, _ = oracle.diag_normal_log_prob_entropy(mean_o, std_o, actions.cpu())
+  nt.assert_allclose(log_prob.cpu().numpy(), lp.numpy(), rtol=1e-4, atol=1e-4)
+  nt.assert_allclose(vals.cpu().numpy(), val_o.numpy()[:, 0], rtol=1e-4, atol=1e-5)
+  roll = policy.act(mb["observations"].astype(np.float64))
+  assert list(roll.keys()) == ["actions", "log_prob", "values"]
+  assert roll["actions"].shape == (64, 6) and roll["actions"].dtype == np.float32
+  assert roll["log_prob"].shape == (64,) and roll["values"].shape == (64, 1)
+
+
+def test_normal_sampler_statistics():
+  from derl_amd import ops
+  B, P = 1 << 15, 6
+  head = torch.zeros(B, 32, device=DEV)
+  logstd = torch.tensor([0.0, -1.0, 0.5, 0.0, 0.2, -0.3], device=DEV)
+  actions, _, _ = ops.normal_act(head, logstd, None, seed=7, counter=3)
+  a = actions.cpu().numpy()
+  sigma = np.exp(logstd.cpu().numpy())
+  assert np.all(np.abs(a.mean(0)) < 5 * sigma / np.sqrt(B)), (a.mean(0), sigma)
+  nt.assert_allclose(a.std(0), np.exp(logstd.cpu().numpy()), rtol=0.03)
+  assert abs(np.corrcoef(a[:, 0], a[:, 1])[0, 1]) < 0.03
+
+
+class FakeRunner:
+  def __init__(self, policy, step_count):
+    self.policy, self.step_count = policy, step_count
+
+
+def test_ppo_mlp_trainer_steps_match_reference_golden():
+  import derl_amd as derl
+  from derl_amd.optim import Adam
+  from tests.test_oracle_golden import oracle_step_case, _check_summary
+  derl.summary.stop_recording()
+  cfg, g, params, names, data = oracle_step_case("ppo_step_mlp")
+  data["advantages"] = gi.mlp_minibatch(cfg["batch"], cfg["obs_dim"], cfg["act_dim"], cfg["seed"] + 50)["advantages"]
+  model = make_model(cfg["obs_dim"], cfg["act_dim"], params)
+  policy = derl.ActorCriticPolicy(model)
+  derl.NormalizeAdvantages()(data)
+  lr = derl.LinearAnneal(cfg["lr"], cfg["num_train_steps"], name="lr")
+  trainer = derl.Trainer(Adam(model, lr=lr.get_tensor(), eps=cfg["optimizer_epsilon"]), anneals=[lr],
+                         max_grad_norm=cfg["max_grad_norm"])
+  alg = derl.PPO(FakeRunner(policy, cfg["step_count"]), trainer, cliprange=cfg["cliprange"],
+                 value_loss_coef=cfg["value_loss_coef"], entropy_coef=cfg["entropy_coef"])
+  assert [k for k, _ in model.named_parameters()] == list(g["param_names"])
+  loss = alg.loss(data)
+  loss.backward()
+  nt.assert_allclose(loss.item(), g["loss0"], rtol=1e-5, atol=1e-5)
+  for k, p in model.named_parameters():
+    _check_summary(p.grad.cpu().numpy(), g, f"grad0.{k}", rtol=1e-4, atol=1e-5)
+  for step in range(cfg["nsteps"]):
+    if step == 2:
+      alg.runner.step_count += 4096
+    loss = alg.step(data)
+    nt.assert_allclose(loss.item(), g["losses"][step], rtol=1e-5, atol=1e-5)
+    nt.assert_equal(np.float32(lr.get_tensor().item()), g[f"lr.{step}"])
+    for k, p in model.named_parameters():
+      _check_summary(p.detach().cpu().numpy(), g, f"param{step}.{k}", rtol=1e-5, atol=2e-6)
+
+
+def test_upstream_ppo_pybullet_fixture():
+  """alg/ppo_test.py:45-53: loss and all 13 gradients of the seed-0 MuJoCoModel(26,[6,1])."""
+  import derl_amd as derl
+  torch.manual_seed(0)
+  model = derl.MuJoCoModel(26, [6, 1])
+  ref = om.init_mujoco(26, (6, 1), seed=0)
+  for k, v in model.state_dict().items():
+    nt.assert_array_equal(v.cpu().numpy(), ref[k].numpy())
+  with np.load(os.path.join(G, "upstream", "ppo_pybullet_interactions.npz")) as d:
+    data = {k: d[k] for k in d.files}
+  data["advantages"] = data["advantages"].astype(np.float32)
+  policy = derl.ActorCriticPolicy(model)
+  loss_fn = derl.PPOLoss(policy, cliprange=0.2, value_loss_coef=0.25, entropy_coef=0.0)
+  loss = loss_fn(data)
+  loss.backward()
+  expected = np.load(os.path.join(G, "upstream", "ppo_pybullet_losses.npy"))[0]
+  terms, _ = oracle.ppo_loss_and_grads(ref, data, "mlp", 0.2, 0.25, 0.0)
+  if abs(terms["loss"] - expected) > 1e-4:
+    pytest.skip("seed-0 init of this torch build does not reproduce the upstream model")
+  nt.assert_allclose(loss.item(), expected, rtol=1e-5, atol=1e-5)
+  with np.load(os.path.join(G, "upstream", "ppo_pybullet_grads.npz")) as eg:
+    for i, p in enumerate(model.parameters()):
+      nt.assert_allclose(p.grad.cpu().numpy(), eg[f"grad_{i}"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("batch,obs_dim,act_dim", [(1, 3, 2), (37, 17, 6), (4096, 17, 6), (300, 111, 8)])
+def test_mlp_gradients_ragged_shapes(batch, obs_dim, act_dim):
+  import derl_amd as derl
+  weights = gi.mujoco_weights(obs_dim, act_dim, batch)
+  mb = gi.mlp_minibatch(batch, obs_dim, act_dim, batch + 1)
+  model = make_model(obs_dim, act_dim, weights)
+  policy = derl.ActorCriticPolicy(model)
+  mean, std, vals = oracle.mujoco_forward(weights, mb["observations"])
+  lp, _ = oracle.diag_normal_log_prob_entropy(mean, std, mb["actions"])
+  data = dict(observations=mb["observations"], actions=mb["actions"],
+              log_prob=(lp.numpy() + mb["logp_noise"]).astype(np.float32),
+              advantages=mb["advantages"], values=(vals.numpy() + mb["value_noise"]).astype(np.float32),
+              value_targets=(vals.numpy() + mb["target_noise"]).astype(np.float32))
+  for loss_cls, oracle_fn, kw in ((derl.PPOLoss, oracle.ppo_loss_and_grads, dict(cliprange=0.2, value_loss_coef=0.25, entropy_coef=0.01)),
+                                  (derl.A2CLoss, oracle.a2c_loss_and_grads, dict(value_loss_coef=0.5, entropy_coef=0.01))):
+    loss = loss_cls(policy, **kw)(data)
+    loss.backward()
+    terms, grads = oracle_fn(weights, data, "mlp", *kw.values(), dtype=torch.float64)
+    nt.assert_allclose(loss.item(), terms["loss"], rtol=1e-4, atol=1e-5)
+    for k, p in model.named_parameters():
+      scale = np.abs(grads[k]).max()
+      nt.assert_allclose(p.grad.cpu().numpy(), grads[k], rtol=1e-4, atol=1e-6 + 1e-5 * scale, err_msg=k)
+
+
+def test_cartpole_ppo_config1_runs_end_to_end():
+  """BASELINE config 1 plumbing: PPO CartPole-v1 nenvs=8 nsteps=128 through the factory, host
+  env + generic runner path + MLP categorical model on the device."""
+  import derl_amd as derl
+  derl.summary.stop_recording()
+  torch.manual_seed(0)
+  np.random.seed(0)
+  env = derl.env.make("CartPole-v1", nenvs=8, seed=0)
+  kwargs = derl.PPOFactory.get_kwargs("atari")
+  kwargs.update(nenvs=8, num_runner_steps=128, num_train_steps=8 * 128 * 2)
+  alg = derl.PPOFactory(**kwargs).make(env)
+  assert isinstance(alg.model, derl.MLPCategoricalModel)
+  losses = [alg.step(data).item() for data in alg.runner.run()]
+  assert len(losses) == 2 * 3 * 4 and np.all(np.isfinite(losses))
+  assert alg.runner.step_count == 2048
