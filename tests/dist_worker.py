@@ -1,0 +1,125 @@
+"""Worker for the world_size-2 tests (launched by torch.distributed.run with the gloo backend).
+
+mode cpu_math : the sharding rules of SURVEY.md 8e with the CPU oracle as the compute --
+                per-rank gradients scaled by 1/global_batch, one SUM all-reduce, global
+                advantage statistics from one 3-double all-reduce -- equal the single-process
+                result on the concatenated batch.
+mode gpu_step : two ranks sharing one GPU run Trainer.step on half a minibatch each through the
+                HIP kernels; parameters after the step equal a single-process step on the
+                whole minibatch.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import inputs as gi  # noqa: E402
+import oracle  # noqa: E402
+from derl_amd import distributed  # noqa: E402
+
+
+def global_normalize(adv_local):
+  """NormalizeAdvantages under sharding: stats {sum, sumsq, count} all-reduced."""
+  a = adv_local.astype(np.float64)
+  stats = torch.tensor([a.sum(), (a ** 2).sum(), a.size], dtype=torch.float64)
+  distributed.all_reduce_sum(stats)
+  mean = stats[0].item() / stats[2].item()
+  var = max(stats[1].item() / stats[2].item() - mean * mean, 0.0)
+  return ((adv_local - np.float32(mean)) / (np.float32(np.sqrt(var)) + np.float32(1e-8))).astype(np.float32)
+
+
+def cpu_math():
+  world, rank = distributed.world_size(), distributed.rank()
+  assert world == 2
+  obs_dim, act_dim, B = 17, 6, 64
+  weights = gi.mujoco_weights(obs_dim, act_dim, 5)
+  mb = gi.mlp_minibatch(B, obs_dim, act_dim, 9)
+  mean, std, vals = oracle.mujoco_forward(weights, mb["observations"])
+  lp, _ = oracle.diag_normal_log_prob_entropy(mean, std, mb["actions"])
+  full = dict(observations=mb["observations"], actions=mb["actions"],
+              log_prob=(lp.numpy() + mb["logp_noise"]).astype(np.float32),
+              advantages=mb["advantages"], values=(vals.numpy() + mb["value_noise"]).astype(np.float32),
+              value_targets=(vals.numpy() + mb["target_noise"]).astype(np.float32))
+  sl = slice(rank * B // world, (rank + 1) * B // world)
+  shard = {k: v[sl] for k, v in full.items()}
+  shard["advantages"] = global_normalize(shard["advantages"])
+  ref = dict(full, advantages=oracle.normalize_advantages(full["advantages"]))
+  np.testing.assert_allclose(shard["advantages"], ref["advantages"][sl], rtol=1e-5, atol=1e-6)
+  _, grads = oracle.ppo_loss_and_grads(weights, shard, "mlp", 0.2, 0.25, 0.01, dtype=torch.float64)
+  flat = torch.cat([torch.from_numpy(np.asarray(g, np.float64)).reshape(-1) for g in grads.values()])
+  flat *= (B // world) / B  # what the loss kernel's 1/global_batch scaling does
+  distributed.all_reduce_mean_grads(flat)
+  _, gref = oracle.ppo_loss_and_grads(weights, ref, "mlp", 0.2, 0.25, 0.01, dtype=torch.float64)
+  fref = torch.cat([torch.from_numpy(np.asarray(g, np.float64)).reshape(-1) for g in gref.values()])
+  # the only difference is float32 rounding of the (globally) normalised advantages
+  np.testing.assert_allclose(flat.numpy(), fref.numpy(), rtol=1e-5, atol=1e-7)
+  # env sharding arithmetic used by bench.py
+  nenvs_total = 256
+  assert nenvs_total % world == 0 and sum(nenvs_total // world for _ in range(world)) == nenvs_total
+  t = torch.tensor([float(rank + 1)])
+  distributed.broadcast_(t, src=0)
+  assert t.item() == 1.0
+  print(f"rank {rank}: cpu_math OK", flush=True)
+
+
+def gpu_step():
+  import derl_amd as derl
+  from derl_amd.optim import Adam
+  world, rank = distributed.world_size(), distributed.rank()
+  derl.summary.stop_recording()
+  A, B = 4, 32
+  weights = gi.nature_cnn_weights(A, 3)
+  mb = gi.cnn_minibatch(B, A, 5)
+  logits, vals = oracle.nature_cnn_forward(weights, mb["observations"])
+  lp, _, _ = oracle.categorical_log_prob_entropy(logits, mb["actions"])
+  full = dict(observations=mb["observations"], actions=mb["actions"],
+              log_prob=(lp.numpy() + mb["logp_noise"]).astype(np.float32),
+              advantages=mb["advantages"], values=(vals.numpy() + mb["value_noise"]).astype(np.float32),
+              value_targets=(vals.numpy() + mb["target_noise"]).astype(np.float32))
+
+  class Runner:
+    step_count = 1000
+
+  def run(data, sharded):
+    model = derl.NatureCNNModel([A, 1], max_batch=32)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    policy = derl.ActorCriticPolicy(model)
+    runner = Runner()
+    runner.policy = policy
+    lr = derl.LinearAnneal(2.5e-4, 1e6, name="lr")
+    trainer = derl.Trainer(Adam(model, lr=lr.get_tensor(), eps=1e-5), anneals=[lr], max_grad_norm=0.5)
+    alg = derl.PPO(runner, trainer, cliprange=0.1, value_loss_coef=0.25, entropy_coef=0.01)
+    data = dict(data)
+    if sharded:
+      derl.NormalizeAdvantages()(data)  # global statistics through the process group
+      for _ in range(2):
+        alg.step(data)
+    else:
+      # single-process reference on the whole batch: hide the process group from the step
+      saved = distributed.world_size
+      distributed.world_size = lambda: 1
+      try:
+        derl.NormalizeAdvantages()(data)
+        for _ in range(2):
+          alg.step(data)
+      finally:
+        distributed.world_size = saved
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+  sl = slice(rank * B // world, (rank + 1) * B // world)
+  sharded = run({k: v[sl] for k, v in full.items()}, True)
+  single = run(full, False)
+  for k in single:
+    np.testing.assert_allclose(sharded[k], single[k], rtol=0, atol=2e-6, err_msg=k)
+  print(f"rank {rank}: gpu_step OK", flush=True)
+
+
+if __name__ == "__main__":
+  distributed.init_from_env(backend="gloo")
+  {"cpu_math": cpu_math, "gpu_step": gpu_step}[sys.argv[1]]()
+  torch.distributed.destroy_process_group()
