@@ -199,3 +199,49 @@ def test_minibatch_order_matches_reference():
         nt.assert_array_equal(mb["index"].cpu().numpy(), g[f"{tag}.{i}"])
         count += 1
       assert f"{tag}.{count}" not in g.files
+
+
+def test_a2c_factory_config5_shape_runs_and_matches_oracle_first_step():
+  """A2C (BASELINE config 5 shape, scaled down): nsteps=5, lambda=1, no minibatching, RMSprop.
+  The first update's loss equals the oracle's A2C loss on the same rollout."""
+  import derl_amd as derl
+  derl.summary.stop_recording()
+  torch.manual_seed(0)
+  env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=64, seed=3)
+  kwargs = derl.A2CFactory.get_kwargs()
+  kwargs.update(nenvs=64, num_train_steps=64 * 5 * 3)
+  alg = derl.A2CFactory(**kwargs).make(env)
+  weights0 = {k: v.detach().cpu().numpy().copy() for k, v in alg.model.state_dict().items()}
+  losses = []
+  for i, data in enumerate(alg.runner.run()):
+    assert data["observations"].shape == (320, 84, 84, 4) and data["advantages"].shape == (320,)
+    if i == 0:
+      host = {k: v.cpu().numpy() for k, v in data.items() if isinstance(v, torch.Tensor)}
+      terms, _ = oracle.a2c_loss_and_grads(weights0, host, "cnn", 0.5, 0.01)
+      buf = alg.runner.unwrapped._buffers
+      logits, last = oracle.nature_cnn_forward(weights0, buf["obs"][5].cpu().numpy())
+      adv_ref, vt_ref = oracle.gae_advantages(buf["rewards"].cpu().numpy(), buf["resets"].cpu().numpy(),
+                                              buf["values"].cpu().numpy(), last.numpy(), 0.99, 1.0)
+      nt.assert_allclose(host["advantages"], adv_ref.reshape(-1), rtol=1e-4, atol=1e-4)
+      nt.assert_allclose(host["value_targets"], vt_ref.reshape(-1, 1), rtol=1e-4, atol=1e-4)
+    losses.append(alg.step(data).item())
+    if i == 0:
+      nt.assert_allclose(losses[0], terms["loss"], rtol=1e-4, atol=1e-5)
+  assert len(losses) == 3 and np.all(np.isfinite(losses)) and alg.runner.step_count == 960
+  assert alg.trainer.optimizer.step_count == 3
+
+
+def test_cli_entry_point_runs_ppo(tmp_path):
+  """`derl ppo --env-id ... --logdir ...` (scripts/derl:15-34) as a subprocess."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  cmd = [sys.executable, os.path.join(root, "derl_amd", "scripts", "derl"), "ppo",
+         "--env-id", "BreakoutNoFrameskip-v4", "--logdir", str(tmp_path), "--nenvs", "8",
+         "--num-runner-steps", "8", "--num-train-steps", "128", "--nlogs", "2"]
+  out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+  assert out.returncode == 0, out.stderr[-2000:]
+  args = (tmp_path / "args.txt").read_text()
+  assert "env_id: BreakoutNoFrameskip-v4" in args and "num_minibatches: 4" in args
+  bad = subprocess.run(cmd[:2] + ["dqn"] + cmd[3:], capture_output=True, text=True, timeout=60)
+  assert bad.returncode != 0  # only the on-policy family is in scope
