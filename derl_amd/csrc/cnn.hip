@@ -88,6 +88,11 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
     int ms_cap, mper_cap;
     pick_msplit(layer_rows(c, l, c->max_batch), bkn, &ms_cap, &mper_cap);
     pick_msplit(layer_rows(c, l, B), bkn, &p.s[l].msplit, &p.s[l].mper);
+    if (l == L_C0) {  // one slab per persistent workgroup of the direct conv0 wgrad (<= 512)
+      const long long tiles = (layer_rows(c, l, B) + 255) / 256;
+      p.s[l].msplit = static_cast<int>(tiles < 512 ? tiles : 512);
+      p.s[l].mper = roundup((layer_rows(c, l, B) + p.s[l].msplit - 1) / p.s[l].msplit, 32);
+    }
     p.s[l].w_off = off;
     off += static_cast<long long>(ms_cap) * N * K;
     p.s[l].b_off = off;
@@ -272,6 +277,15 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
   NTArgs a;
   switch (stage) {
     case ST_CONV0_FWD:
+      if (obs_is_u8 && conv0_direct_supported(c->in_h, c->in_w, IC0, c->h0, c->w0)) {
+        Conv0Args d;
+        std::memset(&d, 0, sizeof(d));
+        d.obs = static_cast<const uint8_t *>(obs); d.idx = sample_idx;
+        d.in_h = c->in_h; d.in_w = c->in_w; d.h0 = c->h0; d.w0 = c->w0;
+        d.M = static_cast<int>(M0); d.ntiles = static_cast<int>((M0 + 255) / 256);
+        d.Wp = pk + c->pk_c0f; d.bias = w + c->off_b[0]; d.out = c->y0;
+        return launch_conv0_fwd(d, s);
+      }
       a = nt_args(conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), pk + c->pk_c0f,
                   w + c->off_b[0], c->y0, kC0, M0, kC0, 64 * IC0);
       return launch_nt(a, obs_is_u8 != 0, EPI_BIAS_RELU, stage, s);
@@ -327,6 +341,15 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       return launch_nt(a, false, EPI_MASK, stage, s);
     }
     case ST_CONV0_WGRAD:
+      if (obs_is_u8 && conv0_direct_supported(c->in_h, c->in_w, IC0, c->h0, c->w0)) {
+        Conv0Args d;
+        std::memset(&d, 0, sizeof(d));
+        d.obs = static_cast<const uint8_t *>(obs); d.idx = sample_idx;
+        d.in_h = c->in_h; d.in_w = c->in_w; d.h0 = c->h0; d.w0 = c->w0;
+        d.M = static_cast<int>(M0); d.ntiles = static_cast<int>((M0 + 255) / 256);
+        d.G = c->dy0; d.slab = c->slabs + plan.s[L_C0].w_off; d.bias_slab = c->slabs + plan.s[L_C0].b_off;
+        return launch_conv0_wgrad(d, plan.s[L_C0].msplit, s);
+      }
       return tn(L_C0, conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), c->dy0, kC0,
                 M0, kC0, 64 * IC0, obs_is_u8 != 0);
     case ST_FINALIZE: {

@@ -11,6 +11,7 @@
 //   TN: LDS rows are the reduction index m; a lane reads one float per MFMA, consecutive
 //       lanes -> consecutive banks.
 #include "igemm.hpp"
+#include <cstdlib>
 
 namespace dx {
 namespace {
@@ -86,13 +87,14 @@ __device__ __forceinline__ RowPos decode_row(const Gather &g, int m, bool valid)
 // ------------------------------------------------------------------------------------
 // TAG only names the instantiation: every network stage gets its own kernel symbol, so a
 // rocprofv3 --stats row is one stage (one shape), not a mix of layers.
-template <int TAG, int BM, int BN, int WM, int WN, bool AU8, int EPI>
+template <int TAG, int BM, int BN, int WM, int WN, bool AU8, int EPI, int BK = 32>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(const NTArgs a) {
   constexpr int NWN = BN / WN;
   constexpr int NT = 64 * (BM / WM) * NWN;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int LD = 36;        // 32 k + 4 pad floats: conflict-free ds_read_b128
-  constexpr int RPP = NT / 8;   // tile rows filled per pass (8 lanes x 4 k per row)
+  constexpr int LD = BK + 4;    // BK k + 4 pad floats: conflict-free ds_read_b128
+  constexpr int TPR = BK / 4;   // lanes per tile row (4 k each)
+  constexpr int RPP = NT / TPR; // tile rows filled per pass
   static_assert(BM % RPP == 0, "BM must be a multiple of the rows per pass");
   constexpr int APASS = BM / RPP;
   constexpr int BPASS = (BN + RPP - 1) / RPP;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int kper = a.K / a.ksplit;
   const int kbeg = blockIdx.z * kper, kend = kbeg + kper;
-  const int l8 = tid & 7, lr = tid >> 3;
+  const int l8 = tid % TPR, lr = tid / TPR;
 
   RowPos rows[APASS];
 #pragma unroll
@@ -150,8 +152,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
   };
   fetch(kbeg);
 
-  for (int kt = kbeg; kt < kend; kt += 32) {
-    __syncthreads();  // everyone finished reading the previous tile
+  const int abl = a.ablate;
+  for (int kt = kbeg; kt < kend; kt += BK) {
+    if (abl < 3) __syncthreads();  // everyone finished reading the previous tile
+    if (abl < 2 || kt == kbeg) {
 #pragma unroll
     for (int p = 0; p < APASS; ++p)
       *reinterpret_cast<float4 *>(&As[(p * RPP + lr) * LD + 4 * l8]) =
@@ -160,15 +164,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
     for (int p = 0; p < BPASS; ++p)
       if (p * RPP + lr < BN)
         *reinterpret_cast<float4 *>(&Bs[(p * RPP + lr) * LD + 4 * l8]) = masked(braw[p], wvalid[p]);
-    __syncthreads();
-    if (kt + 32 < kend) {  // prefetch the next tile; its latency hides under the MFMAs
-      q += 32;
+    }
+    if (abl < 3) __syncthreads();
+    if (kt + BK < kend && abl < 1) {  // prefetch the next tile; its latency hides under the MFMAs
+      q += BK;
       if (q >= g.seglen) { q = 0; ++seg; }
-      fetch(kt + 32);
+      fetch(kt + BK);
     }
     const int lrow = lane & 31, lk = 4 * (lane >> 5);
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
+    for (int qd = 0; qd < BK / 8; ++qd) {
       float4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -191,6 +196,21 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float *out = a.out + (a.ksplit > 1 ? blockIdx.z * a.slab_stride : 0);
   const OutMap &om = a.om;
+  // per column sub-tile: pixel-group offsets of the output map (uniform per j: scalar division
+  // once per sub-tile instead of runtime divisions per element)
+  int gy[TN], gx[TN], cc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = __builtin_amdgcn_readfirstlane(n0 + wn0 + 32 * j);
+    gy[j] = gx[j] = 0;
+    cc[j] = nb + (lane & 31);
+    if (om.enabled) {
+      const int g = nb / om.chan;
+      gy[j] = g / om.osx;
+      gx[j] = g - gy[j] * om.osx;
+      cc[j] = nb - g * om.chan + (lane & 31);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -210,11 +230,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
         if (n >= a.N) continue;
         long long o;
         if (om.enabled) {
-          const int g = n / om.chan, c = n - g * om.chan;
-          const int yy = static_cast<int>(oy) * om.osy + g / om.osx;
-          const int xx = static_cast<int>(ox) * om.osx + g % om.osx;
+          const int yy = static_cast<int>(oy) * om.osy + gy[j];
+          const int xx = static_cast<int>(ox) * om.osx + gx[j];
           if (yy >= om.OUT_H || xx >= om.OUT_W) continue;
-          o = ((static_cast<long long>(img) * om.OUT_H + yy) * om.OUT_W + xx) * a.ldc + c;
+          o = ((static_cast<long long>(img) * om.OUT_H + yy) * om.OUT_W + xx) * a.ldc + cc[j];
         } else {
           o = static_cast<long long>(m) * a.ldc + n;
         }
@@ -384,11 +403,14 @@ __global__ __launch_bounds__(256) void permute_reduce_kernel(const JobTable t) {
   }
 }
 
-template <int TAG, int BM, int BN, int WM, int WN, bool AU8, int EPI>
+template <int TAG, int BM, int BN, int WM, int WN, bool AU8, int EPI, int BK = 32>
 int launch_nt_as(const NTArgs &a, hipStream_t stream) {
+  DX_REQUIRE(a.g.seglen % BK == 0 && (a.K / a.ksplit) % BK == 0,
+             "igemm_nt: run length %d / K per split %d not a multiple of the K step %d", a.g.seglen,
+             a.K / a.ksplit, BK);
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.ksplit);
   dim3 block(64 * (BM / WM) * (BN / WN));
-  hipLaunchKernelGGL((igemm_nt_kernel<TAG, BM, BN, WM, WN, AU8, EPI>), grid, block, 0, stream, a);
+  hipLaunchKernelGGL((igemm_nt_kernel<TAG, BM, BN, WM, WN, AU8, EPI, BK>), grid, block, 0, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -408,11 +430,29 @@ int launch_tn_as(const TNArgs &a, hipStream_t stream) {
 // barrier pairs -- small ones (rollout batches) smaller tiles so that >= 256 workgroups exist.
 //   N <= 32 : 512x32 (4 waves of 128x32)  |  256x32 (4 waves of 64x32)
 //   N >= 64 : 256x64 (4 waves of 64x64)   |  128x64 (4 waves of 64x32)  |  64x64 (4 waves of 32x32)
-#define DX_NT_N64(ST, EPI)                                                            \
-  if (a.M >= 65536) return launch_nt_as<ST, 128, 64, 64, 32, false, EPI>(a, stream);  \
+static int nt_ablate() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_ABLATE"); v = e ? atoi(e) : 0; }
+  return v;
+}
+static int nt_cfg() {  // experiment switch (DX_NT_CFG), default 0
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_NT_CFG"); v = e ? atoi(e) : 0; }
+  return v;
+}
+#define DX_NT_N64(ST, EPI)                                                                      \
+  if (a.M >= 65536) {                                                                           \
+    const bool k64 = a.g.seglen % 64 == 0 && (a.K / a.ksplit) % 64 == 0;                        \
+    if (nt_cfg() == 1) return launch_nt_as<ST, 256, 64, 64, 64, false, EPI>(a, stream);         \
+    if (nt_cfg() == 2 && k64) return launch_nt_as<ST, 128, 64, 64, 32, false, EPI, 64>(a, stream); \
+    if (nt_cfg() == 3 && k64) return launch_nt_as<ST, 256, 64, 64, 64, false, EPI, 64>(a, stream); \
+    return launch_nt_as<ST, 128, 64, 64, 32, false, EPI>(a, stream);                            \
+  }                                                                                             \
   return launch_nt_as<ST, 64, 64, 32, 32, false, EPI>(a, stream)
 
-int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream) {
+int launch_nt(const NTArgs &a_in, bool a_u8, int epi, int stage, hipStream_t stream) {
+  NTArgs a = a_in;
+  a.ablate = nt_ablate();
   DX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "igemm_nt: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   DX_REQUIRE(a.g.seglen % 32 == 0 && a.g.nseg * a.g.seglen == a.K && a.g.nseg <= kMaxSeg,
              "igemm_nt: K=%d must be nseg(%d) x seglen(%d), seglen %% 32 == 0", a.K, a.g.nseg,

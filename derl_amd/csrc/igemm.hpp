@@ -76,6 +76,7 @@ struct NTArgs {
   int M, N, K;
   int ksplit;             // > 1: raw partial sums into slabs out + z*slab_stride
   long long slab_stride;
+  int ablate;             // timing experiments only (DX_ABLATE): 1 no global loads in the loop, 2 also no LDS writes, 3 also no barriers
 };
 
 // slab[z][n][k] = sum_{m in slice z} G[m][n] * A(m,k);  bias_slab[z][n] = sum_m G[m][n]
@@ -114,6 +115,21 @@ struct PermuteJob {
 };
 constexpr int kMaxJobs = 24;
 int launch_permute_reduce(const PermuteJob *jobs, int njobs, hipStream_t stream);
+
+// direct first-layer convolution on uint8 frames (conv0.hip)
+struct Conv0Args {
+  const uint8_t *obs;     // (imgs, in_h, in_w, 4) uint8
+  const int32_t *idx;     // optional image gather
+  int in_h, in_w, h0, w0;
+  int M, ntiles;          // output pixels = B*h0*w0, tiles of 256 pixels
+  const float *Wp, *bias; // forward: packed [32][256], bias [32]
+  float *out;             // forward: y0 [M][32]
+  const float *G;         // wgrad: dY0 [M][32]
+  float *slab, *bias_slab;  // wgrad: [nblocks][32][256], [nblocks][32]
+};
+bool conv0_direct_supported(int in_h, int in_w, int in_c, int h0, int w0);
+int launch_conv0_fwd(const Conv0Args &a, hipStream_t stream);
+int launch_conv0_wgrad(const Conv0Args &a, int nblocks, hipStream_t stream);
 int launch_heads_act_fused(const float *hid_slabs, int nslab, long long slab_stride, const float *Wh,
                            const float *bh, int B, int A, const float *uniforms, uint64_t seed,
                            uint64_t counter, int64_t *actions, float *log_prob, float *values,
