@@ -149,6 +149,7 @@ def main():
   start = time.perf_counter()
   for _ in range(args.steps):
     iteration()
+  enqueue_s = time.perf_counter() - start  # host time to enqueue everything (no sync inside)
   torch.cuda.synchronize()
   distributed.barrier()
   elapsed = torch.tensor([time.perf_counter() - start], dtype=torch.float64, device=device)
@@ -170,6 +171,7 @@ def main():
                  "nenvs_total": nenvs_total, "nenvs_per_gpu": nenvs, "nsteps": args.nsteps,
                  "minibatch_per_gpu": nenvs * args.nsteps // kwargs["num_minibatches"],
                  "updates_per_step": updates_per_iter, "parallelism": f"dp{world}",
+                 "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 3),
                  "final_loss": float(alg.loss_fn.last_terms[0].item())},
   }
 
@@ -180,27 +182,40 @@ def main():
     obs = alg.runner.unwrapped._buffers["obs"][:args.nsteps].reshape((-1,) + tuple(env.observation_space.shape))
     idx = torch.randperm(obs.shape[0], device=device)[:mb].to(torch.int32)
     train = time_stages(model, obs, idx, mb)
-    roll = time_stages(model, obs[:nenvs].contiguous(), None, nenvs)
-    # time per PPO iteration spent in each kernel: forward stages also run in the rollout
-    per_iter = {}
-    for name in STAGES:
-      t = train[name] * updates_per_iter
-      if name.endswith("_fwd"):
-        t += roll[name] * (args.nsteps + 1)
-      per_iter[name] = t
-    dominant = max((n for n in STAGES if stage_flops(n, 1, A) > 0), key=lambda n: per_iter[n])
+    # the rollout step runs its own path (dx_cnn_act: split-K linear layer + fused heads/sampling)
+    roll_obs = obs[:nenvs].contiguous()
+    ra = torch.empty(nenvs, dtype=torch.int64, device=device)
+    rl, rv = torch.empty(nenvs, device=device), torch.empty(nenvs, device=device)
+    for _ in range(3):
+      model.engine.act(roll_obs, ra, rl, rv)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+      model.engine.act(roll_obs, ra, rl, rv)
+    ev1.record()
+    ev1.synchronize()
+    act_us = ev0.elapsed_time(ev1) * 1e3 / 20
+    fwd_flops = sum(stage_flops(n, nenvs, A) for n in STAGES if n.endswith("_fwd"))
+    # dominant kernel = the training stage with the largest share of a PPO iteration
+    # (updates take ~80 % of the iteration; every stage is its own kernel symbol)
+    flop_stages = [n for n in STAGES if stage_flops(n, 1, A) > 0 and not n.startswith("heads")]
+    dominant = max(flop_stages, key=lambda n: train[n])
     tf = stage_flops(dominant, mb, A) / (train[dominant] * 1e-6) / 1e12
-    table = {n: {"train_us": round(train[n], 1), "rollout_us": round(roll[n], 1),
+    table = {n: {"train_us": round(train[n], 1),
                  "train_TFLOPs": round(stage_flops(n, mb, A) / (train[n] * 1e-6) / 1e12, 2)
                  if stage_flops(n, mb, A) else None,
-                 "us_per_iteration": round(per_iter[n], 1)} for n in STAGES}
+                 "us_per_iteration": round(train[n] * updates_per_iter, 1)} for n in STAGES}
     total_flops = sum(stage_flops(n, mb, A) for n in STAGES)
     total_us = sum(train[n] for n in STAGES)
     result["roofline"] = {
-        "bound": "mfma", "kernel": f"igemm stage {dominant} (batch {mb})",
+        "bound": "mfma", "kernel": f"{dominant} (minibatch {mb})",
         "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-        "network_fwd_bwd_achieved": round(total_flops / (total_us * 1e-6) / 1e12, 2),
+        "network_fwd_bwd": {"us": round(total_us, 1),
+                            "achieved": round(total_flops / (total_us * 1e-6) / 1e12, 2),
+                            "frac": round(total_flops / (total_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+        "rollout_act": {"batch": nenvs, "us": round(act_us, 1),
+                        "achieved": round(fwd_flops / (act_us * 1e-6) / 1e12, 2)},
         "stages": table}
     gae_local = time_gae(args.nsteps, nenvs)
     gae_big = time_gae(args.nsteps, 1 << 20)

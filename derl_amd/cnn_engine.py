@@ -148,6 +148,16 @@ class CnnEngine:
               _lib.ptr(uniforms), int(seed), int(counter), _lib.ptr(actions), _lib.ptr(log_prob),
               _lib.ptr(values), _lib.stream_ptr(self.device))
 
+  def rollout_synth(self, buffers, horizon, nenvs, policy_seed, policy_counter, env_seed,
+                    env_counter, p_reward, p_reset):
+    """Enqueues `horizon` (act, synthetic env step) pairs from one native call."""
+    self.pack()
+    _lib.call("dx_cnn_rollout_synth", ctypes.byref(self.ctx), _lib.ptr(buffers["obs"]),
+              int(horizon), int(nenvs), _lib.ptr(buffers["actions"]), _lib.ptr(buffers["log_prob"]),
+              _lib.ptr(buffers["values"]), _lib.ptr(buffers["rewards"]), _lib.ptr(buffers["resets"]),
+              int(policy_seed), int(policy_counter), int(env_seed), int(env_counter),
+              float(p_reward), float(p_reset), _lib.stream_ptr(self.device))
+
   def backward(self, obs, sample_idx=None):
     """Consumes self.dhead (B, 32) and fills self.grads (same obs / sample_idx as forward)."""
     batch, is_u8 = self._obs_args(obs, sample_idx)

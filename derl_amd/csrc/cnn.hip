@@ -142,10 +142,9 @@ int dx_cnn_init(dx_cnn_ctx *c) {
   c->y2_count = mb * d.flat;
   c->hid_count = mb * kHid;
   c->head_count = mb * kHeadLd;
-  // rollout path: [ksplit][B][512] partial slabs, ksplit = 14 (B <= 128), 7 (B <= 1024), else 1
+  // rollout path: [ksplit][B][512] partial slabs, ksplit = 7 (B <= 1024), else 1
   long long hs = mb;
-  const long long small = mb < 128 ? mb : 128, mid = mb < 1024 ? mb : 1024;
-  if (hs < 14 * small) hs = 14 * small;
+  const long long mid = mb < 1024 ? mb : 1024;
   if (hs < 7 * mid) hs = 7 * mid;
   c->hid_slab_count = hs * kHid;
   return DX_OK;
@@ -413,8 +412,8 @@ int dx_cnn_backward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const i
 
 // split of the 3136-deep linear layer over K for small batches (98 K-steps = 2 x 7 x 7)
 static int fc_ksplit(int B, int flat) {
-  const int steps = flat / 32;
-  int ks = B <= 128 ? 14 : (B <= 1024 ? 7 : 1);
+  const int steps = flat / 64 * 64 == flat ? flat / 64 : flat / 32;  // 64-deep K steps when possible
+  int ks = B <= 1024 ? 7 : 1;
   while (ks > 1 && steps % ks) --ks;
   return ks;
 }
@@ -438,6 +437,37 @@ int dx_cnn_act(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B, const
   return launch_heads_act_fused(c->hid_slabs, ks, a.slab_stride, c->packed + c->pk_hdf,
                                 c->packed + c->pk_hdb, B, c->num_actions, uniforms, seed, counter,
                                 actions, log_prob, values, s);
+}
+
+extern "C" int dx_synth_atari_step(void *frames, long long frame_bytes_total, float *rewards,
+                                   uint8_t *resets, int nenvs, uint64_t seed, uint64_t counter,
+                                   float p_reward, float p_reset, void *stream);
+
+// T rollout steps against the synthetic device env enqueued from one call (the per-step
+// launches are identical to calling dx_cnn_act + dx_synth_atari_step T times; this only
+// removes the host interpreter from between them).  Buffers are time-major:
+// obs (T+1, N, H, W, 4) uint8 with obs[0] given, actions (T, N) int64, log_prob / values /
+// rewards (T, N) float32, resets (T, N) bytes.
+int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_t *actions,
+                         float *log_prob, float *values, float *rewards, uint8_t *resets,
+                         uint64_t policy_seed, uint64_t policy_counter, uint64_t env_seed,
+                         uint64_t env_counter, float p_reward, float p_reset, void *stream) {
+  if (int rc = check_ctx(c, "dx_cnn_rollout_synth", N, false)) return rc;
+  DX_REQUIRE(T >= 1 && obs && actions && log_prob && values && rewards && resets,
+             "dx_cnn_rollout_synth: bad arguments");
+  const long long frame = static_cast<long long>(c->in_h) * c->in_w * c->in_c * N;
+  DX_REQUIRE(frame % 16 == 0, "dx_cnn_rollout_synth: frame batch must be a multiple of 16 bytes");
+  for (int t = 0; t < T; ++t) {
+    if (int rc = dx_cnn_act(c, obs + t * frame, 1, N, nullptr, policy_seed, policy_counter + t,
+                            actions + static_cast<long long>(t) * N, log_prob + static_cast<long long>(t) * N,
+                            values + static_cast<long long>(t) * N, stream))
+      return rc;
+    if (int rc = dx_synth_atari_step(obs + (t + 1) * frame, frame, rewards + static_cast<long long>(t) * N,
+                                     resets + static_cast<long long>(t) * N, N, env_seed, env_counter + t,
+                                     p_reward, p_reset, stream))
+      return rc;
+  }
+  return DX_OK;
 }
 
 // A single stage, for per-kernel timing (bench.py roofline) and layer-level tests.

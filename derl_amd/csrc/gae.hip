@@ -186,10 +186,12 @@ extern "C" int dx_gae_f32(const float *rewards, const uint8_t *resets, const flo
   const bool al16 = dx::aligned(rewards, 16) && dx::aligned(values, 16) &&
                     dx::aligned(last_values, 16) && dx::aligned(advantages, 16) &&
                     dx::aligned(value_targets, 16) && dx::aligned(resets, 4);
-  // widest lane vector that still leaves >= 2 blocks per CU (256 CUs)
+  // widest lane vector that still leaves >= 2 blocks per CU (256 CUs).  Measured at T=128,
+  // N=2^20 (TB/s algorithmic): <4,4,16> 5.16, <4,8,8> 4.82, <4,8,4> 4.99, <4,16,4> 4.86,
+  // <2,8,16> 4.47 -- short chunks on many waves win (90 VGPRs, 5 waves/SIMD).
   if (al16 && N % 4 == 0 && N >= 4 * 64 * 512)
-    return launch<4, 8, 8>(rewards, resets, values, last_values, T, N, gamma, lambda,
-                           advantages, value_targets, s);
+    return launch<4, 4, 16>(rewards, resets, values, last_values, T, N, gamma, lambda,
+                            advantages, value_targets, s);
   if (al16 && N % 2 == 0 && N >= 2 * 64 * 512)
     return launch<2, 8, 16>(rewards, resets, values, last_values, T, N, gamma, lambda,
                             advantages, value_targets, s);

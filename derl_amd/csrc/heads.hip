@@ -100,21 +100,38 @@ __global__ __launch_bounds__(256) void heads_act_fused_kernel(
   if (b >= B) return;  // whole wave exits together
   float h[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float *row = hid_slabs + static_cast<long long>(b) * 512 + lane * 8;
-  for (int z = 0; z < nslab; ++z) {
-    const float4 u = *reinterpret_cast<const float4 *>(row + z * slab_stride);
-    const float4 w = *reinterpret_cast<const float4 *>(row + z * slab_stride + 4);
-    h[0] += u.x; h[1] += u.y; h[2] += u.z; h[3] += u.w;
-    h[4] += w.x; h[5] += w.y; h[6] += w.z; h[7] += w.w;
+  // slabs in batches of 7 with all loads issued before the first add (clamped index, masked add)
+  for (int z0 = 0; z0 < nslab; z0 += 7) {
+    float4 u[7], w[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int z = min(z0 + i, nslab - 1);
+      u[i] = *reinterpret_cast<const float4 *>(row + z * slab_stride);
+      w[i] = *reinterpret_cast<const float4 *>(row + z * slab_stride + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const float k = (z0 + i) < nslab ? 1.f : 0.f;
+      h[0] += k * u[i].x; h[1] += k * u[i].y; h[2] += k * u[i].z; h[3] += k * u[i].w;
+      h[4] += k * w[i].x; h[5] += k * w[i].y; h[6] += k * w[i].z; h[7] += k * w[i].w;
+    }
   }
   float v[32];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    v[j] = 0.f;
-    if (j <= A) {  // uniform
-      const float4 u = *reinterpret_cast<const float4 *>(Wh + j * 512 + lane * 8);
-      const float4 w = *reinterpret_cast<const float4 *>(Wh + j * 512 + lane * 8 + 4);
-      v[j] = h[0] * u.x + h[1] * u.y + h[2] * u.z + h[3] * u.w + h[4] * w.x + h[5] * w.y +
-             h[6] * w.z + h[7] * w.w;
+  for (int j = 0; j < 32; ++j) v[j] = 0.f;
+#pragma unroll
+  for (int j0 = 0; j0 < 32; j0 += 8) {
+    if (j0 <= A) {  // uniform; rows beyond A are zero in the packed head matrix
+      float4 wu[8], ww[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        wu[jj] = *reinterpret_cast<const float4 *>(Wh + (j0 + jj) * 512 + lane * 8);
+        ww[jj] = *reinterpret_cast<const float4 *>(Wh + (j0 + jj) * 512 + lane * 8 + 4);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+        v[j0 + jj] = h[0] * wu[jj].x + h[1] * wu[jj].y + h[2] * wu[jj].z + h[3] * wu[jj].w +
+                     h[4] * ww[jj].x + h[5] * ww[jj].y + h[6] * ww[jj].z + h[7] * ww[jj].w;
     }
   }
   // reduce-scatter: after the steps lane l holds the sum over its 32-lane half of output l&31

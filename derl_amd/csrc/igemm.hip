@@ -435,19 +435,12 @@ static int nt_ablate() {
   if (v < 0) { const char *e = getenv("DX_ABLATE"); v = e ? atoi(e) : 0; }
   return v;
 }
-static int nt_cfg() {  // experiment switch (DX_NT_CFG), default 0
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NT_CFG"); v = e ? atoi(e) : 0; }
-  return v;
-}
+// Small problems (rollout batches) are latency-bound: 64-deep K steps halve the number of
+// barrier / load round trips per tile.
 #define DX_NT_N64(ST, EPI)                                                                      \
-  if (a.M >= 65536) {                                                                           \
-    const bool k64 = a.g.seglen % 64 == 0 && (a.K / a.ksplit) % 64 == 0;                        \
-    if (nt_cfg() == 1) return launch_nt_as<ST, 256, 64, 64, 64, false, EPI>(a, stream);         \
-    if (nt_cfg() == 2 && k64) return launch_nt_as<ST, 128, 64, 64, 32, false, EPI, 64>(a, stream); \
-    if (nt_cfg() == 3 && k64) return launch_nt_as<ST, 256, 64, 64, 64, false, EPI, 64>(a, stream); \
-    return launch_nt_as<ST, 128, 64, 64, 32, false, EPI>(a, stream);                            \
-  }                                                                                             \
+  if (a.M >= 65536) return launch_nt_as<ST, 128, 64, 64, 32, false, EPI>(a, stream);            \
+  if (a.g.seglen % 64 == 0 && (a.K / a.ksplit) % 64 == 0)                                       \
+    return launch_nt_as<ST, 64, 64, 32, 32, false, EPI, 64>(a, stream);                         \
   return launch_nt_as<ST, 64, 64, 32, 32, false, EPI>(a, stream)
 
 int launch_nt(const NTArgs &a_in, bool a_u8, int epi, int stage, hipStream_t stream) {

@@ -238,8 +238,23 @@ def _cnn_loss_forward_backward(model, policy, data, mode, cliprange, value_loss_
   return terms, backward_fn
 
 
+def _cnn_policy_rollout_into(model, policy, env, buffers, horizon):
+  """All `horizon` steps of the synthetic device env in one native call."""
+  from .env.synthetic import SyntheticAtariEnv  # pylint: disable=import-outside-toplevel
+  if not isinstance(env, SyntheticAtariEnv) or buffers["obs"].dtype != torch.uint8:
+    return False
+  nenvs = env.nenvs
+  model.reserve(nenvs)
+  model.engine.rollout_synth(buffers, horizon, nenvs, policy.seed, policy.act_counter, env.seed,
+                             env.counter, 0.1, env.p_reset)
+  policy.act_counter += horizon
+  env.counter += horizon
+  return True
+
+
 NatureCNNModel.policy_act = _cnn_policy_act
 NatureCNNModel.policy_act_into = _cnn_policy_act_into
+NatureCNNModel.policy_rollout_into = _cnn_policy_rollout_into
 NatureCNNModel.loss_forward_backward = _cnn_loss_forward_backward
 NatureCNNModel._loss_partials = None
 

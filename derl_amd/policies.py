@@ -74,6 +74,12 @@ class ActorCriticPolicy(Policy):
     buffers' slots for this step (no per-step allocations or copies)."""
     self.model.policy_act_into(self, observations, actions_out, log_prob_out, values_out)
 
+  def rollout_into(self, env, buffers, horizon):
+    """Whole-rollout fast path when model and env support enqueuing all steps from one native
+    call (same launches as the per-step loop).  Returns False if unsupported."""
+    fused = getattr(self.model, "policy_rollout_into", None)
+    return bool(fused and fused(self, env, buffers, horizon))
+
 
 def numpy_like_input(observations):
   return isinstance(observations, np.ndarray) or (

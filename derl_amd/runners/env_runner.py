@@ -79,12 +79,14 @@ class EnvRunner:
       self.env.reset(out=buf["obs"][0])
     else:
       buf["obs"][0].copy_(obs)
+    fused = getattr(self.policy, "rollout_into", None)
     while not self.is_exhausted():
-      for t in range(T):
-        self.policy.act_into(buf["obs"][t], buf["actions"][t], buf["log_prob"][t],
-                             buf["values"][t])
-        self.env.step(buf["actions"][t], out=buf["obs"][t + 1],
-                      rewards_out=buf["rewards"][t], resets_out=buf["resets"][t])
+      if fused is None or not fused(self.env, buf, T):
+        for t in range(T):
+          self.policy.act_into(buf["obs"][t], buf["actions"][t], buf["log_prob"][t],
+                               buf["values"][t])
+          self.env.step(buf["actions"][t], out=buf["obs"][t + 1],
+                        rewards_out=buf["rewards"][t], resets_out=buf["resets"][t])
       interactions = dict(
           observations=buf["obs"][:T], actions=buf["actions"], log_prob=buf["log_prob"],
           values=buf["values"], rewards=buf["rewards"], resets=buf["resets"],

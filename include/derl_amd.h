@@ -179,6 +179,15 @@ int dx_cnn_backward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
 int dx_cnn_act(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8, int B,
                const float *uniforms, uint64_t seed, uint64_t counter, int64_t *actions,
                float *log_prob, float *values, void *stream);
+/* T rollout steps against the synthetic device env, enqueued from one call -- the inner loop
+ * of derl/runners/env_runner.py:43-65 for the measurement env (same per-step launches as
+ * dx_cnn_act + dx_synth_atari_step; only the host interpreter between them is removed).
+ * obs (T+1, N, H, W, 4) uint8 with obs[0] given; actions (T, N) int64; log_prob, values,
+ * rewards (T, N) float32; resets (T, N) bytes. */
+int dx_cnn_rollout_synth(const dx_cnn_ctx *ctx, uint8_t *obs, int T, int N, int64_t *actions,
+                         float *log_prob, float *values, float *rewards, uint8_t *resets,
+                         uint64_t policy_seed, uint64_t policy_counter, uint64_t env_seed,
+                         uint64_t env_counter, float p_reward, float p_reset, void *stream);
 /* One launch of the network (one profiler row), for per-kernel timing and layer tests.
  * Stages in execution order: 0 conv0_fwd, 1 conv1_fwd, 2 conv2_fwd, 3 fc_fwd, 4 heads_fwd,
  * 5 heads_wgrad, 6 heads_dgrad, 7 fc_wgrad, 8 fc_dgrad, 9 conv2_wgrad, 10 conv2_dgrad,

@@ -245,3 +245,29 @@ def test_cli_entry_point_runs_ppo(tmp_path):
   assert "env_id: BreakoutNoFrameskip-v4" in args and "num_minibatches: 4" in args
   bad = subprocess.run(cmd[:2] + ["dqn"] + cmd[3:], capture_output=True, text=True, timeout=60)
   assert bad.returncode != 0  # only the on-policy family is in scope
+
+
+def test_fused_native_rollout_equals_per_step_loop():
+  """dx_cnn_rollout_synth enqueues the same launches as the Python per-step loop: identical
+  rollout buffers (same policy / env seeds and counters)."""
+  import derl_amd as derl
+  from derl_amd.policies import ActorCriticPolicy
+
+  def rollout(use_fused):
+    torch.manual_seed(0)
+    model = derl.NatureCNNModel([4, 1], max_batch=64)
+    policy = ActorCriticPolicy(model, seed=5)
+    if not use_fused:
+      policy.rollout_into = lambda *a, **k: False
+    env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=24, seed=2)
+    runner = derl.EnvRunner(env, policy, horizon=6, nsteps=24 * 6 * 2)
+    outs = []
+    for inter in runner.run():
+      outs.append({k: v.clone() for k, v in inter.items() if isinstance(v, torch.Tensor)})
+    return outs
+
+  a, b = rollout(True), rollout(False)
+  assert len(a) == len(b) == 2
+  for x, y in zip(a, b):
+    for k in x:
+      assert torch.equal(x[k], y[k]), k
