@@ -10,77 +10,11 @@
 //       row with one ds_read_b128 (conflict-free at stride 36) and feeds 4 MFMAs.
 //   TN: LDS rows are the reduction index m; a lane reads one float per MFMA, consecutive
 //       lanes -> consecutive banks.
-#include "igemm.hpp"
+#include "igemm_dev.hpp"
 #include <cstdlib>
 
 namespace dx {
 namespace {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-// uint8 -> float / 255, bit-identical to IEEE division for every byte value: q = x*r, one
-// fma residual step (checked exhaustively on the host in tests/test_host_logic.py).
-__device__ __forceinline__ float dequant_u8(uint32_t x) {
-  const float r = 1.0f / 255.0f;
-  const float xf = static_cast<float>(x);
-  const float q = xf * r;
-  const float e = __builtin_fmaf(-q, 255.0f, xf);
-  return __builtin_fmaf(e, r, q);
-}
-
-// Loads are unconditional (an invalid element reads offset 0 of the buffer and is zeroed by a
-// select when the tile is written to LDS) and keep the RAW words in registers: conversion and
-// masking happen one K-step later, after the MFMAs the load latency hides under.  A
-// conditional load compiles to a branch with an immediate vmcnt(0), which serialises every
-// load and leaves nothing in flight during the MFMAs.
-template <bool U8> struct Raw { using type = float4; };
-template <> struct Raw<true> { using type = uint32_t; };
-
-template <bool U8>
-__device__ __forceinline__ typename Raw<U8>::type load_raw(const void *base, long long off) {
-  if constexpr (U8)
-    return *reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + off);
-  else
-    return *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off);
-}
-
-__device__ __forceinline__ float4 to_float4(float4 v) { return v; }
-__device__ __forceinline__ float4 to_float4(uint32_t w) {
-  return make_float4(dequant_u8(w & 0xff), dequant_u8((w >> 8) & 0xff), dequant_u8((w >> 16) & 0xff),
-                     dequant_u8(w >> 24));
-}
-__device__ __forceinline__ float4 masked(float4 v, bool ok) {
-  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-}
-
-struct RowPos {
-  long long base;   // element offset of the row's origin pixel (channel 0)
-  uint32_t okmask;  // bit s: run s of this row lies inside the image (all runs if !check)
-};
-
-__device__ __forceinline__ RowPos decode_row(const Gather &g, int m, bool valid) {
-  RowPos r;
-  const uint32_t mm = valid ? static_cast<uint32_t>(m) : 0u;
-  uint32_t img = fdiv(mm, g.div_img);
-  const uint32_t rem = mm - img * g.OHW;
-  const uint32_t oy = fdiv(rem, g.div_row);
-  const uint32_t ox = rem - oy * g.OW;
-  if (g.idx) img = static_cast<uint32_t>(g.idx[img]);
-  const int y0 = static_cast<int>(oy) * g.sy, x0 = static_cast<int>(ox) * g.sx;
-  r.base = static_cast<long long>(img) * g.img_stride + static_cast<long long>(y0 * g.W + x0) * g.C;
-  uint32_t mask = 0xffffffffu;
-  if (g.check) {  // uniform branch, prologue / once per row
-    mask = 0;
-    for (int s = 0; s < g.nseg; ++s) {
-      const int yy = y0 + g.seg_dy[s], xx = x0 + g.seg_dx[s];
-      const bool in = static_cast<unsigned>(yy) < static_cast<unsigned>(g.H) &&
-                      static_cast<unsigned>(xx) < static_cast<unsigned>(g.W);
-      mask |= (in ? 1u : 0u) << s;
-    }
-  }
-  r.okmask = valid ? mask : 0u;
-  return r;
-}
 
 // ------------------------------------------------------------------------------------
 // NT kernel
@@ -430,6 +364,16 @@ int launch_tn_as(const TNArgs &a, hipStream_t stream) {
 // barrier pairs -- small ones (rollout batches) smaller tiles so that >= 256 workgroups exist.
 //   N <= 32 : 512x32 (4 waves of 128x32)  |  256x32 (4 waves of 64x32)
 //   N >= 64 : 256x64 (4 waves of 64x64)   |  128x64 (4 waves of 64x32)  |  64x64 (4 waves of 32x32)
+static int split_bf16() {  // DX_SPLIT_BF16=1: big NT stages on the bf16 matrix cores (3-way split)
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_SPLIT_BF16"); v = e ? atoi(e) : 0; }
+  return v;
+}
+static int split_min_m() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_SPLIT_MIN_M"); v = e ? atoi(e) : 65536; }
+  return v;
+}
 static int nt_ablate() {
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_ABLATE"); v = e ? atoi(e) : 0; }
@@ -458,6 +402,10 @@ int launch_nt(const NTArgs &a_in, bool a_u8, int epi, int stage, hipStream_t str
   DX_REQUIRE(a.M < (1 << 30), "igemm_nt: M too large");
   DX_REQUIRE(!a.om.enabled || (a.om.chan > 0 && a.om.chan % 32 == 0),
              "igemm_nt: output map needs a channel count that is a multiple of 32");
+  if (split_bf16() && !a_u8 && a.M >= split_min_m() && a.ablate == 0) {
+    const int rc = launch_nt_b3(a, epi, stage, stream);
+    if (rc != DX_ENOSUP) return rc;
+  }
   switch (stage) {
     case ST_CONV0_FWD:
       DX_REQUIRE(epi == EPI_BIAS_RELU && a.N <= 32, "igemm_nt: conv0 forward needs bias+relu, N <= 32");

@@ -101,6 +101,8 @@ enum Stage {
 
 int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream);
 int launch_tn(const TNArgs &a, bool a_u8, int stage, hipStream_t stream);
+// 3xbf16-split variant of the big NT stages (igemm_b3.hip); DX_ENOSUP = not covered
+int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream);
 
 // dst[i] = scale * sum_z src[z*slab_stride + off + d0*s0 + d1*s1 + d2*s2 + d3*s3], i = ((d0*D1+d1)*D2+d2)*D3+d3
 struct PermuteJob {

@@ -1,0 +1,253 @@
+// fp32-accurate GEMM on the bf16 matrix cores: every fp32 operand x is split EXACTLY into three
+// bf16 values x = hi + mid + lo (8 + 8 + 8 significand bits), and a product a*b is formed from
+// the six partial products whose weight is >= 2^-16 of the leading one:
+//     a_hi*b_hi + (a_hi*b_mid + a_mid*b_hi) + (a_hi*b_lo + a_mid*b_mid + a_lo*b_hi)
+// Each bf16 x bf16 product is exact in fp32 and accumulation is fp32 inside the MFMA, so the
+// result differs from an fp32 fma chain only by the dropped terms (2 * 2^-24 relative per
+// product, i.e. one fp32 rounding) -- the same tolerance class as a different summation order.
+// v_mfma_f32_32x32x16_bf16 issues every 32 cycles for 16 k, six of them replace eight
+// v_mfma_f32_32x32x2_f32 (64 cycles each): 192 vs 512 cycles per 32x32x16 block.
+//
+// Same interface, gathers and epilogues as igemm_nt_kernel; only the tile staging (split while
+// writing LDS, three planes of [rows][32 k] bf16 with 80-byte rows: conflict-free ds_read_b128)
+// and the MFMA body differ.
+#include "igemm_dev.hpp"
+
+namespace dx {
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {  // round-to-nearest-even
+  bf16x2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float lo_f32(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f32(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+struct Split4 {
+  uint2 hi, mid, lo;  // 4 bf16 each
+};
+
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
+  h = pack2(x0, x1);
+  const float r0 = x0 - lo_f32(h), r1 = x1 - hi_f32(h);  // exact
+  m = pack2(r0, r1);
+  l = pack2(r0 - lo_f32(m), r1 - hi_f32(m));             // exact residual, exact conversion
+}
+
+__device__ __forceinline__ Split4 split4(float4 v) {
+  Split4 s;
+  split2(v.x, v.y, s.hi.x, s.mid.x, s.lo.x);
+  split2(v.z, v.w, s.hi.y, s.mid.y, s.lo.y);
+  return s;
+}
+
+constexpr int kRowB = 80;  // bytes per LDS row: 32 bf16 + 16 pad
+
+template <int TAG, int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_b3_kernel(const NTArgs a) {
+  constexpr int NWN = BN / WN;
+  constexpr int NT = 64 * (BM / WM) * NWN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int BK = 32;
+  constexpr int RPP = NT / 8;
+  static_assert(BM % RPP == 0, "BM must be a multiple of the rows per pass");
+  constexpr int APASS = BM / RPP;
+  constexpr int BPASS = (BN + RPP - 1) / RPP;
+  constexpr int A_PLANE = BM * kRowB, B_PLANE = BN * kRowB;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[3 * (A_PLANE + B_PLANE)];
+  uint8_t *As = smem;                 // planes hi, mid, lo
+  uint8_t *Bs = smem + 3 * A_PLANE;
+
+  const Gather &g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kper = a.K / a.ksplit;
+  const int kbeg = blockIdx.z * kper, kend = kbeg + kper;
+  const int l8 = tid & 7, lr = tid >> 3;
+
+  RowPos rows[APASS];
+#pragma unroll
+  for (int p = 0; p < APASS; ++p) {
+    const int m = m0 + p * RPP + lr;
+    rows[p] = decode_row(g, m, m < a.M);
+  }
+  const float *wrow[BPASS];
+  bool wvalid[BPASS];
+#pragma unroll
+  for (int p = 0; p < BPASS; ++p) {
+    const int nr = p * RPP + lr;
+    wvalid[p] = nr < BN && (n0 + nr) < a.N;
+    wrow[p] = a.Wp + static_cast<long long>(wvalid[p] ? n0 + nr : 0) * a.K + 4 * l8;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int seg = kbeg / g.seglen, q = kbeg - seg * g.seglen;
+  float4 araw[APASS], braw[BPASS];
+  uint32_t aok = 0;
+  auto fetch = [&](int kt) {
+    const int sseg = __builtin_amdgcn_readfirstlane(seg);
+    const long long so = static_cast<long long>(g.seg_off[sseg]) + q + 4 * l8;
+    aok = 0;
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      const bool ok = (rows[p].okmask >> sseg) & 1u;
+      aok |= (ok ? 1u : 0u) << p;
+      araw[p] = load_raw<false>(g.src, ok ? rows[p].base + so : 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) braw[p] = *reinterpret_cast<const float4 *>(wrow[p] + kt);
+  };
+  fetch(kbeg);
+
+  for (int kt = kbeg; kt < kend; kt += BK) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      const Split4 s = split4(masked(araw[p], (aok >> p) & 1u));
+      const int o = (p * RPP + lr) * kRowB + 8 * l8;
+      *reinterpret_cast<uint2 *>(As + o) = s.hi;
+      *reinterpret_cast<uint2 *>(As + A_PLANE + o) = s.mid;
+      *reinterpret_cast<uint2 *>(As + 2 * A_PLANE + o) = s.lo;
+    }
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p)
+      if (p * RPP + lr < BN) {
+        const Split4 s = split4(masked(braw[p], wvalid[p]));
+        const int o = (p * RPP + lr) * kRowB + 8 * l8;
+        *reinterpret_cast<uint2 *>(Bs + o) = s.hi;
+        *reinterpret_cast<uint2 *>(Bs + B_PLANE + o) = s.mid;
+        *reinterpret_cast<uint2 *>(Bs + 2 * B_PLANE + o) = s.lo;
+      }
+    __syncthreads();
+    if (kt + BK < kend) {
+      q += BK;
+      if (q >= g.seglen) { q = 0; ++seg; }
+      fetch(kt + BK);
+    }
+    const int lrow = lane & 31, lk = 16 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // two 16-deep k steps per 32-k tile
+      bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = (wm0 + 32 * i + lrow) * kRowB + 32 * ks + lk;
+        ah[i] = *reinterpret_cast<const bf16x8 *>(As + o);
+        am[i] = *reinterpret_cast<const bf16x8 *>(As + A_PLANE + o);
+        al[i] = *reinterpret_cast<const bf16x8 *>(As + 2 * A_PLANE + o);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int o = (wn0 + 32 * j + lrow) * kRowB + 32 * ks + lk;
+        bh[j] = *reinterpret_cast<const bf16x8 *>(Bs + o);
+        bm[j] = *reinterpret_cast<const bf16x8 *>(Bs + B_PLANE + o);
+        bl[j] = *reinterpret_cast<const bf16x8 *>(Bs + 2 * B_PLANE + o);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // epilogue (identical to igemm_nt_kernel)
+  float *out = a.out + (a.ksplit > 1 ? blockIdx.z * a.slab_stride : 0);
+  const OutMap &om = a.om;
+  int gy[TN], gx[TN], cc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = __builtin_amdgcn_readfirstlane(n0 + wn0 + 32 * j);
+    gy[j] = gx[j] = 0;
+    cc[j] = nb + (lane & 31);
+    if (om.enabled) {
+      const int gg = nb / om.chan;
+      gy[j] = gg / om.osx;
+      gx[j] = gg - gy[j] * om.osx;
+      cc[j] = nb - gg * om.chan + (lane & 31);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= a.M) continue;
+      uint32_t img = 0, oy = 0, ox = 0;
+      if (om.enabled) {
+        img = fdiv(static_cast<uint32_t>(m), om.div_img);
+        const uint32_t rem = static_cast<uint32_t>(m) - img * om.OHW;
+        oy = fdiv(rem, om.div_row);
+        ox = rem - oy * om.OW;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + 32 * j + (lane & 31);
+        if (n >= a.N) continue;
+        long long o;
+        if (om.enabled) {
+          const int yy = static_cast<int>(oy) * om.osy + gy[j];
+          const int xx = static_cast<int>(ox) * om.osx + gx[j];
+          if (yy >= om.OUT_H || xx >= om.OUT_W) continue;
+          o = ((static_cast<long long>(img) * om.OUT_H + yy) * om.OUT_W + xx) * a.ldc + cc[j];
+        } else {
+          o = static_cast<long long>(m) * a.ldc + n;
+        }
+        float v = acc[i][j][r];
+        if (a.ksplit == 1) {
+          if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH) v += a.bias[n];
+          if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+          if (EPI == EPI_BIAS_TANH) v = tanhf(v);
+          if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
+          if (EPI == EPI_DTANH) { const float y = a.mask_src[o]; v *= 1.f - y * y; }
+        } else if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && blockIdx.z == 0) {
+          v += a.bias[n];
+        }
+        out[o] = v;
+      }
+    }
+}
+
+template <int TAG, int EPI>
+int launch_b3(const NTArgs &a, hipStream_t stream) {
+  dim3 grid(cdiv(a.M, 128), cdiv(a.N, 64), a.ksplit);
+  hipLaunchKernelGGL((igemm_nt_b3_kernel<TAG, 128, 64, 64, 32, EPI>), grid, dim3(256), 0, stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+}  // namespace
+
+// bf16x3-split variants of the big NT stages (float inputs, N >= 64).  Returns DX_ENOSUP for a
+// stage it does not cover so that the caller falls back to the fp32-MFMA kernel.
+int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream) {
+  if (a.g.seglen % 32 || (a.K / a.ksplit) % 32 || a.N < 64) return DX_ENOSUP;
+  switch (stage) {
+    case ST_CONV1_FWD: return epi == EPI_BIAS_RELU ? launch_b3<ST_CONV1_FWD, EPI_BIAS_RELU>(a, stream) : DX_ENOSUP;
+    case ST_CONV2_FWD: return epi == EPI_BIAS_RELU ? launch_b3<ST_CONV2_FWD, EPI_BIAS_RELU>(a, stream) : DX_ENOSUP;
+    case ST_FC_FWD: return epi == EPI_BIAS ? launch_b3<ST_FC_FWD, EPI_BIAS>(a, stream) : DX_ENOSUP;
+    case ST_FC_DGRAD: return epi == EPI_MASK ? launch_b3<ST_FC_DGRAD, EPI_MASK>(a, stream) : DX_ENOSUP;
+    case ST_CONV2_DGRAD: return epi == EPI_MASK ? launch_b3<ST_CONV2_DGRAD, EPI_MASK>(a, stream) : DX_ENOSUP;
+    case ST_CONV1_DGRAD: return epi == EPI_MASK ? launch_b3<ST_CONV1_DGRAD, EPI_MASK>(a, stream) : DX_ENOSUP;
+    default: return DX_ENOSUP;
+  }
+}
+
+}  // namespace dx

@@ -152,9 +152,11 @@ def ppo_loss_and_grads(params, data, kind="cnn", cliprange=0.1, value_loss_coef=
   common.py:68-70).  ``data`` holds observations, actions, log_prob, advantages,
   values (B,1), value_targets (B,1).  Returns (terms, grads dict keyed like params).
 
-  ``dtype=torch.float64`` evaluates the same algorithm in double precision: the ground
-  truth for batches >= ~128, where torch-CPU's float32 conv weight-gradient (oneDNN NCHW
-  path) is itself off by ~1e-4 relative (measured against float64)."""
+  ``dtype=torch.float64`` evaluates the same algorithm in double precision: the reference
+  for large batches, where some pre-activation inevitably lies within float32 rounding of
+  zero and float32 evaluations with different summation orders disagree on its ReLU mask
+  (measured: torch-CPU's NCHW and channels-last float32 paths differ on one unit at batch
+  130)."""
   leaf = _leaf_params(params, dtype)
   data = _cast_data(data, dtype)
   log_prob, entropy, values = _forward_dist(leaf, data, kind)

@@ -32,7 +32,7 @@ def nature_cnn_forward(params, observations):
   x = x.permute(0, 3, 1, 2)
   if x.dtype == torch.uint8:
     x = x.float() / 255
-  # float64 parameters select the high-precision evaluation used as ground truth for
+  # float64 parameters select the high-precision evaluation used as the reference for
   # large batches (the float32 dequantisation above is kept: it is part of the semantics)
   x = x.to(_t(params["base.conv-0.weight"]).dtype).contiguous()
   for i, stride in enumerate((4, 2, 1)):

@@ -169,13 +169,33 @@ def test_backward_ragged_batches_with_gather(batch):
   loss, grads = run_loss_and_backward(eng, data, 0, 0.1, 0.25, 0.01, A,
                                       torch.from_numpy(idx).to(DEV))
   odata = dict(data, observations=pool[idx])
-  # float64 evaluation of the oracle: torch-CPU float32 conv wgrad is itself ~1e-4 off at B>=128
+  # float64 evaluation of the oracle.  A pre-activation that lies within float32 rounding of
+  # zero may fall on either side of the ReLU depending on the summation order (at batch 130
+  # torch-CPU's own NCHW and channels-last float32 paths disagree on one conv-1 unit, which
+  # moves conv-0/1 gradients by ~1e-3 of their scale); when such units exist the gradient
+  # comparison allows for a flipped mask, otherwise it is tight.
   terms, ograds = oracle.ppo_loss_and_grads(weights, odata, "cnn", 0.1, 0.25, 0.01,
                                             dtype=torch.float64)
   nt.assert_allclose(loss[0], terms["loss"], rtol=1e-4, atol=1e-5)
+  ambiguous = count_ambiguous_relu_units(weights, pool[idx])
   for k, og in ograds.items():
     scale = np.abs(og).max()
-    nt.assert_allclose(grads[k].cpu().numpy(), og, rtol=1e-4, atol=1e-5 + 1e-5 * scale, err_msg=k)
+    atol = 1e-5 + 1e-5 * scale if ambiguous == 0 else 1e-5 + 4e-3 * scale
+    nt.assert_allclose(grads[k].cpu().numpy(), og, rtol=1e-4, atol=atol, err_msg=k)
+
+
+def count_ambiguous_relu_units(weights, obs, rel=3e-6):
+  """Number of conv pre-activations within `rel` of zero relative to their layer's scale
+  (float64 evaluation): units whose ReLU mask depends on float32 summation order."""
+  import torch.nn.functional as F
+  x = (torch.from_numpy(obs).permute(0, 3, 1, 2).float() / 255).double().contiguous()
+  count = 0
+  for i, s in enumerate((4, 2, 1)):
+    x = F.conv2d(x, torch.from_numpy(weights[f"base.conv-{i}.weight"]).double(),
+                 torch.from_numpy(weights[f"base.conv-{i}.bias"]).double(), stride=s)
+    count += int((x.abs() < rel * x.abs().max()).sum())
+    x = F.relu(x)
+  return count
 
 
 @pytest.mark.parametrize("batch,A", [(1, 4), (7, 6), (128, 4), (256, 4), (300, 18), (1500, 6)])
