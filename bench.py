@@ -116,7 +116,7 @@ def main():
   rank = distributed.rank()
   if world != max(args.gpus, 1) and rank == 0:
     print(f"warning: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
-  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
   torch.cuda.set_device(local_rank)
   device = torch.device("cuda", local_rank)
 
@@ -231,6 +231,7 @@ def main():
   if rank == 0:
     print(json.dumps(result), flush=True)
   if world > 1:
+    distributed.barrier()  # rank 0 may still be measuring the roofline
     torch.distributed.destroy_process_group()
 
 

@@ -28,7 +28,9 @@ def init_from_env(backend=None):
     return world_size()
   local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
   if backend is None:
-    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    # DERL_AMD_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get("DERL_AMD_DIST_BACKEND") or (
+        "nccl" if torch.cuda.is_available() else "gloo")
   if backend == "nccl":
     torch.cuda.set_device(local_rank)
   os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
