@@ -296,9 +296,20 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a = nt_args(conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), pk + c->pk_c2f,
                   w + c->off_b[2], c->y2, kC2, M2, kC2, 9 * kC1);
       return launch_nt(a, false, EPI_BIAS_RELU, stage, s);
-    case ST_FC_FWD:
-      a = nt_args(rows_gather(c->y2, flat), pk + c->pk_fcf, w + c->off_b[3], c->hid, kHid, B, kHid, flat);
-      return launch_nt(a, false, EPI_BIAS, stage, s);
+    case ST_FC_FWD: {
+      // small minibatches (multi-GPU shards): 49 sequential 64-deep K steps on 128 workgroups are
+      // a latency chain; split K 7 ways into the rollout slabs and sum them into hid
+      const int ks = (B <= 1024 && c->hid_slabs && 7LL * B * kHid <= c->hid_slab_count && flat % (7 * 64) == 0) ? 7 : 1;
+      a = nt_args(rows_gather(c->y2, flat), pk + c->pk_fcf, w + c->off_b[3], ks > 1 ? c->hid_slabs : c->hid,
+                  kHid, B, kHid, flat);
+      a.ksplit = ks;
+      a.slab_stride = static_cast<long long>(B) * kHid;
+      if (int rc = launch_nt(a, false, EPI_BIAS, stage, s)) return rc;
+      if (ks == 1) return DX_OK;
+      PermuteJob jr{c->hid_slabs, c->hid, static_cast<long long>(B) * kHid, 1, 1, 1, 1, 0, 0, 0, 0, ks,
+                    static_cast<long long>(B) * kHid, 0};
+      return launch_permute_reduce(&jr, 1, s);
+    }
     case ST_HEADS_FWD:
       a = nt_args(rows_gather(c->hid, kHid), pk + c->pk_hdf, pk + c->pk_hdb, c->head, kHeadLd, B, kHeadLd, kHid);
       return launch_nt(a, false, EPI_BIAS, stage, s);
@@ -354,7 +365,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     case ST_FINALIZE: {
       // slabs -> canonical gradients
       PermuteJob j[kMaxJobs];
-      int n = 0;
+      int n = 0, n_scatter = 0;
       float *g = c->grads;
       auto addw = [&](int layer, long long off_dst, long long total, int D1, int D2, int D3, long long s0,
                       long long s1, long long s2, long long s3, long long off, int N, int K) {
@@ -365,12 +376,15 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
         j[n++] = PermuteJob{c->slabs + plan.s[layer].b_off, g + off_dst, total, 1, 1, 1, 1, 0, 0, 0, off,
                             plan.s[layer].msplit, N};
       };
-      // conv: canonical (oc, ic, kh, kw) <- slab [oc][(kh*KW + kw)*IC + ic]
-      addw(L_C0, c->off_w[0], kC0 * 64LL * IC0, IC0, 8, 8, 64LL * IC0, 1, 8 * IC0, IC0, 0, kC0, 64 * IC0);
-      addw(L_C1, c->off_w[1], kC1 * 16LL * kC0, kC0, 4, 4, 16LL * kC0, 1, 4 * kC0, kC0, 0, kC1, 16 * kC0);
-      addw(L_C2, c->off_w[2], kC2 * 9LL * kC1, kC1, 3, 3, 9LL * kC1, 1, 3 * kC1, kC1, 0, kC2, 9 * kC1);
-      // linear: canonical (n, c, p) <- slab [n][p*64 + c]
-      addw(L_FC, c->off_w[3], static_cast<long long>(kHid) * flat, kC2, P, 1, flat, 1, kC2, 0, 0, kHid, flat);
+      // conv: iterate the slab [oc][kh][kw][ic] in its own order (coalesced slab reads) and
+      // scatter into the canonical (oc, ic, kh, kw) layout
+      addw(L_C0, c->off_w[0], kC0 * 64LL * IC0, 8, 8, IC0, IC0 * 64LL, 8, 1, 64, 0, kC0, 64 * IC0);
+      addw(L_C1, c->off_w[1], kC1 * 16LL * kC0, 4, 4, kC0, kC0 * 16LL, 4, 1, 16, 0, kC1, 16 * kC0);
+      addw(L_C2, c->off_w[2], kC2 * 9LL * kC1, 3, 3, kC1, kC1 * 9LL, 3, 1, 9, 0, kC2, 9 * kC1);
+      n_scatter = n;  // the jobs above scatter; the rest are identity maps
+      // linear: slab [n][p][c] -> canonical [n][c*P + p]
+      addw(L_FC, c->off_w[3], static_cast<long long>(kHid) * flat, P, kC2, 1, flat, 1, P, 0, 0, kHid, flat);
+      n_scatter = n;
       addw(L_HD, c->off_w[4], static_cast<long long>(A) * kHid, kHid, 1, 1, kHid, 1, 0, 0, 0, kHeadLd, kHid);
       addw(L_HD, c->off_w[5], kHid, kHid, 1, 1, kHid, 1, 0, 0, static_cast<long long>(A) * kHid, kHeadLd, kHid);
       addb(L_C0, c->off_b[0], kC0, 0, kC0);
@@ -379,6 +393,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       addb(L_FC, c->off_b[3], kHid, 0, kHid);
       addb(L_HD, c->off_b[4], A, 0, kHeadLd);
       addb(L_HD, c->off_b[5], 1, A, kHeadLd);
+      for (int i = 0; i < n_scatter; ++i) j[i].scatter = 1;
       return launch_permute_reduce(j, n, s);
     }
     default:

@@ -421,28 +421,39 @@ struct JobTable {
   PermuteJob jobs[kMaxJobs];
 };
 
-// Each output element is summed by a team of `team` consecutive lanes (1..64, power of two):
-// lane t of the team adds slabs z = t, t+team, ... and the team combines by shuffles, so a
-// layer with few outputs but many slabs (conv0: 8192 outputs x 1280 slabs) still fills the chip.
+// A workgroup owns 64 consecutive elements of the contiguous side; its 4 waves split the slabs (wave g sums
+// slabs z = g, g+4, ...) with the 64 lanes on consecutive elements, so every slab read is one
+// coalesced 256-B row when the source is contiguous along the fastest output dimension (all
+// finalize jobs), and the waves combine through LDS.  Loads are issued 8 deep.
 __global__ __launch_bounds__(256) void permute_reduce_kernel(const JobTable t) {
+  __shared__ float red[4][64];
   const PermuteJob &j = t.jobs[blockIdx.y];
-  const int team = j.team;
-  const int tl = threadIdx.x & (team - 1);
-  const long long per_block = blockDim.x / team;
-  const long long stride = static_cast<long long>(gridDim.x) * per_block;
-  // uniform trip count per team (shuffles need the whole team active)
-  for (long long i0 = static_cast<long long>(blockIdx.x) * per_block; i0 < j.total; i0 += stride) {
-    const long long i = i0 + threadIdx.x / team;
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long nchunks = (j.total + 63) / 64;
+  for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const long long i = c * 64 + lane;
     const bool active = i < j.total;
     long long rest = active ? i : 0;
     const long long d3 = rest % j.D3; rest /= j.D3;
     const long long d2 = rest % j.D2; rest /= j.D2;
     const long long d1 = rest % j.D1; rest /= j.D1;
-    const long long s = j.off + rest * j.s0 + d1 * j.s1 + d2 * j.s2 + d3 * j.s3;
+    const long long strided = rest * j.s0 + d1 * j.s1 + d2 * j.s2 + d3 * j.s3;
+    const float *src = j.src + j.off + (j.scatter ? (active ? i : 0) : strided);
     float v = 0.f;
-    for (int z = tl; z < j.nslab; z += team) v += j.src[z * j.slab_stride + s];
-    for (int o = team >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (active && tl == 0) j.dst[i] = v;
+    int z = g;
+    for (; z + 28 < j.nslab; z += 32) {  // 8 loads in flight
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = src[(z + 4 * u) * j.slab_stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += x[u];
+    }
+    for (; z < j.nslab; z += 4) v += src[z * j.slab_stride];
+    __syncthreads();  // previous chunk's reads of `red` are done
+    red[g][lane] = v;
+    __syncthreads();
+    if (g == 0 && active)
+      j.dst[j.scatter ? strided : i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
   }
 }
 
@@ -531,7 +542,9 @@ int launch_nt(const NTArgs &a_in, bool a_u8, int epi, int stage, hipStream_t str
     case ST_CONV1_FWD: DX_NT_N64(ST_CONV1_FWD, EPI_BIAS_RELU);
     case ST_CONV2_FWD: DX_NT_N64(ST_CONV2_FWD, EPI_BIAS_RELU);
     case ST_FC_FWD: DX_NT_N64(ST_FC_FWD, EPI_BIAS);
-    case ST_HEADS_FWD: return launch_nt_as<ST_HEADS_FWD, 256, 32, 64, 32, false, EPI_BIAS>(a, stream);
+    case ST_HEADS_FWD:
+      if (a.M <= 16384 && a.K % 64 == 0) return launch_nt_small<ST_HEADS_FWD, EPI_BIAS>(a, stream);
+      return launch_nt_as<ST_HEADS_FWD, 256, 32, 64, 32, false, EPI_BIAS>(a, stream);
     case ST_HEADS_DGRAD: return launch_nt_as<ST_HEADS_DGRAD, 128, 64, 64, 32, false, EPI_NONE>(a, stream);
     case ST_FC_DGRAD: DX_NT_N64(ST_FC_DGRAD, EPI_MASK);
     // zero-fill gathers: 64x64 tiles win at every size (minibatch 8192: 472 vs 504 us, 600 vs 711 us)
@@ -578,13 +591,9 @@ int launch_permute_reduce(const PermuteJob *jobs, int njobs, hipStream_t stream)
                    jobs[i].D3 > 0,
                "permute_reduce: bad job %d", i);
     t.jobs[i] = jobs[i];
-    // team size: enough lanes in flight (~256k) without exceeding the slab count
-    int team = 1;
-    while (team < 64 && team * 2 <= jobs[i].nslab && jobs[i].total * team < (1 << 18)) team *= 2;
-    t.jobs[i].team = team;
-    if (jobs[i].total * team > biggest) biggest = jobs[i].total * team;
+    if (jobs[i].total > biggest) biggest = jobs[i].total;
   }
-  int bx = cdiv(biggest, 256 * 4);
+  int bx = cdiv(biggest, 64);
   if (bx > 2048) bx = 2048;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(permute_reduce_kernel, dim3(bx, njobs), dim3(256), 0, stream, t);

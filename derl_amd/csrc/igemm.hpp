@@ -104,7 +104,9 @@ int launch_tn(const TNArgs &a, bool a_u8, int stage, hipStream_t stream);
 // 3xbf16-split variant of the big NT stages (igemm_b3.hip); DX_ENOSUP = not covered
 int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream);
 
-// dst[i] = scale * sum_z src[z*slab_stride + off + d0*s0 + d1*s1 + d2*s2 + d3*s3], i = ((d0*D1+d1)*D2+d2)*D3+d3
+// gather (scatter = 0): dst[i] = sum_z src[z*slab_stride + off + d0*s0 + d1*s1 + d2*s2 + d3*s3]
+// scatter (scatter = 1): dst[d0*s0 + d1*s1 + d2*s2 + d3*s3] = sum_z src[z*slab_stride + off + i]
+// with i = ((d0*D1+d1)*D2+d2)*D3+d3 the CONTIGUOUS side (slab reads stay coalesced when scattering)
 struct PermuteJob {
   const float *src;
   float *dst;
@@ -113,7 +115,7 @@ struct PermuteJob {
   long long s0, s1, s2, s3, off;
   int nslab;
   long long slab_stride;
-  int team;  // set by launch_permute_reduce
+  int scatter;
 };
 constexpr int kMaxJobs = 24;
 int launch_permute_reduce(const PermuteJob *jobs, int njobs, hipStream_t stream);
