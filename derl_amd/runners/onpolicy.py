@@ -78,11 +78,20 @@ class IterateWithMinibatches(RunnerWrapper):
         if isinstance(val, torch.Tensor) and val.is_cuda:
           device = val.device
           break
+      # All epochs' composed permutations are drawn up front (nothing else consumes np.random
+      # between the reference's per-epoch draws, so the stream is identical) and uploaded with
+      # ONE pinned, non-blocking copy: a pageable H2D copy per epoch would drain the stream.
+      orders = []
       for _ in range(self.num_epochs):
         if self.shuffle_before_epoch:
           order = order[np.random.permutation(sample_size)]
-        order_dev = (torch.from_numpy(order.astype(np.int32)).to(device)
-                     if device is not None else None)
+        orders.append(order)
+      orders_dev = None
+      if device is not None:
+        host = torch.from_numpy(np.stack(orders).astype(np.int32)).pin_memory()
+        orders_dev = host.to(device, non_blocking=True)
+      for epoch, order in enumerate(orders):
+        order_dev = orders_dev[epoch] if orders_dev is not None else None
         mbsize = sample_size // self.num_minibatches
         for start in range(0, sample_size, mbsize):
           stop = min(start + mbsize, sample_size)
