@@ -30,6 +30,7 @@ SIGNATURES = {
     "dx_clip_rmsprop_step_f32": [P, P, P, c_longlong, P, c_int, c_double, c_double, c_double,
                                  c_double, P, P],
     "dx_gather_rows": [P, P, P, c_longlong, c_longlong, P],
+    "dx_gather_rows_multi": [P, P, P, c_int, P, c_longlong, P],
     "dx_categorical_act_f32": [P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
     "dx_categorical_loss_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float,
                                 c_float, c_longlong, P, P, c_int, P, P],
@@ -119,9 +120,19 @@ def ptr(tensor):
   return c_void_p(tensor.data_ptr())
 
 
+_raw_stream = None
+
+
 def stream_ptr(device=None):
   """The current torch HIP stream as void* (torch is the stream/memory plumbing)."""
+  global _raw_stream  # pylint: disable=global-statement
   import torch
+  if _raw_stream is None:
+    # the raw getter is ~20x cheaper than building a torch.cuda.Stream object per call
+    _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)  # pylint: disable=protected-access
+  index = getattr(device, "index", device)
+  if _raw_stream and isinstance(index, int):
+    return c_void_p(_raw_stream(index))
   return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

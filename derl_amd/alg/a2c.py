@@ -24,6 +24,14 @@ class A2CLoss(ActorCriticDeviceLoss):
     terms, _ = self._evaluate(trajectory, None, self.value_loss_coef, self.entropy_coef)
     return terms[3]
 
+  def evaluate_native(self, data):
+    """(loss scalar on the device, model-backward closure); see PPOLoss.evaluate_native."""
+    terms, backward_fn = self._evaluate(data, None, self.value_loss_coef, self.entropy_coef)
+    if summary.should_record():
+      self._summaries(terms)
+    self.call_count += 1
+    return terms[0], backward_fn
+
   def __call__(self, data):
     terms, backward_fn = self._evaluate(data, None, self.value_loss_coef, self.entropy_coef)
     if summary.should_record():

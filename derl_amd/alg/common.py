@@ -53,6 +53,9 @@ class Loss(ABC):
   def to_device(self, arr, dtype=None):
     """Host array or tensor -> contiguous device tensor (the reference's
     torch_from_numpy, alg/common.py:39-41); device tensors pass through."""
+    if isinstance(arr, torch.Tensor) and arr.is_cuda and (dtype is None or arr.dtype == dtype) \
+        and arr.is_contiguous():
+      return arr  # minibatches of the device-resident runner: nothing to do
     if not isinstance(arr, torch.Tensor):
       arr = torch.as_tensor(arr)
     return arr.to(device=self.device, dtype=dtype).contiguous()
@@ -93,9 +96,19 @@ class Trainer:
       summary.add_scalar(tag, grad_norm, global_step=self.step_count)
 
   def step(self, alg, data):
-    loss = alg.loss(data)
-    self.optimizer.zero_grad()
-    loss.backward()
+    native = None
+    if isinstance(self.optimizer, _FlatOptimizer) and type(alg).loss is Alg.loss:
+      native = getattr(alg.loss_fn, "evaluate_native", None)
+    if native is not None:
+      # same launches as loss -> backward below, without building a one-node autograd graph
+      # per update (the head gradient already sits in the engine when the loss returns)
+      loss, backward_fn = native(data)
+      self.optimizer.zero_grad()
+      backward_fn(None)
+    else:
+      loss = alg.loss(data)
+      self.optimizer.zero_grad()
+      loss.backward()
     self.preprocess_gradients(alg.model.parameters(), f"{alg.name}/grad_norm")
     for anneal in self.anneals:
       if summary.should_record():

@@ -85,6 +85,16 @@ class PPOLoss(ActorCriticDeviceLoss):
     terms, _ = self._evaluate(trajectory, self.cliprange, self.value_loss_coef, self.entropy_coef)
     return terms[3]
 
+  def evaluate_native(self, data):
+    """(loss scalar on the device, closure running the model backward): what ``__call__``
+    wraps into an autograd scalar; Trainer.step calls the closure directly."""
+    terms, backward_fn = self._evaluate(data, self.cliprange, self.value_loss_coef,
+                                        self.entropy_coef)
+    if summary.should_record():
+      self._summaries(terms)
+    self.call_count += 1
+    return terms[0], backward_fn
+
   def __call__(self, data):
     terms, backward_fn = self._evaluate(data, self.cliprange, self.value_loss_coef,
                                         self.entropy_coef)

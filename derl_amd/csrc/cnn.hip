@@ -7,6 +7,7 @@
 // the NHWC activations.  NOTE (models.py:112,119-124): the reference flattens NCHW, so the
 // 3136-wide linear layer is permuted while packing; there is no ReLU after it.
 #include "igemm.hpp"
+#include <cstdlib>
 #include <cstring>
 
 using namespace dx;
@@ -20,6 +21,12 @@ struct Derived {
 };
 
 int conv_out(int n, int k, int s) { return (n - k) / s + 1; }
+
+bool conv0_f32() {  // DX_CONV0_F32=1: first layer on the fp32 matrix instructions (conv0.hip)
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_CONV0_F32"); v = e ? atoi(e) : 0; }
+  return v != 0;
+}
 
 int roundup(long long v, int m) { return static_cast<int>((v + m - 1) / m * m); }
 
@@ -276,6 +283,12 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
   NTArgs a;
   switch (stage) {
     case ST_CONV0_FWD:
+      a = nt_args(conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), pk + c->pk_c0f,
+                  w + c->off_b[0], c->y0, kC0, M0, kC0, 64 * IC0);
+      if (obs_is_u8) {  // rollout-sized batches: latency-shaped kernel
+        const int rc = launch_nt_lat(a, true, EPI_BIAS_RELU, stage, s);
+        if (rc != DX_ENOSUP) return rc;
+      }
       if (obs_is_u8 && conv0_direct_supported(c->in_h, c->in_w, IC0, c->h0, c->w0)) {
         Conv0Args d;
         std::memset(&d, 0, sizeof(d));
@@ -283,10 +296,8 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
         d.in_h = c->in_h; d.in_w = c->in_w; d.h0 = c->h0; d.w0 = c->w0;
         d.M = static_cast<int>(M0); d.ntiles = static_cast<int>((M0 + 255) / 256);
         d.Wp = pk + c->pk_c0f; d.bias = w + c->off_b[0]; d.out = c->y0;
-        return launch_conv0_fwd(d, s);
+        return conv0_f32() ? launch_conv0_fwd(d, s) : launch_conv0_fwd_b16(d, s);
       }
-      a = nt_args(conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), pk + c->pk_c0f,
-                  w + c->off_b[0], c->y0, kC0, M0, kC0, 64 * IC0);
       return launch_nt(a, obs_is_u8 != 0, EPI_BIAS_RELU, stage, s);
     case ST_CONV1_FWD:
       a = nt_args(conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), pk + c->pk_c1f,
@@ -358,7 +369,8 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
         d.in_h = c->in_h; d.in_w = c->in_w; d.h0 = c->h0; d.w0 = c->w0;
         d.M = static_cast<int>(M0); d.ntiles = static_cast<int>((M0 + 255) / 256);
         d.G = c->dy0; d.slab = c->slabs + plan.s[L_C0].w_off; d.bias_slab = c->slabs + plan.s[L_C0].b_off;
-        return launch_conv0_wgrad(d, plan.s[L_C0].msplit, s);
+        return conv0_f32() ? launch_conv0_wgrad(d, plan.s[L_C0].msplit, s)
+                           : launch_conv0_wgrad_b16(d, plan.s[L_C0].msplit, s);
       }
       return tn(L_C0, conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), c->dy0, kC0,
                 M0, kC0, 64 * IC0, obs_is_u8 != 0);

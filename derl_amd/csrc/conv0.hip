@@ -13,12 +13,10 @@
 //             (k = kh*32 + kw*4 + c is 32 consecutive bytes of an input row), reduction over the
 //             256 pixels of the tile; a workgroup loops over tiles and writes one slab.
 // No barrier inside the 256-MFMA body of a tile; workgroups loop over tiles (persistent).
-#include "igemm.hpp"
+#include "conv0_tile.hpp"
 
 namespace dx {
 namespace {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __device__ __forceinline__ float dq(uint32_t x) {  // exact x / 255 (see igemm.hip dequant_u8)
 #ifdef DX_CONV0_FASTDQ
@@ -31,85 +29,7 @@ __device__ __forceinline__ float dq(uint32_t x) {  // exact x / 255 (see igemm.h
 #endif
 }
 
-constexpr int kTile = 256;    // output pixels per tile
 constexpr int kWLd = 260;     // LDS row stride of the packed weights (256 + 4 pad floats)
-
-struct Seg {       // the (at most two) images a tile touches
-  int cnt_a, cnt_b;      // pixels of the tile in the first / second image
-  int pa;                // first pixel inside the first image
-  int oya0;              // first output row of segment a
-  long long src_a, src_b;  // byte offsets of the staged ranges in the observation buffer
-  int bytes_a, bytes_b;
-};
-
-__device__ __forceinline__ Seg tile_segments(const Conv0Args &a, int m0) {
-  Seg s;
-  const int P = a.h0 * a.w0;
-  const int rowB = a.in_w * 4;
-  const long long imgB = static_cast<long long>(a.in_h) * rowB;
-  const int left = min(kTile, a.M - m0);
-  const int img_a = m0 / P;
-  s.pa = m0 - img_a * P;
-  s.cnt_a = min(left, P - s.pa);
-  s.cnt_b = left - s.cnt_a;
-  s.oya0 = s.pa / a.w0;
-  const int oya1 = (s.pa + s.cnt_a - 1) / a.w0;
-  const long long ia = a.idx ? a.idx[img_a] : img_a;
-  s.src_a = ia * imgB + static_cast<long long>(4 * s.oya0) * rowB;
-  s.bytes_a = (4 * (oya1 - s.oya0) + 8) * rowB;
-  s.src_b = 0;
-  s.bytes_b = 0;
-  if (s.cnt_b > 0) {
-    const long long ib = a.idx ? a.idx[img_a + 1] : img_a + 1;
-    s.src_b = ib * imgB;
-    s.bytes_b = (4 * ((s.cnt_b - 1) / a.w0) + 8) * rowB;
-  }
-  return s;
-}
-
-// byte offset inside the LDS patch of input pixel (4*oy, 4*ox) for tile pixel p (0 if p is padding)
-__device__ __forceinline__ int pixel_base(const Conv0Args &a, const Seg &s, int p) {
-  const int rowB = a.in_w * 4;
-  if (p < s.cnt_a) {
-    const int pix = s.pa + p;
-    const int oy = pix / a.w0, ox = pix - oy * a.w0;
-    return 4 * (oy - s.oya0) * rowB + ox * 16;
-  }
-  if (p < s.cnt_a + s.cnt_b) {
-    const int pix = p - s.cnt_a;
-    const int oy = pix / a.w0, ox = pix - oy * a.w0;
-    return s.bytes_a + 4 * oy * rowB + ox * 16;
-  }
-  return 0;
-}
-
-// Both byte ranges -> LDS patch (range b follows range a), split in two halves so that the
-// global loads of tile t+1 are in flight during the MFMA body of tile t:
-//   patch_load : up to 6 x 16 B per lane into registers, unconditional (clamped index)
-//   patch_store: registers -> LDS after the barrier that retires the previous tile's reads
-constexpr int kPatchRegs = 6;  // 6 * 256 lanes * 16 B = 24 KB >= the largest patch (launch-checked)
-
-__device__ __forceinline__ void patch_load(const Conv0Args &a, const Seg &s, uint4 (&v)[kPatchRegs]) {
-  const uint4 *sa = reinterpret_cast<const uint4 *>(a.obs + s.src_a);
-  const uint4 *sb = reinterpret_cast<const uint4 *>(a.obs + s.src_b);
-  const int na = s.bytes_a / 16, n = na + s.bytes_b / 16;
-#pragma unroll
-  for (int u = 0; u < kPatchRegs; ++u) {
-    const int i = u * 256 + threadIdx.x;
-    const int ic = i < n ? i : 0;
-    v[u] = *(ic < na ? sa + ic : sb + (ic - na));
-  }
-}
-
-__device__ __forceinline__ void patch_store(const Seg &s, const uint4 (&v)[kPatchRegs], uint8_t *patch) {
-  uint4 *dst = reinterpret_cast<uint4 *>(patch);
-  const int n = (s.bytes_a + s.bytes_b) / 16;
-#pragma unroll
-  for (int u = 0; u < kPatchRegs; ++u) {
-    const int i = u * 256 + threadIdx.x;
-    if (i < n) dst[i] = v[u];
-  }
-}
 
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const Conv0Args a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -124,7 +44,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const Conv0Args a) {
   }
   const int lrow = lane & 31, h = lane >> 5;
   const float bias = a.bias[lrow];
-  uint4 pre[kPatchRegs];
+  u32x4 pre[kPatchRegs];
   if (blockIdx.x < a.ntiles) patch_load(a, tile_segments(a, blockIdx.x * kTile), pre);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int m0 = tile * kTile;
@@ -188,11 +108,11 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const Conv0Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t2][r] = 0.f;
   float bias_acc = 0.f;
-  uint4 pre[kPatchRegs];
-  float4 gpre[8];
+  u32x4 pre[kPatchRegs];
+  f32x4 gpre[8];
   // dY0 tile: 256 rows x 32 floats, contiguous; rows beyond M are zeroed when stored
   auto g_load = [&](int m0) {
-    const float4 *g4 = reinterpret_cast<const float4 *>(a.G + static_cast<long long>(m0) * 32);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(a.G + static_cast<long long>(m0) * 32);
     const int nvalid = min(kTile, a.M - m0) * 8;
 #pragma unroll
     for (int u = 0; u < 8; ++u) gpre[u] = g4[min(tid + u * 256, nvalid - 1)];
@@ -207,11 +127,11 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const Conv0Args a) {
     __syncthreads();
     patch_store(s, pre, patch);
     {
-      float4 *d4 = reinterpret_cast<float4 *>(Gs);
+      f32x4 *d4 = reinterpret_cast<f32x4 *>(Gs);
       const int nvalid = min(kTile, a.M - m0) * 8;
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        d4[tid + u * 256] = (tid + u * 256) < nvalid ? gpre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        d4[tid + u * 256] = (tid + u * 256) < nvalid ? gpre[u] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     rbtab[tid] = pixel_base(a, s, tid);
     __syncthreads();
@@ -251,12 +171,6 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const Conv0Args a) {
     if (tid < 32)
       a.bias_slab[static_cast<long long>(blockIdx.x) * 32 + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
   }
-}
-
-int patch_bytes(const Conv0Args &a) {
-  // rows of the (at most two) staged ranges: 4 per output row touched + 4 per range
-  const int out_rows = kTile / a.w0 + 3;
-  return (4 * out_rows + 8) * a.in_w * 4;
 }
 
 }  // namespace

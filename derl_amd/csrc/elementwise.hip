@@ -151,6 +151,33 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const uint8_t *sr
   }
 }
 
+// Up to kMaxGather arrays gathered by ONE index vector in one launch (blockIdx.y = array):
+// the minibatch selection of every small per-sample array of a rollout.
+constexpr int kMaxGather = 8;
+struct GatherTable {
+  const uint8_t *src[kMaxGather];
+  uint8_t *dst[kMaxGather];
+  int row_bytes[kMaxGather];
+};
+
+__global__ __launch_bounds__(kThreads) void gather_rows_multi_kernel(const GatherTable t, const int32_t *idx,
+                                                                     long long nrows) {
+  const uint8_t *src = t.src[blockIdx.y];
+  uint8_t *dst = t.dst[blockIdx.y];
+  const int rb = t.row_bytes[blockIdx.y];
+  const int unit = (rb % 4 == 0) ? 4 : 1;  // host checked 4-byte alignment when rb % 4 == 0
+  const long long per_row = rb / unit, total = nrows * per_row;
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / per_row, c = i - r * per_row;
+    const long long so = static_cast<long long>(idx[r]) * rb, d = r * rb;
+    if (unit == 4)
+      reinterpret_cast<uint32_t *>(dst + d)[c] = reinterpret_cast<const uint32_t *>(src + so)[c];
+    else
+      dst[d + c] = src[so + c];
+  }
+}
+
 int grid_for(long long n, int per_thread) {
   long long b = (n + static_cast<long long>(kThreads) * per_thread - 1) / (static_cast<long long>(kThreads) * per_thread);
   if (b < 1) b = 1;
@@ -234,6 +261,32 @@ extern "C" int dx_clip_rmsprop_step_f32(float *params, float *grads, float *squa
             static_cast<float>(alpha), static_cast<float>(eps), 1.f, 1.f,
             static_cast<float>(1.0 - alpha)};
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n, 4)), dim3(kThreads), 0, dx::as_stream(stream), a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_gather_rows_multi(const void *const *src, void *const *dst, const long long *row_bytes,
+                                    int narrays, const int32_t *idx, long long nrows, void *stream) {
+  DX_REQUIRE(narrays >= 0 && narrays <= kMaxGather, "dx_gather_rows_multi: %d arrays (max %d)", narrays,
+             kMaxGather);
+  DX_REQUIRE(nrows >= 0, "dx_gather_rows_multi: negative row count");
+  if (narrays == 0 || nrows == 0) return DX_OK;
+  DX_REQUIRE(src && dst && row_bytes && idx, "dx_gather_rows_multi: null pointer");
+  GatherTable t;
+  long long biggest = 0;
+  for (int i = 0; i < narrays; ++i) {
+    DX_REQUIRE(src[i] && dst[i] && row_bytes[i] > 0 && row_bytes[i] < (1 << 30),
+               "dx_gather_rows_multi: bad array %d", i);
+    t.src[i] = static_cast<const uint8_t *>(src[i]);
+    t.dst[i] = static_cast<uint8_t *>(dst[i]);
+    t.row_bytes[i] = static_cast<int>(row_bytes[i]);
+    if (row_bytes[i] % 4 == 0)
+      DX_REQUIRE(dx::aligned(src[i], 4) && dx::aligned(dst[i], 4), "dx_gather_rows_multi: array %d misaligned", i);
+    const long long units = nrows * (row_bytes[i] % 4 == 0 ? row_bytes[i] / 4 : row_bytes[i]);
+    if (units > biggest) biggest = units;
+  }
+  hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(grid_for(biggest, 4), narrays), dim3(kThreads), 0,
+                     dx::as_stream(stream), t, idx, nrows);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

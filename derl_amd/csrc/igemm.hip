@@ -530,6 +530,10 @@ int launch_nt(const NTArgs &a_in, bool a_u8, int epi, int stage, hipStream_t str
   DX_REQUIRE(a.M < (1 << 30), "igemm_nt: M too large");
   DX_REQUIRE(!a.om.enabled || (a.om.chan > 0 && a.om.chan % 32 == 0),
              "igemm_nt: output map needs a channel count that is a multiple of 32");
+  {  // small batches: one 32x32 tile per workgroup, K split over its waves (igemm_lat.hip)
+    const int rc = launch_nt_lat(a, a_u8, epi, stage, stream);
+    if (rc != DX_ENOSUP) return rc;
+  }
   if (split_bf16() && !a_u8 && a.M >= split_min_m() && a.ablate == 0) {
     const int rc = launch_nt_b3(a, epi, stage, stream);
     if (rc != DX_ENOSUP) return rc;

@@ -101,6 +101,8 @@ enum Stage {
 
 int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream);
 int launch_tn(const TNArgs &a, bool a_u8, int stage, hipStream_t stream);
+// latency-shaped NT kernels for small batches (igemm_lat.hip); DX_ENOSUP = not covered
+int launch_nt_lat(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream);
 // 3xbf16-split variant of the big NT stages (igemm_b3.hip); DX_ENOSUP = not covered
 int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream);
 
@@ -134,6 +136,10 @@ struct Conv0Args {
 bool conv0_direct_supported(int in_h, int in_w, int in_c, int h0, int w0);
 int launch_conv0_fwd(const Conv0Args &a, hipStream_t stream);
 int launch_conv0_wgrad(const Conv0Args &a, int nblocks, hipStream_t stream);
+// the same two kernels on the bf16 matrix cores with an exact 3-term weight / gradient split
+// (conv0_b16.hip); the default.  DX_CONV0_F32=1 selects the fp32-MFMA kernels above.
+int launch_conv0_fwd_b16(const Conv0Args &a, hipStream_t stream);
+int launch_conv0_wgrad_b16(const Conv0Args &a, int nblocks, hipStream_t stream);
 int launch_heads_act_fused(const float *hid_slabs, int nslab, long long slab_stride, const float *Wh,
                            const float *bh, int B, int A, const float *uniforms, uint64_t seed,
                            uint64_t counter, int64_t *actions, float *log_prob, float *values,

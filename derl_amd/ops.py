@@ -3,6 +3,8 @@
 torch supplies device memory and the stream only; all arithmetic happens in
 libderl_amd.so.  Every function raises if its inputs are not on a HIP device.
 """
+import math
+
 import torch
 
 from . import _lib
@@ -116,6 +118,26 @@ def gather_rows(src, idx, out=None):
   _lib.call("dx_gather_rows", _lib.ptr(src), _lib.ptr(idx), _lib.ptr(out), n, row_bytes,
             _lib.stream_ptr(src.device))
   return out
+
+
+def gather_rows_multi(sources, idx):
+  """[src[idx] for src in sources] along dim 0 with one launch per 8 arrays."""
+  _dev(idx, "idx", torch.int32)
+  n = idx.numel()
+  outs = []
+  for start in range(0, len(sources), 8):
+    group = sources[start:start + 8]
+    k = len(group)
+    src_p, dst_p, rb = (_lib.c_void_p * k)(), (_lib.c_void_p * k)(), (_lib.c_longlong * k)()
+    for i, src in enumerate(group):
+      _dev(src, "src")
+      out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+      outs.append(out)
+      src_p[i], dst_p[i] = src.data_ptr(), out.data_ptr()
+      rb[i] = src.element_size() * math.prod(src.shape[1:])
+    _lib.call("dx_gather_rows_multi", src_p, dst_p, rb, k, _lib.ptr(idx), n,
+              _lib.stream_ptr(idx.device))
+  return outs
 
 
 def categorical_act(head_out, num_actions, uniforms=None, seed=0, counter=0, out=None):

@@ -1,4 +1,6 @@
 """On-policy runner wrappers (derl/runners/onpolicy.py:11-82)."""
+import math
+
 import numpy as np
 import torch
 
@@ -57,17 +59,30 @@ class IterateWithMinibatches(RunnerWrapper):
     self.shuffle_before_epoch = shuffle_before_epoch
 
   @staticmethod
-  def _select(val, index_dev, index_host):
-    if isinstance(val, torch.Tensor) and val.is_cuda:
-      row_bytes = val.element_size() * int(np.prod(val.shape[1:], dtype=np.int64))
-      if row_bytes >= LAZY_ROW_BYTES:
-        return GatheredRows(val, index_dev)
-      return ops.gather_rows(val.contiguous(), index_dev)
-    if isinstance(val, torch.Tensor):
-      return val[torch.from_numpy(index_host.astype(np.int64))]
-    if isinstance(val, np.ndarray):
-      return val[index_host]
-    return val
+  def _select_all(interactions, index_dev, index_host):
+    """One minibatch of every array: device arrays with small rows share ONE gather launch,
+    arrays with big rows (frames) are referenced lazily, host arrays are fancy-indexed."""
+    out, small = {}, []
+    for key, val in interactions.items():
+      if key == "state":
+        out[key] = val
+      elif isinstance(val, torch.Tensor) and val.is_cuda:
+        row_bytes = val.element_size() * math.prod(val.shape[1:])
+        if row_bytes >= LAZY_ROW_BYTES:
+          out[key] = GatheredRows(val, index_dev)
+        else:
+          out[key] = None
+          small.append(key)
+      elif isinstance(val, torch.Tensor):
+        out[key] = val[torch.from_numpy(index_host.astype(np.int64))]
+      elif isinstance(val, np.ndarray):
+        out[key] = val[index_host]
+      else:
+        out[key] = val
+    if small:
+      gathered = ops.gather_rows_multi([interactions[key].contiguous() for key in small], index_dev)
+      out.update(zip(small, gathered))
+    return out
 
   def run(self, obs=None):
     for interactions in self.runner.run(obs=obs):
@@ -97,8 +112,7 @@ class IterateWithMinibatches(RunnerWrapper):
           stop = min(start + mbsize, sample_size)
           index_host = order[start:stop]
           index_dev = order_dev[start:stop] if order_dev is not None else None
-          yield dict((key, self._select(val, index_dev, index_host)) if key != "state"
-                     else (key, val) for key, val in interactions.items())
+          yield self._select_all(interactions, index_dev, index_host)
 
 
 def ppo_runner_wrap(runner, gamma=0.99, lambda_=0.95, num_epochs=3, num_minibatches=4):

@@ -101,6 +101,11 @@ int dx_clip_rmsprop_step_f32(float *params, float *grads, float *square_avg, lon
  * gathered by index inside the conv loader instead of being copied). */
 int dx_gather_rows(const void *src, const int32_t *idx, void *dst, long long nrows,
                    long long row_bytes, void *stream);
+/* The same selection for up to 8 arrays sharing one index vector, in one launch (host
+ * arrays of narrays device pointers / row sizes): onpolicy.py:59-62 loops over every key of
+ * the interactions dict. */
+int dx_gather_rows_multi(const void *const *src, void *const *dst, const long long *row_bytes,
+                         int narrays, const int32_t *idx, long long nrows, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Categorical head -- replaces the distribution part of derl/policies.py:61-80
