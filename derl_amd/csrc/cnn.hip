@@ -176,14 +176,13 @@ int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
   const int A = c->num_actions, IC0 = c->in_c, P = c->h2 * c->w2, flat = c->flat;
   const float *w = c->params;
   float *pk = c->packed;
-  // padded head rows beyond A stay zero
-  DX_HIP(hipMemsetAsync(pk + c->pk_hdf, 0, sizeof(float) * kHeadLd * kHid, s));
-  DX_HIP(hipMemsetAsync(pk + c->pk_hdb, 0, sizeof(float) * kHeadLd, s));
+  // The padded head rows / columns beyond A + 1 are never written: `packed` must be zero-filled
+  // once by its owner (include/derl_amd.h), not on every parameter update.
   PermuteJob j[kMaxJobs];
   int n = 0;
   auto add = [&](const float *src, float *dst, long long total, int D1, int D2, int D3, long long s0,
                  long long s1, long long s2, long long s3, long long off) {
-    j[n++] = PermuteJob{src, dst, total, D1, D2, D3, s0, s1, s2, s3, off, 1, 0};
+    j[n++] = PermuteJob{src, dst, total, D1, D2, D3, s0, s1, s2, s3, off, 1, 0, 0};
   };
   // conv forward: dst [oc][kh][kw][ic] <- OIHW
   add(w + c->off_w[0], pk + c->pk_c0f, kC0 * 64LL * IC0, 8, 8, IC0, IC0 * 64LL, 8, 1, 64, 0);
@@ -204,11 +203,12 @@ int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
   add(w + c->off_w[2], pk + c->pk_c2d, kC1 * 9LL * kC2, 3, 3, kC2, 9, 3, 1, kC1 * 9LL, 0);
   // linear dgrad: dst [p][c][n] <- [n][c*P + p]
   add(w + c->off_w[3], pk + c->pk_fcd, static_cast<long long>(flat) * kHid, kC2, kHid, 1, 1, P, flat, 0, 0);
-  if (int rc = launch_permute_reduce(j, n, s)) return rc;
-  // heads dgrad: dst [k][j] <- padded [j][k] (second launch: reads the rows packed above)
-  PermuteJob t{pk + c->pk_hdf, pk + c->pk_hdd, static_cast<long long>(kHid) * kHeadLd, kHeadLd, 1, 1,
-               1, kHid, 0, 0, 0, 1, 0};
-  return launch_permute_reduce(&t, 1, s);
+  // heads dgrad: dst [k][32] <- heads [j][k] (scatter: the source rows are the contiguous side)
+  add(w + c->off_w[4], pk + c->pk_hdd, static_cast<long long>(A) * kHid, kHid, 1, 1, 1, kHeadLd, 0, 0, 0);
+  j[n - 1].scatter = 1;
+  add(w + c->off_w[5], pk + c->pk_hdd + A, kHid, kHid, 1, 1, 1, kHeadLd, 0, 0, 0);
+  j[n - 1].scatter = 1;
+  return launch_permute_reduce(j, n, s);
 }
 
 static Gather conv_gather(const void *src, const int32_t *idx, int H, int W, int C, int OH, int OW,
@@ -342,6 +342,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a = nt_args(dgrad_gather(c->dy2, c->h2, c->w2, kC2, c->h1, c->w1, 3, 3), pk + c->pk_c2d, nullptr,
                   c->dy1, kC1, M1, kC1, 9 * kC2);
       a.mask_src = c->y1;
+      if (const int rc = launch_nt_pix(a, B, EPI_MASK, stage, s); rc != DX_ENOSUP) return rc;
       return launch_nt(a, false, EPI_MASK, stage, s);
     case ST_CONV1_WGRAD:
       return tn(L_C1, conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), c->dy1, kC1, M1,
@@ -359,6 +360,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a.om.OHW = OHp * OWp; a.om.OW = OWp;
       a.om.div_img = make_fastdiv(a.om.OHW); a.om.div_row = make_fastdiv(OWp);
       a.om.OUT_H = c->h0; a.om.OUT_W = c->w0; a.om.osy = a.om.osx = 2; a.om.chan = kC0;
+      if (const int rc = launch_nt_pix(a, B, EPI_MASK, stage, s); rc != DX_ENOSUP) return rc;
       return launch_nt(a, false, EPI_MASK, stage, s);
     }
     case ST_CONV0_WGRAD:

@@ -5,7 +5,7 @@
 //   * every bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32,
 // so  sum_k x_k * w_k  costs THREE bf16 MFMAs of 32 cycles per 16 k instead of eight fp32 MFMAs of
 // 64 cycles (5.3x less matrix time), with only the fp32 accumulation roundings any fp32 chain has.
-// The 1/255 of the reference's `observations / 255` (models.py:121-123) is one IEEE division of the
+// The 1/255 of the reference's `observations / 255` (models.py:121-123) is one division (div255) of the
 // finished sum (forward) or of the slab element (weight gradient) instead of one rounding per term.
 //
 //   forward : A = 8 channel-bytes of two adjacent input pixels per lane (one ds_read_b64 from the
@@ -49,6 +49,14 @@ __device__ __forceinline__ bf16x8 expand8(uint2 w) {
   r.z = bytes_to_bf16x2(static_cast<float>(w.y & 0xff), static_cast<float>((w.y >> 8) & 0xff));
   r.w = bytes_to_bf16x2(static_cast<float>((w.y >> 16) & 0xff), static_cast<float>(w.y >> 24));
   return __builtin_bit_cast(bf16x8, r);
+}
+
+// x / 255 to within the last bit: multiply by the rounded reciprocal, one Newton residual step
+// (3 instructions instead of the ~10 of an IEEE division; 32 of them per lane and tile)
+__device__ __forceinline__ float div255(float x) {
+  const float r = 1.0f / 255.0f;
+  const float q = x * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
 }
 
 constexpr int kWRowB = 528;                 // bytes per LDS weight row: 256 bf16 + 16 pad
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_b16_kernel(const Conv0Args a) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wave * 64 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < a.M) {
-          const float v = acc[t2][r] / 255.0f + bias;
+          const float v = div255(acc[t2][r]) + bias;
           a.out[static_cast<long long>(m) * 32 + lrow] = v > 0.f ? v : 0.f;
         }
       }
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_b16_kernel(const Conv0Args a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int oc = (r & 3) + 8 * (r >> 2) + 4 * h;
-      slab[oc * 256 + (2 * wave + t2) * 32 + lcol] = acc[t2][r] / 255.0f;
+      slab[oc * 256 + (2 * wave + t2) * 32 + lcol] = div255(acc[t2][r]);
     }
   if (a.bias_slab) {
     __syncthreads();

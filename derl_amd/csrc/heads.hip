@@ -98,6 +98,16 @@ __global__ __launch_bounds__(256) void heads_act_fused_kernel(
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;  // whole wave exits together
+  // the head weights of outputs 0..7 (every game has A + 1 <= 8 or needs the loop below anyway),
+  // the bias and the uniform do not depend on the slabs: issue them first, one round trip in all
+  float4 wu0[8], ww0[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    wu0[jj] = *reinterpret_cast<const float4 *>(Wh + jj * 512 + lane * 8);
+    ww0[jj] = *reinterpret_cast<const float4 *>(Wh + jj * 512 + lane * 8 + 4);
+  }
+  const float bias_col = bh[lane & 31];
+  const float u_given = uniforms ? uniforms[b] : 0.f;
   float h[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float *row = hid_slabs + static_cast<long long>(b) * 512 + lane * 8;
   // slabs in batches of 7 with all loads issued before the first add (clamped index, masked add)
@@ -120,7 +130,11 @@ __global__ __launch_bounds__(256) void heads_act_fused_kernel(
 #pragma unroll
   for (int j = 0; j < 32; ++j) v[j] = 0.f;
 #pragma unroll
-  for (int j0 = 0; j0 < 32; j0 += 8) {
+  for (int jj = 0; jj < 8; ++jj)
+    v[jj] = h[0] * wu0[jj].x + h[1] * wu0[jj].y + h[2] * wu0[jj].z + h[3] * wu0[jj].w +
+            h[4] * ww0[jj].x + h[5] * ww0[jj].y + h[6] * ww0[jj].z + h[7] * ww0[jj].w;
+#pragma unroll
+  for (int j0 = 8; j0 < 32; j0 += 8) {
     if (j0 <= A) {  // uniform; rows beyond A are zero in the packed head matrix
       float4 wu[8], ww[8];
 #pragma unroll
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(256) void heads_act_fused_kernel(
   }
   float x = v[0] + __shfl_xor(v[0], 32);
   const int col = lane & 31;
-  x += bh[col];
+  x += bias_col;
   // from here: the half-wave categorical head (see categorical_act_kernel)
   const bool is_logit = col < A;
   const float mx = half_max(is_logit ? x : -INFINITY);
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(256) void heads_act_fused_kernel(
     acc += __shfl(e, k);
     if (k == col) cdf = acc;
   }
-  const float u = uniforms ? uniforms[b] : uniform01(seed, counter, b);
+  const float u = uniforms ? u_given : uniform01(seed, counter, b);
   const float thresh = u * acc;
   const unsigned long long below = __ballot(is_logit && cdf <= thresh);
   int a = __popcll(below & 0xffffffffull);

@@ -101,6 +101,8 @@ enum Stage {
 
 int launch_nt(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream);
 int launch_tn(const TNArgs &a, bool a_u8, int stage, hipStream_t stream);
+// dgrad GEMMs tiled as one pixel x 64 images so that zero taps are skipped (igemm_pix.hip)
+int launch_nt_pix(const NTArgs &a, int nimg, int epi, int stage, hipStream_t stream);
 // latency-shaped NT kernels for small batches (igemm_lat.hip); DX_ENOSUP = not covered
 int launch_nt_lat(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream);
 // 3xbf16-split variant of the big NT stages (igemm_b3.hip); DX_ENOSUP = not covered

@@ -161,7 +161,8 @@ typedef struct dx_cnn_ctx {
   long long hid_slab_count;         /* split-K partials of the linear layer (rollout path) */
   /* ---- device buffers (caller-allocated, fp32) ---- */
   float *params, *grads;            /* param_count */
-  float *packed;                    /* packed_count */
+  float *packed;                    /* packed_count; ZERO-FILLED once by the owner: dx_cnn_pack
+                                       never writes the padding of the 32-wide head matrices */
   float *y0, *y1, *y2, *hid, *head; /* activations kept for backward */
   float *dy0, *dy1, *dy2, *dhid, *dhead; /* same sizes as the activations */
   float *slabs;                     /* slab_count: split-reduction partials of wgrad */
