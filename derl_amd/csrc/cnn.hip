@@ -22,6 +22,12 @@ struct Derived {
 
 int conv_out(int n, int k, int s) { return (n - k) / s + 1; }
 
+bool use_b3() {  // DX_SPLIT_BF16=1: big NT stages on the bf16 matrix cores (exact 3-term split)
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_SPLIT_BF16"); v = e ? atoi(e) : 0; }
+  return v != 0;
+}
+
 bool conv0_f32() {  // DX_CONV0_F32=1: first layer on the fp32 matrix instructions (conv0.hip)
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_CONV0_F32"); v = e ? atoi(e) : 0; }
@@ -141,6 +147,11 @@ int dx_cnn_init(dx_cnn_ctx *c) {
   c->pk_hdf = take(kHeadLd * kHid); c->pk_hdb = take(kHeadLd);
   for (int p = 0; p < 4; ++p) c->pk_c1d[p] = take(kC0 * 4LL * kC1);
   c->pk_c2d = take(wsz[2]); c->pk_fcd = take(wsz[3]); c->pk_hdd = take(kHid * kHeadLd);
+  // bf16 planes of the NT mirrors: 3 planes x 2 bytes = 1.5 floats per element
+  auto take_planes = [&](long long n) { return take((3 * n + 1) / 2); };
+  c->pb_c1f = take_planes(wsz[1]); c->pb_c2f = take_planes(wsz[2]); c->pb_fcf = take_planes(wsz[3]);
+  c->pb_c1d = take_planes(wsz[1]); c->pb_c2d = take_planes(wsz[2]); c->pb_fcd = take_planes(wsz[3]);
+  c->pb_c0f = take_planes(wsz[0]);
   c->packed_count = po;
   c->slab_count = make_plan(c, c->max_batch).total;
   const long long mb = c->max_batch;
@@ -167,6 +178,10 @@ static int check_ctx(const dx_cnn_ctx *c, const char *who, long long B, bool nee
     DX_REQUIRE(c->grads && c->dy0 && c->dy1 && c->dy2 && c->dhid && c->dhead && c->slabs,
                "%s: backward buffers not set", who);
   return DX_OK;
+}
+
+static uint16_t *planes(const dx_cnn_ctx *c, long long off) {
+  return reinterpret_cast<uint16_t *>(c->packed + off);
 }
 
 // canonical parameters -> packed mirrors (call after every parameter change)
@@ -208,7 +223,17 @@ int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
   j[n - 1].scatter = 1;
   add(w + c->off_w[5], pk + c->pk_hdd + A, kHid, kHid, 1, 1, 1, kHeadLd, 0, 0, 0);
   j[n - 1].scatter = 1;
-  return launch_permute_reduce(j, n, s);
+  if (int rc = launch_permute_reduce(j, n, s)) return rc;
+  // bf16 planes (second launch: reads the mirrors packed above): conv0 for the rollout kernel,
+  // the other NT mirrors only for the opt-in bf16-split GEMMs
+  const long long wsz0 = kC0 * 64LL * IC0, wsz1 = kC1 * 16LL * kC0, wsz2 = kC2 * 9LL * kC1,
+                  wsz3 = static_cast<long long>(kHid) * flat;
+  const float *src[7] = {pk + c->pk_c0f, pk + c->pk_c1f, pk + c->pk_c2f, pk + c->pk_fcf, pk + c->pk_c1d[0],
+                         pk + c->pk_c2d, pk + c->pk_fcd};
+  uint16_t *dst[7] = {planes(c, c->pb_c0f), planes(c, c->pb_c1f), planes(c, c->pb_c2f), planes(c, c->pb_fcf),
+                      planes(c, c->pb_c1d), planes(c, c->pb_c2d), planes(c, c->pb_fcd)};
+  const long long cnt[7] = {wsz0, wsz1, wsz2, wsz3, wsz1, wsz2, wsz3};
+  return launch_split_planes(src, dst, cnt, use_b3() ? 7 : 1, s);
 }
 
 static Gather conv_gather(const void *src, const int32_t *idx, int H, int W, int C, int OH, int OW,
@@ -285,7 +310,16 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     case ST_CONV0_FWD:
       a = nt_args(conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), pk + c->pk_c0f,
                   w + c->off_b[0], c->y0, kC0, M0, kC0, 64 * IC0);
-      if (obs_is_u8) {  // rollout-sized batches: latency-shaped kernel
+      if (obs_is_u8 && IC0 == 4 && M0 <= 32 * 4096 && !conv0_f32()) {  // rollout-sized batches
+        Conv0Args d;
+        std::memset(&d, 0, sizeof(d));
+        d.obs = static_cast<const uint8_t *>(obs); d.idx = sample_idx;
+        d.in_h = c->in_h; d.in_w = c->in_w; d.h0 = c->h0; d.w0 = c->w0;
+        d.M = static_cast<int>(M0); d.bias = w + c->off_b[0]; d.out = c->y0;
+        const int rc = launch_conv0_lat_b16(d, planes(c, c->pb_c0f), s);
+        if (rc != DX_ENOSUP) return rc;
+      }
+      if (obs_is_u8) {  // fp32-MFMA latency kernel
         const int rc = launch_nt_lat(a, true, EPI_BIAS_RELU, stage, s);
         if (rc != DX_ENOSUP) return rc;
       }
@@ -302,10 +336,12 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     case ST_CONV1_FWD:
       a = nt_args(conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), pk + c->pk_c1f,
                   w + c->off_b[1], c->y1, kC1, M1, kC1, 16 * kC0);
+      a.Wb = planes(c, c->pb_c1f); a.wb_plane = kC1 * 16LL * kC0;
       return launch_nt(a, false, EPI_BIAS_RELU, stage, s);
     case ST_CONV2_FWD:
       a = nt_args(conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), pk + c->pk_c2f,
                   w + c->off_b[2], c->y2, kC2, M2, kC2, 9 * kC1);
+      a.Wb = planes(c, c->pb_c2f); a.wb_plane = kC2 * 9LL * kC1;
       return launch_nt(a, false, EPI_BIAS_RELU, stage, s);
     case ST_FC_FWD: {
       // small minibatches (multi-GPU shards): 49 sequential 64-deep K steps on 128 workgroups are
@@ -313,6 +349,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       const int ks = (B <= 1024 && c->hid_slabs && 7LL * B * kHid <= c->hid_slab_count && flat % (7 * 64) == 0) ? 7 : 1;
       a = nt_args(rows_gather(c->y2, flat), pk + c->pk_fcf, w + c->off_b[3], ks > 1 ? c->hid_slabs : c->hid,
                   kHid, B, kHid, flat);
+      a.Wb = planes(c, c->pb_fcf); a.wb_plane = static_cast<long long>(kHid) * flat;
       a.ksplit = ks;
       a.slab_stride = static_cast<long long>(B) * kHid;
       if (int rc = launch_nt(a, false, EPI_BIAS, stage, s)) return rc;
@@ -333,6 +370,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       return tn(L_FC, rows_gather(c->y2, flat), c->dhid, kHid, B, kHid, flat, false);
     case ST_FC_DGRAD:
       a = nt_args(rows_gather(c->dhid, kHid), pk + c->pk_fcd, nullptr, c->dy2, flat, B, flat, kHid);
+      a.Wb = planes(c, c->pb_fcd); a.wb_plane = static_cast<long long>(kHid) * flat;
       a.mask_src = c->y2;
       return launch_nt(a, false, EPI_MASK, stage, s);
     case ST_CONV2_WGRAD:
@@ -341,6 +379,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     case ST_CONV2_DGRAD:
       a = nt_args(dgrad_gather(c->dy2, c->h2, c->w2, kC2, c->h1, c->w1, 3, 3), pk + c->pk_c2d, nullptr,
                   c->dy1, kC1, M1, kC1, 9 * kC2);
+      a.Wb = planes(c, c->pb_c2d); a.wb_plane = kC2 * 9LL * kC1;
       a.mask_src = c->y1;
       if (const int rc = launch_nt_pix(a, B, EPI_MASK, stage, s); rc != DX_ENOSUP) return rc;
       return launch_nt(a, false, EPI_MASK, stage, s);
@@ -355,6 +394,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       const int OHp = (c->h0 + 1) / 2, OWp = (c->w0 + 1) / 2;
       a = nt_args(dgrad_gather(c->dy1, c->h1, c->w1, kC1, OHp, OWp, 2, 2), pk + c->pk_c1d[0], nullptr,
                   c->dy0, kC0, static_cast<long long>(B) * OHp * OWp, 4 * kC0, 4 * kC1);
+      a.Wb = planes(c, c->pb_c1d); a.wb_plane = kC1 * 16LL * kC0;
       a.mask_src = c->y0;
       a.om.enabled = 1;
       a.om.OHW = OHp * OWp; a.om.OW = OWp;

@@ -250,6 +250,60 @@ __global__ __launch_bounds__(256) void conv0_wgrad_b16_kernel(const Conv0Args a)
   }
 }
 
+// Rollout batches (a few thousand output pixels): one 32-pixel x 32-channel tile per workgroup,
+// the four waves split the 16 K chunks (kernel rows 2w, 2w+1), every operand goes straight from
+// global memory into the MFMA layout -- 8 input bytes and 3 x 16 bytes of the pre-split weight
+// planes (dx_cnn_pack) per lane and chunk, all 16 loads in flight before the first of 12 MFMAs --
+// and the four partial tiles meet in LDS once (igemm_lat.hip has the fp32 layers of this path).
+__global__ __launch_bounds__(256) void conv0_lat_b16_kernel(const Conv0Args a, const uint16_t *Wb) {
+  __shared__ float red[4][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int rowB = a.in_w * 4;
+  const int P = a.h0 * a.w0;
+  const int m = min(static_cast<int>(blockIdx.x) * 32 + r, a.M - 1);  // clamped rows are not stored
+  int img = m / P;
+  const int pix = m - img * P;
+  const int oy = pix / a.w0, ox = pix - oy * a.w0;
+  if (a.idx) img = a.idx[img];
+  const uint8_t *src = a.obs + static_cast<long long>(img) * a.in_h * rowB + (4 * oy + 2 * wave) * rowB + ox * 16 + 8 * h;
+  const uint16_t *wsrc = Wb + r * 256 + (2 * wave) * 32 + 8 * h;
+  uint2 araw[4];
+  u32x4 braw[3][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {  // chunk c: kernel row 2*wave + (c >> 1), bytes 16*(c & 1) .. +15
+    araw[c] = *reinterpret_cast<const uint2 *>(src + (c >> 1) * rowB + 16 * (c & 1));
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      braw[pl][c] = *reinterpret_cast<const u32x4 *>(wsrc + pl * 8192 + (c >> 1) * 32 + 16 * (c & 1));
+  }
+  __builtin_amdgcn_sched_barrier(0);  // all loads before the first MFMA (see igemm_lat.hip)
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bf16x8 af = expand8(araw[c]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, braw[2][c]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, braw[1][c]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, braw[0][c]), acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+  __syncthreads();
+  const float bias = a.bias[r];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {  // wave w finishes accumulator registers 4w .. 4w+3
+    const int i = 4 * wave + t;
+    const float sum = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
+    const int mm = blockIdx.x * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (mm < a.M) {
+      const float v = div255(sum) + bias;
+      a.out[static_cast<long long>(mm) * 32 + r] = v > 0.f ? v : 0.f;
+    }
+  }
+}
+
 }  // namespace
 
 int launch_conv0_fwd_b16(const Conv0Args &a, hipStream_t stream) {
@@ -261,6 +315,15 @@ int launch_conv0_fwd_b16(const Conv0Args &a, hipStream_t stream) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int grid = a.ntiles < 512 ? a.ntiles : 512;
   hipLaunchKernelGGL(conv0_fwd_b16_kernel, dim3(grid), dim3(256), lds, stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+// DX_ENOSUP when the shape is not covered (odd row pitch) or the batch is too big for this path
+int launch_conv0_lat_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t stream) {
+  DX_REQUIRE(a.obs && Wb && a.bias && a.out && a.M > 0, "conv0_lat_b16: bad arguments");
+  if (a.in_w % 2 || (static_cast<long long>(a.in_h) * a.in_w) % 2 || a.w0 < 1) return DX_ENOSUP;
+  hipLaunchKernelGGL(conv0_lat_b16_kernel, dim3(cdiv(a.M, 32)), dim3(256), 0, stream, a, Wb);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -83,13 +83,27 @@ __global__ __launch_bounds__(kThreads) void sumsq_kernel(const float *g, long lo
 // clip coefficient of torch.nn.utils.clip_grad_norm_: min(1, max_norm / (norm + 1e-6))
 __device__ __forceinline__ float clip_coef(const double *partials, int npartials, float max_norm,
                                            float *norm_out) {
-  double s = 0.0;
-  for (int i = 0; i < npartials; ++i) s += partials[i];
-  const float norm = static_cast<float>(sqrt(s));
-  if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
-  if (max_norm <= 0.f) return 1.f;
-  const float c = max_norm / (norm + 1e-6f);
-  return c < 1.f ? c : 1.f;
+  // wave 0 sums the partials (lane-strided, then an xor butterfly: every workgroup forms the
+  // same sum in the same order) and publishes the coefficient to the workgroup
+  __shared__ float coef_shared;
+  if (threadIdx.x < 64) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < npartials; i += 64) s += partials[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) {
+      const float norm = static_cast<float>(sqrt(s));
+      if (norm_out && blockIdx.x == 0) *norm_out = norm;
+      float c = 1.f;
+      if (max_norm > 0.f) {
+        c = max_norm / (norm + 1e-6f);
+        c = c < 1.f ? c : 1.f;
+      }
+      coef_shared = c;
+    }
+  }
+  __syncthreads();
+  return coef_shared;
 }
 
 struct OptArgs {
@@ -101,24 +115,39 @@ struct OptArgs {
   float *norm_out;
   float lr_or_step_size, beta1, beta2, eps, bc2_sqrt;
   float one_minus_beta1, one_minus_beta2;  // formed in double on the host, like torch
+  int vec4;
 };
 
 // Adam (torch semantics, no weight decay / amsgrad):
 //   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
 // g is the clipped gradient and is written back (clip_grad_norm_ clips in place).
+__device__ __forceinline__ void adam_one(const OptArgs &a, float coef, float &p, float &g, float &m, float &v) {
+  g *= coef;
+  m = m * a.beta1 + g * a.one_minus_beta1;
+  v = v * a.beta2 + (g * g) * a.one_minus_beta2;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  p = p - a.lr_or_step_size * (m / denom);
+}
+
 __global__ __launch_bounds__(kThreads) void adam_kernel(const OptArgs a) {
   const float coef = clip_coef(a.partials, a.npartials, a.max_norm, a.norm_out);
-  const float omb1 = a.one_minus_beta1, omb2 = a.one_minus_beta2;
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
-  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-    const float g = a.g[i] * coef;
-    const float m = a.m[i] * a.beta1 + g * omb1;
-    const float v = a.v[i] * a.beta2 + (g * g) * omb2;
-    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-    a.p[i] = a.p[i] - a.lr_or_step_size * (m / denom);
-    a.m[i] = m;
-    a.v[i] = v;
-    a.g[i] = g;
+  const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long n4 = a.vec4 ? a.n / 4 : 0;  // 16-byte lanes when all four buffers are aligned
+  for (long long i = tid; i < n4; i += stride) {
+    float4 p = reinterpret_cast<float4 *>(a.p)[i], g = reinterpret_cast<float4 *>(a.g)[i];
+    float4 m = reinterpret_cast<float4 *>(a.m)[i], v = reinterpret_cast<float4 *>(a.v)[i];
+    adam_one(a, coef, p.x, g.x, m.x, v.x);
+    adam_one(a, coef, p.y, g.y, m.y, v.y);
+    adam_one(a, coef, p.z, g.z, m.z, v.z);
+    adam_one(a, coef, p.w, g.w, m.w, v.w);
+    reinterpret_cast<float4 *>(a.p)[i] = p; reinterpret_cast<float4 *>(a.g)[i] = g;
+    reinterpret_cast<float4 *>(a.m)[i] = m; reinterpret_cast<float4 *>(a.v)[i] = v;
+  }
+  for (long long i = 4 * n4 + tid; i < a.n; i += stride) {
+    float p = a.p[i], g = a.g[i], m = a.m[i], v = a.v[i];
+    adam_one(a, coef, p, g, m, v);
+    a.p[i] = p; a.g[i] = g; a.m[i] = m; a.v[i] = v;
   }
 }
 
@@ -244,8 +273,10 @@ extern "C" int dx_clip_adam_step_f32(float *params, float *grads, float *exp_avg
             static_cast<float>(max_norm), norm_out, static_cast<float>(lr / bc1),
             static_cast<float>(beta1), static_cast<float>(beta2), static_cast<float>(eps),
             static_cast<float>(sqrt(bc2)), static_cast<float>(1.0 - beta1),
-            static_cast<float>(1.0 - beta2)};
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(kThreads), 0, dx::as_stream(stream), a);
+            static_cast<float>(1.0 - beta2),
+            dx::aligned(params, 16) && dx::aligned(grads, 16) && dx::aligned(exp_avg, 16) &&
+                    dx::aligned(exp_avg_sq, 16) ? 1 : 0};
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 8)), dim3(kThreads), 0, dx::as_stream(stream), a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -259,7 +290,7 @@ extern "C" int dx_clip_rmsprop_step_f32(float *params, float *grads, float *squa
   OptArgs a{params, grads, nullptr, square_avg, n, sumsq_partials, npartials,
             static_cast<float>(max_norm), norm_out, static_cast<float>(lr), 0.f,
             static_cast<float>(alpha), static_cast<float>(eps), 1.f, 1.f,
-            static_cast<float>(1.0 - alpha)};
+            static_cast<float>(1.0 - alpha), 0};
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n, 4)), dim3(kThreads), 0, dx::as_stream(stream), a);
   DX_LAUNCH_CHECK();
   return DX_OK;

@@ -86,10 +86,32 @@ __global__ __launch_bounds__(256) void categorical_act_kernel(
   }
 }
 
-// Rollout heads fused with sampling: hid (B,512) arrives as `nslab` split-K partial slabs of
-// the 3136->512 linear layer (bias already on slab 0); one wave per row sums them, forms the
-// A+1 head dot products (policy logits, value) with a 64-lane reduce-scatter, and samples.
-// Replaces two GEMM launches (reduce + heads) and the act launch of the rollout step.
+// Rollout tail in ONE launch, one wave per batch row: sums the split-K partial slabs of the hidden
+// layer (adds the bias riding on slab 0; no ReLU after that layer, models.py:112), forms the A + 1
+// head dot products (policy logits, value) and samples.  Replaces two GEMM launches (reduce +
+// heads) and the act launch of the rollout step.  Cross-lane sums use DPP row operations and
+// v_readlane (uniform lane indices), not LDS permutes: the kernel is a dependent chain.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, moved);  // rows masked off receive 0
+}
+
+// sum over the 64 lanes, returned in every lane (gfx9 wave64 DPP reduction + readlane 63)
+__device__ __forceinline__ float wave_sum_all(float v) {
+  v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);   // row_mirror: every lane holds its row's (16 lanes) total
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ float lane_value(float v, int lane_uniform) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_uniform));
+}
+
 __global__ __launch_bounds__(256) void heads_act_fused_kernel(
     const float *__restrict__ hid_slabs, int nslab, long long slab_stride,
     const float *__restrict__ Wh, const float *__restrict__ bh, int B, int A,
@@ -98,15 +120,16 @@ __global__ __launch_bounds__(256) void heads_act_fused_kernel(
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;  // whole wave exits together
-  // the head weights of outputs 0..7 (every game has A + 1 <= 8 or needs the loop below anyway),
-  // the bias and the uniform do not depend on the slabs: issue them first, one round trip in all
+  // the head weights of outputs 0..7, the bias and the uniform do not depend on the slabs:
+  // issue them first, one memory round trip in all
   float4 wu0[8], ww0[8];
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) {
     wu0[jj] = *reinterpret_cast<const float4 *>(Wh + jj * 512 + lane * 8);
     ww0[jj] = *reinterpret_cast<const float4 *>(Wh + jj * 512 + lane * 8 + 4);
   }
-  const float bias_col = bh[lane & 31];
+  const int col = lane & 31;
+  const float bias_col = bh[col];
   const float u_given = uniforms ? uniforms[b] : 0.f;
   float h[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float *row = hid_slabs + static_cast<long long>(b) * 512 + lane * 8;
@@ -126,50 +149,32 @@ __global__ __launch_bounds__(256) void heads_act_fused_kernel(
       h[4] += k * w[i].x; h[5] += k * w[i].y; h[6] += k * w[i].z; h[7] += k * w[i].w;
     }
   }
-  float v[32];
+  // x: lane j (and j + 32) ends up with head output j
+  float x = 0.f;
 #pragma unroll
-  for (int j = 0; j < 32; ++j) v[j] = 0.f;
-#pragma unroll
-  for (int jj = 0; jj < 8; ++jj)
-    v[jj] = h[0] * wu0[jj].x + h[1] * wu0[jj].y + h[2] * wu0[jj].z + h[3] * wu0[jj].w +
-            h[4] * ww0[jj].x + h[5] * ww0[jj].y + h[6] * ww0[jj].z + h[7] * ww0[jj].w;
-#pragma unroll
-  for (int j0 = 8; j0 < 32; j0 += 8) {
-    if (j0 <= A) {  // uniform; rows beyond A are zero in the packed head matrix
-      float4 wu[8], ww[8];
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        wu[jj] = *reinterpret_cast<const float4 *>(Wh + (j0 + jj) * 512 + lane * 8);
-        ww[jj] = *reinterpret_cast<const float4 *>(Wh + (j0 + jj) * 512 + lane * 8 + 4);
-      }
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj)
-        v[j0 + jj] = h[0] * wu[jj].x + h[1] * wu[jj].y + h[2] * wu[jj].z + h[3] * wu[jj].w +
-                     h[4] * ww[jj].x + h[5] * ww[jj].y + h[6] * ww[jj].z + h[7] * ww[jj].w;
-    }
+  for (int jj = 0; jj < 8; ++jj) {
+    const float part = h[0] * wu0[jj].x + h[1] * wu0[jj].y + h[2] * wu0[jj].z + h[3] * wu0[jj].w +
+                       h[4] * ww0[jj].x + h[5] * ww0[jj].y + h[6] * ww0[jj].z + h[7] * ww0[jj].w;
+    const float tot = wave_sum_all(part);
+    x = col == jj ? tot : x;
   }
-  // reduce-scatter: after the steps lane l holds the sum over its 32-lane half of output l&31
-#pragma unroll
-  for (int step = 0; step < 5; ++step) {
-    const int off = 16 >> step, cnt = 16 >> step;
-    const bool upper = lane & off;
-#pragma unroll
-    for (int jj = 0; jj < cnt; ++jj) {
-      const float keep = upper ? v[jj + cnt] : v[jj];
-      const float send = upper ? v[jj] : v[jj + cnt];
-      v[jj] = keep + __shfl_xor(send, off);
-    }
+  for (int j = 8; j <= A; ++j) {  // uniform; more than 7 actions
+    const float4 wu = *reinterpret_cast<const float4 *>(Wh + j * 512 + lane * 8);
+    const float4 ww = *reinterpret_cast<const float4 *>(Wh + j * 512 + lane * 8 + 4);
+    const float part = h[0] * wu.x + h[1] * wu.y + h[2] * wu.z + h[3] * wu.w +
+                       h[4] * ww.x + h[5] * ww.y + h[6] * ww.z + h[7] * ww.w;
+    const float tot = wave_sum_all(part);
+    x = col == j ? tot : x;
   }
-  float x = v[0] + __shfl_xor(v[0], 32);
-  const int col = lane & 31;
   x += bias_col;
-  // from here: the half-wave categorical head (see categorical_act_kernel)
+  // categorical head (see categorical_act_kernel); lane indices below are uniform -> v_readlane
+  float mx = -INFINITY;
+  for (int k = 0; k < A; ++k) mx = fmaxf(mx, lane_value(x, k));
   const bool is_logit = col < A;
-  const float mx = half_max(is_logit ? x : -INFINITY);
   const float e = is_logit ? expf(x - mx) : 0.f;
   float acc = 0.f, cdf = 0.f;
-  for (int k = 0; k < A; ++k) {
-    acc += __shfl(e, k);
+  for (int k = 0; k < A; ++k) {  // sequential float32 running sum in column order
+    acc += lane_value(e, k);
     if (k == col) cdf = acc;
   }
   const float u = uniforms ? u_given : uniform01(seed, counter, b);
@@ -178,8 +183,8 @@ __global__ __launch_bounds__(256) void heads_act_fused_kernel(
   int a = __popcll(below & 0xffffffffull);
   if (a > A - 1) a = A - 1;
   const float lse = mx + logf(acc);
-  const float la = __shfl(x, a) - lse;
-  const float val = __shfl(x, A);
+  const float la = lane_value(x, a) - lse;
+  const float val = lane_value(x, A);
   if (lane == 0) {
     actions[b] = a;
     log_prob[b] = la;

@@ -69,6 +69,8 @@ struct NTArgs {
   Gather g;
   OutMap om;
   const float *Wp;        // [N][K]
+  const uint16_t *Wb;     // optional: the same matrix as three bf16 planes [3][N][K] (hi, mid, lo)
+  long long wb_plane;     // elements per plane (N*K)
   const float *bias;      // [N]
   const float *mask_src;  // EPI_MASK: zero where mask_src[out_row][n] <= 0
   float *out;
@@ -107,6 +109,9 @@ int launch_nt_pix(const NTArgs &a, int nimg, int epi, int stage, hipStream_t str
 int launch_nt_lat(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream);
 // 3xbf16-split variant of the big NT stages (igemm_b3.hip); DX_ENOSUP = not covered
 int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream);
+constexpr int kMaxSplitJobs = 8;
+int launch_split_planes(const float *const *src, uint16_t *const *dst, const long long *count, int njobs,
+                        hipStream_t stream);
 
 // gather (scatter = 0): dst[i] = sum_z src[z*slab_stride + off + d0*s0 + d1*s1 + d2*s2 + d3*s3]
 // scatter (scatter = 1): dst[d0*s0 + d1*s1 + d2*s2 + d3*s3] = sum_z src[z*slab_stride + off + i]
@@ -142,6 +147,8 @@ int launch_conv0_wgrad(const Conv0Args &a, int nblocks, hipStream_t stream);
 // (conv0_b16.hip); the default.  DX_CONV0_F32=1 selects the fp32-MFMA kernels above.
 int launch_conv0_fwd_b16(const Conv0Args &a, hipStream_t stream);
 int launch_conv0_wgrad_b16(const Conv0Args &a, int nblocks, hipStream_t stream);
+// rollout-sized batches: 32x32 tile per workgroup, pre-split weight planes Wb [3][32][256] bf16
+int launch_conv0_lat_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t stream);
 int launch_heads_act_fused(const float *hid_slabs, int nslab, long long slab_stride, const float *Wh,
                            const float *bh, int B, int A, const float *uniforms, uint64_t seed,
                            uint64_t counter, int64_t *actions, float *log_prob, float *values,

@@ -18,6 +18,8 @@ namespace {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {  // round-to-nearest-even
   bf16x2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};
@@ -37,7 +39,7 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t &h, uint32_t
   l = pack2(r0 - lo_f32(m), r1 - hi_f32(m));             // exact residual, exact conversion
 }
 
-__device__ __forceinline__ Split4 split4(float4 v) {
+__device__ __forceinline__ Split4 split4(f32x4 v) {
   Split4 s;
   split2(v.x, v.y, s.hi.x, s.mid.x, s.lo.x);
   split2(v.z, v.w, s.hi.y, s.mid.y, s.lo.y);
@@ -55,9 +57,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_b3_kernel
   constexpr int RPP = NT / 8;
   static_assert(BM % RPP == 0, "BM must be a multiple of the rows per pass");
   constexpr int APASS = BM / RPP;
-  constexpr int BPASS = (BN + RPP - 1) / RPP;
+  // weights: pre-split planes [3][N][K] bf16 (dx_cnn_pack); a tile row is 32 k = 4 x 16 bytes per plane
+  constexpr int BCH = BN * 4 * 3;  // 16-byte chunks per K step
+  constexpr int BPASS = (BCH + NT - 1) / NT;
   constexpr int A_PLANE = BM * kRowB, B_PLANE = BN * kRowB;
-  __shared__ __attribute__((aligned(16))) uint8_t smem[3 * (A_PLANE + B_PLANE)];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 3 * (A_PLANE + B_PLANE) bytes
   uint8_t *As = smem;                 // planes hi, mid, lo
   uint8_t *Bs = smem + 3 * A_PLANE;
 
@@ -75,13 +79,17 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_b3_kernel
     const int m = m0 + p * RPP + lr;
     rows[p] = decode_row(g, m, m < a.M);
   }
-  const float *wrow[BPASS];
-  bool wvalid[BPASS];
+  // chunk c of the B tile: plane = c / (BN*4), row = (c / 4) % BN, 16-byte piece = c % 4
+  const uint8_t *wsrc[BPASS];
+  int wdst[BPASS];
 #pragma unroll
   for (int p = 0; p < BPASS; ++p) {
-    const int nr = p * RPP + lr;
-    wvalid[p] = nr < BN && (n0 + nr) < a.N;
-    wrow[p] = a.Wp + static_cast<long long>(wvalid[p] ? n0 + nr : 0) * a.K + 4 * l8;
+    const int c = min(p * NT + tid, BCH - 1);
+    const int plane = c / (BN * 4), row = (c >> 2) % BN, piece = c & 3;
+    const int n = min(n0 + row, a.N - 1);  // columns past N are computed but never stored
+    wsrc[p] = reinterpret_cast<const uint8_t *>(a.Wb) +
+              2 * (plane * a.wb_plane + static_cast<long long>(n) * a.K) + 16 * piece;
+    wdst[p] = plane * B_PLANE + row * kRowB + 16 * piece;
   }
 
   f32x16 acc[TM][TN];
@@ -92,10 +100,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_b3_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int seg = kbeg / g.seglen, q = kbeg - seg * g.seglen;
-  float4 araw[APASS], braw[BPASS];
+  // Software pipeline (per K step of 32): the activation tile is fetched TWO steps ahead as raw
+  // fp32, split into its three bf16 planes ONE step ahead -- in the shadow of the current step's
+  // MFMAs, not between the barriers -- and written to LDS at the start of its own step.  The
+  // weight planes need no arithmetic and are fetched one step ahead.
+  int seg = kbeg / g.seglen, q = kbeg - seg * g.seglen;  // position of the next A fetch
+  f32x4 araw[APASS];
+  u32x4 braw[BPASS];
+  uint2 shi[APASS], smid[APASS], slo[APASS];
   uint32_t aok = 0;
-  auto fetch = [&](int kt) {
+  auto fetch_a = [&]() {
     const int sseg = __builtin_amdgcn_readfirstlane(seg);
     const long long so = static_cast<long long>(g.seg_off[sseg]) + q + 4 * l8;
     aok = 0;
@@ -103,38 +117,42 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_b3_kernel
     for (int p = 0; p < APASS; ++p) {
       const bool ok = (rows[p].okmask >> sseg) & 1u;
       aok |= (ok ? 1u : 0u) << p;
-      araw[p] = load_raw<false>(g.src, ok ? rows[p].base + so : 0);
+      araw[p] = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(g.src) + (ok ? rows[p].base + so : 0));
     }
-#pragma unroll
-    for (int p = 0; p < BPASS; ++p) braw[p] = *reinterpret_cast<const float4 *>(wrow[p] + kt);
+    q += BK;
+    if (q >= g.seglen) { q = 0; ++seg; }
   };
-  fetch(kbeg);
+  auto fetch_b = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) braw[p] = *reinterpret_cast<const u32x4 *>(wsrc[p] + 2 * kt);
+  };
+  auto split_a = [&]() {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      const Split4 s = split4(((aok >> p) & 1u) ? araw[p] : zero);
+      shi[p] = s.hi; smid[p] = s.mid; slo[p] = s.lo;
+    }
+  };
+  fetch_a();
+  fetch_b(kbeg);
+  split_a();
+  if (kbeg + BK < kend) fetch_a();
 
   for (int kt = kbeg; kt < kend; kt += BK) {
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
-      const Split4 s = split4(masked(araw[p], (aok >> p) & 1u));
       const int o = (p * RPP + lr) * kRowB + 8 * l8;
-      *reinterpret_cast<uint2 *>(As + o) = s.hi;
-      *reinterpret_cast<uint2 *>(As + A_PLANE + o) = s.mid;
-      *reinterpret_cast<uint2 *>(As + 2 * A_PLANE + o) = s.lo;
+      *reinterpret_cast<uint2 *>(As + o) = shi[p];
+      *reinterpret_cast<uint2 *>(As + A_PLANE + o) = smid[p];
+      *reinterpret_cast<uint2 *>(As + 2 * A_PLANE + o) = slo[p];
     }
 #pragma unroll
     for (int p = 0; p < BPASS; ++p)
-      if (p * RPP + lr < BN) {
-        const Split4 s = split4(masked(braw[p], wvalid[p]));
-        const int o = (p * RPP + lr) * kRowB + 8 * l8;
-        *reinterpret_cast<uint2 *>(Bs + o) = s.hi;
-        *reinterpret_cast<uint2 *>(Bs + B_PLANE + o) = s.mid;
-        *reinterpret_cast<uint2 *>(Bs + 2 * B_PLANE + o) = s.lo;
-      }
+      if (p * NT + tid < BCH) *reinterpret_cast<u32x4 *>(Bs + wdst[p]) = braw[p];
     __syncthreads();
-    if (kt + BK < kend) {
-      q += BK;
-      if (q >= g.seglen) { q = 0; ++seg; }
-      fetch(kt + BK);
-    }
+    if (kt + BK < kend) fetch_b(kt + BK);
     const int lrow = lane & 31, lk = 16 * (lane >> 5);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {  // two 16-deep k steps per 32-k tile
@@ -165,6 +183,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_b3_kernel
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
+      if (ks == 0 && kt + BK < kend) {  // next tile: split now (MFMAs above are in flight), refill the raw regs
+        split_a();
+        if (kt + 2 * BK < kend) fetch_a();
+      }
     }
   }
 
@@ -225,20 +247,41 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_b3_kernel
     }
 }
 
-template <int TAG, int EPI>
-int launch_b3(const NTArgs &a, hipStream_t stream) {
-  dim3 grid(cdiv(a.M, 128), cdiv(a.N, 64), a.ksplit);
-  hipLaunchKernelGGL((igemm_nt_b3_kernel<TAG, 128, 64, 64, 32, EPI>), grid, dim3(256), 0, stream, a);
+template <int TAG, int BM, int BN, int WM, int WN, int EPI>
+int launch_b3_as(const NTArgs &a, hipStream_t stream) {
+  constexpr int lds = 3 * (BM + BN) * kRowB;
+  static bool configured = false;  // per instantiation
+  if (!configured) {
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_nt_b3_kernel<TAG, BM, BN, WM, WN, EPI>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.ksplit);
+  hipLaunchKernelGGL((igemm_nt_b3_kernel<TAG, BM, BN, WM, WN, EPI>), grid, dim3(64 * (BM / WM) * (BN / WN)),
+                     lds, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
 
+int b3_tile() {  // DX_B3_TILE: 0 = 256x64 (4 waves of 64x64), 1 = 128x64 (4 waves of 64x32)
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_B3_TILE"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+template <int TAG, int EPI>
+int launch_b3(const NTArgs &a, hipStream_t stream) {
+  if (b3_tile() == 1) return launch_b3_as<TAG, 128, 64, 64, 32, EPI>(a, stream);
+  return launch_b3_as<TAG, 256, 64, 64, 64, EPI>(a, stream);
+}
+
 }  // namespace
 
-// bf16x3-split variants of the big NT stages (float inputs, N >= 64).  Returns DX_ENOSUP for a
-// stage it does not cover so that the caller falls back to the fp32-MFMA kernel.
+// bf16x3-split variants of the big NT stages (float activations, pre-split weight planes, N >= 64).
+// Returns DX_ENOSUP for a stage it does not cover so that the caller falls back to the
+// fp32-MFMA kernel.
 int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream) {
-  if (a.g.seglen % 32 || (a.K / a.ksplit) % 32 || a.N < 64) return DX_ENOSUP;
+  if (!a.Wb || a.g.seglen % 32 || (a.K / a.ksplit) % 32 || a.N < 64 || a.K % 8) return DX_ENOSUP;
   switch (stage) {
     case ST_CONV1_FWD: return epi == EPI_BIAS_RELU ? launch_b3<ST_CONV1_FWD, EPI_BIAS_RELU>(a, stream) : DX_ENOSUP;
     case ST_CONV2_FWD: return epi == EPI_BIAS_RELU ? launch_b3<ST_CONV2_FWD, EPI_BIAS_RELU>(a, stream) : DX_ENOSUP;
@@ -248,6 +291,45 @@ int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream) {
     case ST_CONV1_DGRAD: return epi == EPI_MASK ? launch_b3<ST_CONV1_DGRAD, EPI_MASK>(a, stream) : DX_ENOSUP;
     default: return DX_ENOSUP;
   }
+}
+
+// fp32 [n] -> three bf16 planes dst[0..n), dst[n..2n), dst[2n..3n) with src == hi + mid + lo exactly
+namespace {
+struct SplitTable {
+  const float *src[kMaxSplitJobs];
+  uint16_t *dst[kMaxSplitJobs];
+  long long count[kMaxSplitJobs];
+};
+__global__ __launch_bounds__(256) void split_planes_kernel(const SplitTable t) {
+  const float *src = t.src[blockIdx.y];
+  uint16_t *dst = t.dst[blockIdx.y];
+  const long long n = t.count[blockIdx.y];  // multiple of 4
+  for (long long i = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 4; i < n;
+       i += static_cast<long long>(gridDim.x) * 1024) {
+    const Split4 s = split4(*reinterpret_cast<const f32x4 *>(src + i));
+    *reinterpret_cast<uint2 *>(dst + i) = s.hi;
+    *reinterpret_cast<uint2 *>(dst + n + i) = s.mid;
+    *reinterpret_cast<uint2 *>(dst + 2 * n + i) = s.lo;
+  }
+}
+}  // namespace
+
+int launch_split_planes(const float *const *src, uint16_t *const *dst, const long long *count, int njobs,
+                        hipStream_t stream) {
+  DX_REQUIRE(njobs >= 0 && njobs <= kMaxSplitJobs, "split_planes: %d jobs (max %d)", njobs, kMaxSplitJobs);
+  if (njobs == 0) return DX_OK;
+  SplitTable t;
+  long long biggest = 0;
+  for (int i = 0; i < njobs; ++i) {
+    DX_REQUIRE(src[i] && dst[i] && count[i] > 0 && count[i] % 4 == 0, "split_planes: bad job %d", i);
+    t.src[i] = src[i]; t.dst[i] = dst[i]; t.count[i] = count[i];
+    if (count[i] > biggest) biggest = count[i];
+  }
+  int bx = cdiv(biggest, 1024);
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(split_planes_kernel, dim3(bx, njobs), dim3(256), 0, stream, t);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
 }
 
 }  // namespace dx

@@ -159,6 +159,11 @@ typedef struct dx_cnn_ctx {
   long long packed_count, slab_count;
   long long y0_count, y1_count, y2_count, hid_count, head_count;  /* floats per buffer */
   long long hid_slab_count;         /* split-K partials of the linear layer (rollout path) */
+  /* offsets (in floats, inside `packed`) of the bf16 planes [3][N][K] of the NT weight mirrors:
+   * conv1 fwd, conv2 fwd, linear fwd, conv1 dgrad (4 parity packs as one matrix), conv2 dgrad,
+   * linear dgrad -- operands of the bf16-split GEMMs (igemm_b3.hip) */
+  long long pb_c1f, pb_c2f, pb_fcf, pb_c1d, pb_c2d, pb_fcd;
+  long long pb_c0f;                 /* conv0 fwd planes: operand of the rollout first-layer kernel */
   /* ---- device buffers (caller-allocated, fp32) ---- */
   float *params, *grads;            /* param_count */
   float *packed;                    /* packed_count; ZERO-FILLED once by the owner: dx_cnn_pack

@@ -1,6 +1,6 @@
 """Latency of the rollout step (dx_cnn_act + synthetic env step) per batch size."""
 import json, sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from derl_amd.cnn_engine import CnnEngine
 dev = torch.device("cuda:0")
 for B in (32, 64, 128, 256):

@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import derl_amd as derl  # noqa: E402
 
 

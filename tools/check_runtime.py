@@ -1,6 +1,6 @@
 """Prints which HIP runtime copies are mapped after loading torch + libderl_amd.so."""
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from derl_amd import _lib
 _lib.load()

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, "."); sys.path.insert(0, "tests/golden")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); sys.path.insert(0, "tests/golden")
 import numpy as np, torch, torch.nn.functional as F
 import inputs as gi, oracle
 from derl_amd.cnn_engine import CnnEngine

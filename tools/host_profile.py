@@ -5,7 +5,7 @@ usage: python tools/host_profile.py [nenvs] [iterations]
 import cProfile, io, pstats, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import derl_amd as derl
 
 nenvs = int(sys.argv[1]) if len(sys.argv) > 1 else 32

@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench  # noqa: E402
 from derl_amd import _lib  # noqa: E402
 from derl_amd.cnn_engine import CnnEngine  # noqa: E402
