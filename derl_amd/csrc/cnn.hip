@@ -28,6 +28,14 @@ bool use_b3() {  // DX_SPLIT_BF16=1: big NT stages on the bf16 matrix cores (exa
   return v != 0;
 }
 
+// DX_C0LAT_MAX_TILES: largest 32-pixel tile count of the rollout conv0 kernel.  Measured crossover
+// against the 256-pixel-tile kernel: B=64 9.4 vs 11.1 us, B=128 14.7 vs 11.7 us, B=256 25.8 vs 15.0 us.
+int conv0_lat_max_tiles() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_C0LAT_MAX_TILES"); v = e ? atoi(e) : 1024; }
+  return v;
+}
+
 bool conv0_f32() {  // DX_CONV0_F32=1: first layer on the fp32 matrix instructions (conv0.hip)
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_CONV0_F32"); v = e ? atoi(e) : 0; }
@@ -310,7 +318,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     case ST_CONV0_FWD:
       a = nt_args(conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), pk + c->pk_c0f,
                   w + c->off_b[0], c->y0, kC0, M0, kC0, 64 * IC0);
-      if (obs_is_u8 && IC0 == 4 && M0 <= 32 * 4096 && !conv0_f32()) {  // rollout-sized batches
+      if (obs_is_u8 && IC0 == 4 && M0 <= 32LL * conv0_lat_max_tiles() && !conv0_f32()) {  // rollout-sized batches
         Conv0Args d;
         std::memset(&d, 0, sizeof(d));
         d.obs = static_cast<const uint8_t *>(obs); d.idx = sample_idx;
