@@ -5,6 +5,8 @@ with the same observation / action contract, and CartPole-v1 is built in."""
 from .spaces import Box, Discrete, Space, is_box, is_discrete
 from .synthetic import SyntheticAtariEnv, SyntheticMuJoCoEnv
 from .cartpole import CartPoleBatch
+from .env_batch import EnvBatch, ParallelEnvBatch, SingleEnvBatch, SpaceBatch
+from .bridge import HostEnvBridge
 
 ATARI_ACTIONS = {"Breakout": 4, "SpaceInvaders": 6, "Pong": 6, "BeamRider": 9, "Qbert": 6,
                  "Seaquest": 18, "Enduro": 9}

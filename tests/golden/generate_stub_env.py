@@ -34,3 +34,45 @@ class CountingPolicy:
     n = inputs.shape[0]
     return dict(actions=np.arange(n) + self.calls, log_prob=np.full(n, -0.5, np.float32),
                 values=np.full((n, 1), float(self.calls), np.float32))
+
+
+class _PlainSpace:
+  """Stand-in for a gym space: only the attributes derl's SpaceBatch reads."""
+  def __init__(self, shape, dtype, n=None):
+    self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+    if n is not None:
+      self.n = n
+
+  def sample(self):
+    return np.zeros(self.shape, self.dtype)
+
+
+class ScriptedEnv:
+  """Single env with a fixed episode length: obs = (tag, episode, t), reward = 0.5*action + t,
+  done when t == episode_len (the env-batch fixtures exercise the auto-reset with it)."""
+  def __init__(self, tag, episode_len):
+    self.tag, self.episode_len = float(tag), int(episode_len)
+    self.episode, self.t = -1, 0
+    self.observation_space = _PlainSpace((3,), np.float32)
+    self.action_space = _PlainSpace((), np.int64, n=5)
+
+  def _obs(self):
+    return np.array([self.tag, self.episode, self.t], np.float32)
+
+  def reset(self):
+    self.episode += 1
+    self.t = 0
+    return self._obs()
+
+  def step(self, action):
+    self.t += 1
+    reward = 0.5 * float(action) + self.t
+    done = self.t == self.episode_len
+    return self._obs(), reward, done, {"t": self.t}
+
+  def close(self):
+    pass
+
+
+def scripted_actions(step, nenvs):
+  return (np.arange(nenvs) * 3 + step) % 5
