@@ -7,6 +7,7 @@ from .synthetic import SyntheticAtariEnv, SyntheticMuJoCoEnv
 from .cartpole import CartPoleBatch
 from .env_batch import EnvBatch, ParallelEnvBatch, SingleEnvBatch, SpaceBatch
 from .bridge import HostEnvBridge
+from .normalize import Normalize
 
 ATARI_ACTIONS = {"Breakout": 4, "SpaceInvaders": 6, "Pong": 6, "BeamRider": 9, "Qbert": 6,
                  "Seaquest": 18, "Enduro": 9}
@@ -33,9 +34,11 @@ def is_mujoco_id(env_id):
   return _base_name(env_id) in MUJOCO_DIMS
 
 
-def make(env_id, nenvs=None, seed=0, device="cuda", rank=0, **kwargs):
+def make(env_id, nenvs=None, seed=0, device="cuda", rank=0, normalize=False, **kwargs):
   """Creates a batched env.  nenvs=None means one env (derl's unbatched case maps to a
-  batch of 1 here)."""
+  batch of 1 here).  ``normalize=True`` puts the device ``Normalize`` wrapper on a
+  MuJoCo-family env like derl's mujoco_wrap does (make_env.py:158-167); the synthetic stand-in
+  already produces observations in the wrapper's output range, so it is off by default."""
   del kwargs
   seed = 0 if seed is None else seed
   if env_id.startswith("CartPole"):
@@ -45,6 +48,7 @@ def make(env_id, nenvs=None, seed=0, device="cuda", rank=0, **kwargs):
                              device=device, rank=rank)
   if is_mujoco_id(env_id):
     obs_dim, act_dim = MUJOCO_DIMS[_base_name(env_id)]
-    return SyntheticMuJoCoEnv(nenvs or 1, obs_dim, act_dim, seed, device=device, rank=rank)
+    env = SyntheticMuJoCoEnv(nenvs or 1, obs_dim, act_dim, seed, device=device, rank=rank)
+    return Normalize(env) if normalize else env
   raise ValueError(f"unknown env id {env_id!r}: this build provides CartPole-v1 and synthetic "
                    f"stand-ins for {sorted(ATARI_ACTIONS)} / {sorted(MUJOCO_DIMS)}")

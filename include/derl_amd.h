@@ -107,6 +107,20 @@ int dx_gather_rows(const void *src, const int32_t *idx, void *dst, long long nro
 int dx_gather_rows_multi(const void *const *src, void *const *dst, const long long *row_bytes,
                          int narrays, const int32_t *idx, long long nrows, void *stream);
 
+/* Observation / return normalisation of a batched env -- replaces the per-step body of
+ * derl/env/mujoco_wrappers.py:64-124 (Normalize.step / .reset / .observation) and
+ * RunningMeanVar (:8-61).  obs (N, D) f32; rewards (N) f32 and resets (N) bytes may be NULL
+ * (reset(): observations only).  State, float64 on the device, updated in place:
+ * obs_stats = {mean[D], var[D], count} (NULL: observations pass through), ret_stats =
+ * {mean, var, count} (NULL: rewards pass through unclipped), ret (N) discounted returns.
+ * workspace: >= 256 * D doubles of scratch (partial moments per row block).
+ * update_stats = 0 applies the current statistics without updating them. */
+int dx_normalize_step_f32(const float *obs, int N, int D, const float *rewards,
+                          const uint8_t *resets, double *obs_stats, double *ret_stats, double *ret,
+                          double *workspace, long long workspace_count, float clipobs, float cliprew,
+                          double gamma, double eps, int update_stats, float *obs_out, float *rew_out,
+                          void *stream);
+
 /* ---------------------------------------------------------------------------------
  * Categorical head -- replaces the distribution part of derl/policies.py:61-80
  * (ActorCriticPolicy.act with torch Categorical) and derl/alg/ppo.py:24-108 (PPOLoss) /
