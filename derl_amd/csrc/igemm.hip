@@ -319,8 +319,22 @@ __global__ __launch_bounds__(64 * (BN / WN) * (BKO / WK)) void igemm_tn_kernel(c
   const Gather &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn0 = (wave / NWK) * WN, wk0 = (wave % NWK) * WK;
-  const int k0 = blockIdx.x * BKO, n0 = blockIdx.y * BN;
-  const int mbeg = blockIdx.z * a.mper;
+  // Block -> (k block, n block, M slice).  With a.swizzle the grid is 1-D and numbered so that the
+  // blocks an XCD receives (round-robin over the 8 XCDs) are ALL (k, n) blocks of one M slice after
+  // another: they re-read the same G rows and overlapping activation rows from that XCD's L2
+  // instead of HBM (conv1 wgrad: 1.43 GB -> see DESIGN.md).
+  int bk = blockIdx.x, bn = blockIdx.y, bz = blockIdx.z;
+  if (a.swizzle) {
+    const int per_slice = a.gk * a.gn;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int zl = seq / per_slice, inner = seq - zl * per_slice;
+    bk = inner % a.gk;
+    bn = inner / a.gk;
+    bz = zl * 8 + xcd;
+    if (bz >= a.msplit) return;  // uniform: the grid is padded to a multiple of 8 slices
+  }
+  const int k0 = bk * BKO, n0 = bn * BN;
+  const int mbeg = bz * a.mper;
   const int mend = min(a.M, mbeg + a.mper);
 
   // this thread's fixed k position (4 consecutive k inside one run)
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(64 * (BN / WN) * (BKO / WK)) void igemm_tn_kernel(c
         *reinterpret_cast<float4 *>(&Gs[(p * GRPP + grow) * BN + 4 * gnq]) = masked(graw[p], (gok >> p) & 1u);
     __syncthreads();
     if (ms + BMS < mend) fetch(ms + BMS);
-    if (a.bias_slab && blockIdx.x == 0 && tid < BN) {
+    if (a.bias_slab && bk == 0 && tid < BN) {
 #pragma unroll 8
       for (int r = 0; r < BMS; ++r) bias_acc += Gs[r * BN + tid];
     }
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(64 * (BN / WN) * (BKO / WK)) void igemm_tn_kernel(c
     }
   }
 
-  float *slab = a.slab + static_cast<long long>(blockIdx.z) * a.N * a.K;
+  float *slab = a.slab + static_cast<long long>(bz) * a.N * a.K;
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -410,8 +424,8 @@ __global__ __launch_bounds__(64 * (BN / WN) * (BKO / WK)) void igemm_tn_kernel(c
         if (kk < a.K) slab[static_cast<long long>(n) * a.K + kk] = acc[i][j][r];
       }
     }
-  if (a.bias_slab && blockIdx.x == 0 && tid < BN && n0 + tid < a.N)
-    a.bias_slab[static_cast<long long>(blockIdx.z) * a.N + n0 + tid] = bias_acc;
+  if (a.bias_slab && bk == 0 && tid < BN && n0 + tid < a.N)
+    a.bias_slab[static_cast<long long>(bz) * a.N + n0 + tid] = bias_acc;
 }
 
 // ------------------------------------------------------------------------------------
@@ -477,9 +491,20 @@ int launch_nt_small(const NTArgs &a, hipStream_t stream) {
   return DX_OK;
 }
 
+int tn_swizzle() {  // DX_TN_SWIZZLE=0: plain 3-D grid for the wgrad kernels
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_TN_SWIZZLE"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 template <int TAG, int BN, int BKO, int WN, int WK, bool AU8>
-int launch_tn_as(const TNArgs &a, hipStream_t stream) {
-  dim3 grid(cdiv(a.K, BKO), cdiv(a.N, BN), a.msplit);
+int launch_tn_as(const TNArgs &a_in, hipStream_t stream) {
+  TNArgs a = a_in;
+  a.gk = cdiv(a.K, BKO);
+  a.gn = cdiv(a.N, BN);
+  a.swizzle = (tn_swizzle() && a.msplit >= 64) ? 1 : 0;  // few slices: keep every XCD busy instead
+  dim3 grid(a.gk, a.gn, a.msplit);
+  if (a.swizzle) grid = dim3(cdiv(a.msplit, 8) * 8 * a.gk * a.gn, 1, 1);
   hipLaunchKernelGGL((igemm_tn_kernel<TAG, BN, BKO, WN, WK, AU8>), grid,
                      dim3(64 * (BN / WN) * (BKO / WK)), 0, stream, a);
   DX_LAUNCH_CHECK();
@@ -502,6 +527,11 @@ static int split_min_m() {
   if (v < 0) { const char *e = getenv("DX_SPLIT_MIN_M"); v = e ? atoi(e) : 65536; }
   return v;
 }
+static int nt_big_min_m() {  // DX_NT_BIG_MIN_M: rows from which the N=64 stages use 128x64 tiles
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_NT_BIG_MIN_M"); v = e ? atoi(e) : 65536; }
+  return v;
+}
 static int nt_ablate() {
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_ABLATE"); v = e ? atoi(e) : 0; }
@@ -510,7 +540,7 @@ static int nt_ablate() {
 // Small problems (rollout batches) are latency-bound: 64-deep K steps halve the number of
 // barrier / load round trips per tile.
 #define DX_NT_N64(ST, EPI)                                                                      \
-  if (a.M >= 65536) return launch_nt_as<ST, 128, 64, 64, 32, false, EPI>(a, stream);            \
+  if (a.M >= nt_big_min_m()) return launch_nt_as<ST, 128, 64, 64, 32, false, EPI>(a, stream);   \
   if (a.g.seglen % 64 == 0 && (a.K / a.ksplit) % 64 == 0 && !a.om.enabled)                      \
     return launch_nt_small<ST, EPI>(a, stream);                                                 \
   return launch_nt_as<ST, 64, 64, 32, 32, false, EPI>(a, stream)

@@ -90,6 +90,7 @@ struct TNArgs {
   float *bias_slab;  // [msplit][N] or nullptr
   int M, N, K;
   int msplit, mper;  // mper % 32 == 0
+  int swizzle, gk, gn;  // set by the launcher: XCD-aware 1-D block numbering (see igemm_tn_kernel)
 };
 
 // network stages: one kernel instantiation (= one profiler row) each
