@@ -48,6 +48,7 @@ SIGNATURES = {
     "dx_cnn_pack": [P, P],
     "dx_cnn_forward": [P, P, c_int, P, c_int, P],
     "dx_cnn_backward": [P, P, c_int, P, c_int, P],
+    "dx_cnn_backward_part": [P, P, c_int, P, c_int, c_int, P],
     "dx_cnn_stage": [P, c_int, P, c_int, P, c_int, P],
     "dx_cnn_act": [P, P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
     "dx_cnn_rollout_synth": [P, P, c_int, c_int, P, P, P, P, P, c_uint64, c_uint64, c_uint64,

@@ -3,7 +3,7 @@ from abc import ABC, abstractmethod
 
 import torch
 
-from .. import summary
+from .. import distributed, summary
 from ..optim import _FlatOptimizer
 
 
@@ -104,7 +104,10 @@ class Trainer:
       # per update (the head gradient already sits in the engine when the loss returns)
       loss, backward_fn = native(data)
       self.optimizer.zero_grad()
-      backward_fn(None)
+      if distributed.world_size() > 1 and hasattr(alg.model.engine, "tail_offset"):
+        backward_fn(None, on_part=self.optimizer.reduce_part)  # all-reduce overlapped with backward
+      else:
+        backward_fn(None)
     else:
       loss = alg.loss(data)
       self.optimizer.zero_grad()

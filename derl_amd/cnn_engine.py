@@ -158,10 +158,21 @@ class CnnEngine:
               int(policy_seed), int(policy_counter), int(env_seed), int(env_counter),
               float(p_reward), float(p_reset), _lib.stream_ptr(self.device))
 
-  def backward(self, obs, sample_idx=None):
-    """Consumes self.dhead (B, 32) and fills self.grads (same obs / sample_idx as forward)."""
+  def backward(self, obs, sample_idx=None, part=None):
+    """Consumes self.dhead (B, 32) and fills self.grads (same obs / sample_idx as forward).
+    ``part`` 0 / 1 runs the two halves separately (``tail_offset`` splits the gradient buffer):
+    after part 0 the gradients of the linear layer and the heads are final."""
     batch, is_u8 = self._obs_args(obs, sample_idx)
     self._ensure_backward()
-    _lib.call("dx_cnn_backward", ctypes.byref(self.ctx), _lib.ptr(obs), is_u8,
-              _lib.ptr(sample_idx), batch, _lib.stream_ptr(self.device))
+    if part is None:
+      _lib.call("dx_cnn_backward", ctypes.byref(self.ctx), _lib.ptr(obs), is_u8,
+                _lib.ptr(sample_idx), batch, _lib.stream_ptr(self.device))
+    else:
+      _lib.call("dx_cnn_backward_part", ctypes.byref(self.ctx), _lib.ptr(obs), is_u8,
+                _lib.ptr(sample_idx), batch, int(part), _lib.stream_ptr(self.device))
     return self.grads
+
+  @property
+  def tail_offset(self):
+    """First element of the (linear layer + heads) part of the flat parameter / gradient buffer."""
+    return int(self.ctx.off_w[3])

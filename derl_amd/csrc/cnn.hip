@@ -295,13 +295,52 @@ static NTArgs nt_args(const Gather &g, const float *Wp, const float *bias, float
   return a;
 }
 
+// slabs -> canonical gradients.  `which`: bit 0 = the three conv layers, bit 1 = linear layer +
+// heads (the contiguous tail of the flat gradient buffer: its all-reduce can start while the conv
+// layers' backward still runs)
+static int finalize_grads(const dx_cnn_ctx *c, const Plan &plan, int which, hipStream_t s) {
+  const int IC0 = c->in_c, A = c->num_actions, flat = c->flat, P = c->h2 * c->w2;
+  PermuteJob j[kMaxJobs];
+  int n = 0;
+  float *g = c->grads;
+  auto addw = [&](int layer, long long off_dst, long long total, int D1, int D2, int D3, long long s0,
+                  long long s1, long long s2, long long s3, long long off, int N, int K, int scatter) {
+    j[n++] = PermuteJob{c->slabs + plan.s[layer].w_off, g + off_dst, total, D1, D2, D3, s0, s1, s2, s3,
+                        off, plan.s[layer].msplit, static_cast<long long>(N) * K, scatter};
+  };
+  auto addb = [&](int layer, long long off_dst, long long total, long long off, int N) {
+    j[n++] = PermuteJob{c->slabs + plan.s[layer].b_off, g + off_dst, total, 1, 1, 1, 1, 0, 0, 0, off,
+                        plan.s[layer].msplit, N, 0};
+  };
+  if (which & 1) {
+    // conv: iterate the slab [oc][kh][kw][ic] in its own order (coalesced slab reads) and
+    // scatter into the canonical (oc, ic, kh, kw) layout
+    addw(L_C0, c->off_w[0], kC0 * 64LL * IC0, 8, 8, IC0, IC0 * 64LL, 8, 1, 64, 0, kC0, 64 * IC0, 1);
+    addw(L_C1, c->off_w[1], kC1 * 16LL * kC0, 4, 4, kC0, kC0 * 16LL, 4, 1, 16, 0, kC1, 16 * kC0, 1);
+    addw(L_C2, c->off_w[2], kC2 * 9LL * kC1, 3, 3, kC1, kC1 * 9LL, 3, 1, 9, 0, kC2, 9 * kC1, 1);
+    addb(L_C0, c->off_b[0], kC0, 0, kC0);
+    addb(L_C1, c->off_b[1], kC1, 0, kC1);
+    addb(L_C2, c->off_b[2], kC2, 0, kC2);
+  }
+  if (which & 2) {
+    // linear: slab [n][p][c] -> canonical [n][c*P + p]
+    addw(L_FC, c->off_w[3], static_cast<long long>(kHid) * flat, P, kC2, 1, flat, 1, P, 0, 0, kHid, flat, 1);
+    addw(L_HD, c->off_w[4], static_cast<long long>(A) * kHid, kHid, 1, 1, kHid, 1, 0, 0, 0, kHeadLd, kHid, 0);
+    addw(L_HD, c->off_w[5], kHid, kHid, 1, 1, kHid, 1, 0, 0, static_cast<long long>(A) * kHid, kHeadLd, kHid, 0);
+    addb(L_FC, c->off_b[3], kHid, 0, kHid);
+    addb(L_HD, c->off_b[4], A, 0, kHeadLd);
+    addb(L_HD, c->off_b[5], 1, A, kHeadLd);
+  }
+  return launch_permute_reduce(j, n, s);
+}
+
 // One launch (one profiler row) of the network.  Forward = stages ST_CONV0_FWD..ST_HEADS_FWD,
 // backward = ST_HEADS_WGRAD..ST_FINALIZE in enum order.
 static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is_u8,
                      const int32_t *sample_idx, int B, const Plan &plan, hipStream_t s) {
   const float *w = c->params;
   const float *pk = c->packed;
-  const int IC0 = c->in_c, A = c->num_actions, flat = c->flat, P = c->h2 * c->w2;
+  const int IC0 = c->in_c, flat = c->flat, P = c->h2 * c->w2;
   const long long M0 = static_cast<long long>(B) * c->h0 * c->w0, M1 = static_cast<long long>(B) * c->h1 * c->w1,
                   M2 = static_cast<long long>(B) * P;
   auto tn = [&](int layer, const Gather &g, const float *G, int ldg, long long M, int N, int K, bool u8) {
@@ -424,40 +463,8 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       }
       return tn(L_C0, conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), c->dy0, kC0,
                 M0, kC0, 64 * IC0, obs_is_u8 != 0);
-    case ST_FINALIZE: {
-      // slabs -> canonical gradients
-      PermuteJob j[kMaxJobs];
-      int n = 0, n_scatter = 0;
-      float *g = c->grads;
-      auto addw = [&](int layer, long long off_dst, long long total, int D1, int D2, int D3, long long s0,
-                      long long s1, long long s2, long long s3, long long off, int N, int K) {
-        j[n++] = PermuteJob{c->slabs + plan.s[layer].w_off, g + off_dst, total, D1, D2, D3, s0, s1, s2, s3,
-                            off, plan.s[layer].msplit, static_cast<long long>(N) * K};
-      };
-      auto addb = [&](int layer, long long off_dst, long long total, long long off, int N) {
-        j[n++] = PermuteJob{c->slabs + plan.s[layer].b_off, g + off_dst, total, 1, 1, 1, 1, 0, 0, 0, off,
-                            plan.s[layer].msplit, N};
-      };
-      // conv: iterate the slab [oc][kh][kw][ic] in its own order (coalesced slab reads) and
-      // scatter into the canonical (oc, ic, kh, kw) layout
-      addw(L_C0, c->off_w[0], kC0 * 64LL * IC0, 8, 8, IC0, IC0 * 64LL, 8, 1, 64, 0, kC0, 64 * IC0);
-      addw(L_C1, c->off_w[1], kC1 * 16LL * kC0, 4, 4, kC0, kC0 * 16LL, 4, 1, 16, 0, kC1, 16 * kC0);
-      addw(L_C2, c->off_w[2], kC2 * 9LL * kC1, 3, 3, kC1, kC1 * 9LL, 3, 1, 9, 0, kC2, 9 * kC1);
-      n_scatter = n;  // the jobs above scatter; the rest are identity maps
-      // linear: slab [n][p][c] -> canonical [n][c*P + p]
-      addw(L_FC, c->off_w[3], static_cast<long long>(kHid) * flat, P, kC2, 1, flat, 1, P, 0, 0, kHid, flat);
-      n_scatter = n;
-      addw(L_HD, c->off_w[4], static_cast<long long>(A) * kHid, kHid, 1, 1, kHid, 1, 0, 0, 0, kHeadLd, kHid);
-      addw(L_HD, c->off_w[5], kHid, kHid, 1, 1, kHid, 1, 0, 0, static_cast<long long>(A) * kHid, kHeadLd, kHid);
-      addb(L_C0, c->off_b[0], kC0, 0, kC0);
-      addb(L_C1, c->off_b[1], kC1, 0, kC1);
-      addb(L_C2, c->off_b[2], kC2, 0, kC2);
-      addb(L_FC, c->off_b[3], kHid, 0, kHid);
-      addb(L_HD, c->off_b[4], A, 0, kHeadLd);
-      addb(L_HD, c->off_b[5], 1, A, kHeadLd);
-      for (int i = 0; i < n_scatter; ++i) j[i].scatter = 1;
-      return launch_permute_reduce(j, n, s);
-    }
+    case ST_FINALIZE:
+      return finalize_grads(c, plan, 3, s);
     default:
       return fail(DX_EINVAL, "dx_cnn: unknown stage %d", stage);
   }
@@ -485,6 +492,24 @@ int dx_cnn_backward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const i
   for (int st = ST_HEADS_WGRAD; st <= ST_FINALIZE; ++st)
     if (int rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, as_stream(stream))) return rc;
   return DX_OK;
+}
+
+// The same backward in two calls so that a data-parallel caller can start the all-reduce of the
+// big tail of the gradient buffer early: part 0 = heads + linear layer (their gradients
+// grads[off_w[3] .. param_count) are final when it returns to the stream), part 1 = the three
+// conv layers (grads[0 .. off_w[3])).  Part 0 must be enqueued first.
+int dx_cnn_backward_part(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const int32_t *sample_idx,
+                         int B, int part, void *stream) {
+  if (int rc = check_ctx(c, "dx_cnn_backward_part", B, true)) return rc;
+  DX_REQUIRE(obs != nullptr, "dx_cnn_backward_part: null observations");
+  DX_REQUIRE(part == 0 || part == 1, "dx_cnn_backward_part: part must be 0 or 1, got %d", part);
+  const Plan plan = make_plan(c, B);
+  hipStream_t s = as_stream(stream);
+  const int first = part == 0 ? ST_HEADS_WGRAD : ST_CONV2_WGRAD;
+  const int last = part == 0 ? ST_FC_DGRAD : ST_CONV0_WGRAD;
+  for (int st = first; st <= last; ++st)
+    if (int rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, s)) return rc;
+  return finalize_grads(c, plan, part == 0 ? 2 : 1, s);
 }
 
 // split of the 3136-deep linear layer over K for small batches (98 K-steps = 2 x 7 x 7)

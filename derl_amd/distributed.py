@@ -44,6 +44,14 @@ def all_reduce_sum(tensor):
   return tensor
 
 
+def all_reduce_sum_async(tensor):
+  """Starts the all-reduce on the communicator's stream (ordered after the work already on the
+  current stream) and returns the handle; ``handle.wait()`` orders the current stream after it."""
+  if world_size() > 1:
+    return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
+  return None
+
+
 def all_reduce_mean_grads(flat_grads):
   """Sum over ranks of the per-shard gradients.  Each rank's loss kernel already scales
   by 1/global_batch, so the SUM is the single-process mean gradient."""

@@ -231,9 +231,16 @@ def _cnn_loss_forward_backward(model, policy, data, mode, cliprange, value_loss_
                                eng.num_actions, mode, cliprange, value_loss_coef, entropy_coef,
                                dhead, global_batch, model._loss_partials)
 
-  def backward_fn(grad_output):
+  def backward_fn(grad_output, on_part=None):
+    """``on_part(k)`` is called when half k of the gradient buffer is final (see
+    _FlatOptimizer.reduce_part): the tail's all-reduce overlaps the conv layers' backward."""
     del grad_output
-    eng.backward(observations, sample_idx)
+    if on_part is None:
+      eng.backward(observations, sample_idx)
+      return
+    for part in (0, 1):
+      eng.backward(observations, sample_idx, part=part)
+      on_part(part)
 
   return terms, backward_fn
 

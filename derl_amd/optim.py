@@ -25,6 +25,7 @@ class _FlatOptimizer:
     self.partials = torch.zeros(ops.NORM_PARTIALS, dtype=torch.float64, device=self.engine.device)
     self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.engine.device)
     self.param_groups = [dict(params=list(model.parameters()), lr=lr)]
+    self._pending = []
 
   def current_lr(self):
     return float(self.lr)
@@ -32,9 +33,28 @@ class _FlatOptimizer:
   def zero_grad(self, set_to_none=False):
     """Gradients are overwritten by every backward; nothing to clear."""
 
+  def reduce_part(self, part):
+    """Data-parallel overlap (the one exchange step of the path): called by the
+    model's backward when one half of the flat gradient buffer is final -- part 0 = linear layer
+    + heads (95 % of the bytes, ready before the conv layers' backward starts), part 1 = the
+    conv layers -- and starts that half's all-reduce on the communicator's stream."""
+    if distributed.world_size() == 1:
+      return
+    off = self.engine.tail_offset
+    grads = self.engine.grads
+    handle = distributed.all_reduce_sum_async(grads[off:] if part == 0 else grads[:off])
+    if handle is not None:
+      self._pending.append(handle)
+
   def reduce_and_norm(self):
-    """All-reduce (when sharded) and the float64 partial sums of g^2."""
-    distributed.all_reduce_mean_grads(self.engine.grads)
+    """All-reduce (when sharded; or wait for the halves started by ``reduce_part``) and the
+    float64 partial sums of g^2."""
+    if self._pending:
+      for handle in self._pending:
+        handle.wait()
+      self._pending = []
+    else:
+      distributed.all_reduce_mean_grads(self.engine.grads)
     ops.grad_sumsq(self.engine.grads, self.partials)
 
 

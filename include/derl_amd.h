@@ -196,6 +196,12 @@ int dx_cnn_forward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
                    const int32_t *sample_idx, int B, void *stream);
 int dx_cnn_backward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
                     const int32_t *sample_idx, int B, void *stream);
+/* The same backward in two calls, for overlapping the gradient all-reduce with it (the one
+ * exchange step of the path): part 0 = heads + linear layer, after which
+ * grads[off_w[3] .. param_count) -- 95 % of the bytes -- are final; part 1 = the conv layers,
+ * grads[0 .. off_w[3]).  Part 0 first. */
+int dx_cnn_backward_part(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
+                         const int32_t *sample_idx, int B, int part, void *stream);
 /* Rollout step of the policy -- replaces derl/policies.py:61-80 for one batch of observations:
  * conv stack, the 3136->512 linear layer as split-K partial slabs (so that a 256-row batch
  * still fills the chip) and ONE fused launch for both heads + Categorical sampling

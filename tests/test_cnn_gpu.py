@@ -225,3 +225,25 @@ def test_fused_rollout_act_matches_unfused_path(batch, A):
   lp, _, _ = oracle.categorical_log_prob_entropy(logits, actions.cpu().numpy())
   nt.assert_allclose(log_prob.cpu().numpy(), lp.numpy(), rtol=1e-4, atol=2e-5)
   nt.assert_allclose(values.cpu().numpy(), vals.numpy()[:, 0], rtol=1e-4, atol=2e-5)
+
+
+def test_backward_in_two_parts_equals_whole_backward():
+  """dx_cnn_backward_part(0) then (1) (the split a data-parallel caller overlaps its all-reduce
+  with) gives bit-identical gradients, and part 0 alone already finalises the tail."""
+  weights = gi.nature_cnn_weights(4, 3)
+  obs = torch.from_numpy(gi.frames(96, 5)).to(DEV)
+  eng = make_engine(4, weights, max_batch=96)
+  eng.forward(obs)
+  eng._ensure_backward()
+  eng.dhead[:96 * 32].normal_()
+  dhead = eng.dhead.clone()
+  whole = eng.backward(obs).clone()
+  eng.forward(obs)
+  eng.dhead.copy_(dhead)
+  eng.grads.fill_(float("nan"))
+  eng.backward(obs, part=0)
+  off = eng.tail_offset
+  assert torch.equal(eng.grads[off:], whole[off:])
+  assert torch.isnan(eng.grads[:off]).all()
+  eng.backward(obs, part=1)
+  assert torch.equal(eng.grads, whole)
