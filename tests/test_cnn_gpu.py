@@ -153,7 +153,9 @@ def test_loss_and_gradients_match_reference_golden(name):
                        err_msg=k)
 
 
-@pytest.mark.parametrize("batch", [1, 5, 37, 130])
+# 1024 / 2100: the training-size code paths (128x64 forward tiles from 65536 rows, wgrad with the
+# XCD-aware block numbering from 64 reduction slices, pixel-group dgrads with a ragged last group)
+@pytest.mark.parametrize("batch", [1, 5, 37, 130, 1024, 2100, 8192])  # 8192 = BASELINE minibatch
 def test_backward_ragged_batches_with_gather(batch):
   rs = np.random.RandomState(batch)
   A = 6
@@ -165,7 +167,7 @@ def test_backward_ragged_batches_with_gather(batch):
               advantages=rs.standard_normal(batch).astype(np.float32),
               values=rs.standard_normal((batch, 1)).astype(np.float32) * 0.2,
               value_targets=rs.standard_normal((batch, 1)).astype(np.float32))
-  eng = make_engine(A, weights, max_batch=256)
+  eng = make_engine(A, weights, max_batch=max(256, batch))
   loss, grads = run_loss_and_backward(eng, data, 0, 0.1, 0.25, 0.01, A,
                                       torch.from_numpy(idx).to(DEV))
   odata = dict(data, observations=pool[idx])
