@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_b16_kernel(const Conv0Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t2][r] = 0.f;
     const uint8_t *wl = Wpl + lrow * kWRowB + 16 * h;
+#pragma unroll 2
     for (int kh = 0; kh < 8; ++kh) {
       const uint8_t *prow = patch + kh * rowB;
 #pragma unroll
@@ -117,17 +118,30 @@ __global__ __launch_bounds__(256) void conv0_fwd_b16_kernel(const Conv0Args a) {
         }
       }
     }
-    // /255, bias, ReLU, NHWC store: col = lane&31 (oc), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // /255, bias, ReLU, NHWC store: col = lane&31 (oc), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Full tiles (all but the last) store through one per-lane base pointer with immediate
+    // offsets; a guarded store per element compiles to 32 exec-mask branches.
+    float *obase = a.out + (static_cast<long long>(m0) + wave * 64 + 4 * h) * 32 + lrow;
+    if (m0 + kTile <= a.M) {
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+      for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wave * 64 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < a.M) {
+        for (int r = 0; r < 16; ++r) {
           const float v = div255(acc[t2][r]) + bias;
-          a.out[static_cast<long long>(m) * 32 + lrow] = v > 0.f ? v : 0.f;
+          obase[(t2 * 32 + (r & 3) + 8 * (r >> 2)) * 32] = v > 0.f ? v : 0.f;
         }
-      }
+    } else {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wave * 64 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < a.M) {
+            const float v = div255(acc[t2][r]) + bias;
+            obase[(t2 * 32 + (r & 3) + 8 * (r >> 2)) * 32] = v > 0.f ? v : 0.f;
+          }
+        }
+    }
   }
 }
 

@@ -130,6 +130,33 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float *out = a.out + (a.ksplit > 1 ? blockIdx.z * a.slab_stride : 0);
   const OutMap &om = a.om;
+  auto finish = [&](float v, long long o, int n) {
+    if (a.ksplit == 1) {
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH) v += a.bias[n];
+      if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+      if (EPI == EPI_BIAS_TANH) v = tanhf(v);
+      if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
+      if (EPI == EPI_DTANH) { const float y = a.mask_src[o]; v *= 1.f - y * y; }
+    } else if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && blockIdx.z == 0) {
+      v += a.bias[n];  // split-K partials: the bias rides on slab 0 (no activation allowed)
+    }
+    out[o] = v;
+  };
+  if (!om.enabled && m0 + BM <= a.M && n0 + BN <= a.N) {
+    // interior tile (uniform): no per-element guards -- each guard is an exec-mask branch
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long row = static_cast<long long>(m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * a.ldc;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn0 + 32 * j + (lane & 31);
+          finish(acc[i][j][r], row + n, n);
+        }
+      }
+    return;
+  }
   // per column sub-tile: pixel-group offsets of the output map (uniform per j: scalar division
   // once per sub-tile instead of runtime divisions per element)
   int gy[TN], gx[TN], cc[TN];
@@ -171,17 +198,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
         } else {
           o = static_cast<long long>(m) * a.ldc + n;
         }
-        float v = acc[i][j][r];
-        if (a.ksplit == 1) {
-          if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH) v += a.bias[n];
-          if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
-          if (EPI == EPI_BIAS_TANH) v = tanhf(v);
-          if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
-          if (EPI == EPI_DTANH) { const float y = a.mask_src[o]; v *= 1.f - y * y; }
-        } else if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && blockIdx.z == 0) {
-          v += a.bias[n];  // split-K partials: the bias rides on slab 0 (no activation allowed)
-        }
-        out[o] = v;
+        finish(acc[i][j][r], o, n);
       }
     }
 }
@@ -275,13 +292,8 @@ __global__ __launch_bounds__(256) void igemm_nt_small_kernel(const NTArgs a) {
     }
   }
   float *out = a.out + (a.ksplit > 1 ? blockIdx.z * a.slab_stride : 0);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int n = n0 + wn0 + (lane & 31);
-    if (m >= a.M || n >= a.N) continue;
-    const long long o = static_cast<long long>(m) * a.ldc + n;
-    float v = acc[r];
+  const int n = n0 + wn0 + (lane & 31);
+  auto finish = [&](float v, long long o) {
     if (a.ksplit == 1) {
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH) v += a.bias[n];
       if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
@@ -292,6 +304,19 @@ __global__ __launch_bounds__(256) void igemm_nt_small_kernel(const NTArgs a) {
       v += a.bias[n];
     }
     out[o] = v;
+  };
+  if (m0 + BM <= a.M && n0 + BN <= a.N) {  // interior tile (uniform): no per-element exec branches
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      finish(acc[r], static_cast<long long>(m) * a.ldc + n);
+    }
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m < a.M && n < a.N) finish(acc[r], static_cast<long long>(m) * a.ldc + n);
   }
 }
 
@@ -412,18 +437,30 @@ __global__ __launch_bounds__(64 * (BN / WN) * (BKO / WK)) void igemm_tn_kernel(c
   }
 
   float *slab = a.slab + static_cast<long long>(bz) * a.N * a.K;
+  if (n0 + BN <= a.N && k0 + BKO <= a.K) {  // interior tile (uniform): unguarded stores
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wn0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (n >= a.N) continue;
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 #pragma unroll
-      for (int j = 0; j < TK; ++j) {
-        const int kk = k0 + wk0 + 32 * j + (lane & 31);
-        if (kk < a.K) slab[static_cast<long long>(n) * a.K + kk] = acc[i][j][r];
+        for (int j = 0; j < TK; ++j)
+          slab[static_cast<long long>(n) * a.K + k0 + wk0 + 32 * j + (lane & 31)] = acc[i][j][r];
       }
-    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n >= a.N) continue;
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+          const int kk = k0 + wk0 + 32 * j + (lane & 31);
+          if (kk < a.K) slab[static_cast<long long>(n) * a.K + kk] = acc[i][j][r];
+        }
+      }
+  }
   if (a.bias_slab && bk == 0 && tid < BN && n0 + tid < a.N)
     a.bias_slab[static_cast<long long>(bz) * a.N + n0 + tid] = bias_acc;
 }

@@ -137,16 +137,22 @@ __global__ __launch_bounds__(256) void igemm_nt_pix_kernel(const NTArgs a, int n
       imgo = static_cast<long long>(g.OHW) * a.ldc;
     }
     if (!inside) continue;  // uniform
+    const bool full = (grp + 1) * BM <= nimg;  // uniform: all but the last image group
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int img = grp * BM + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (img >= nimg) continue;
         const long long o = img * imgo + pixo + col;
-        float v = acc[i][j][r];
-        if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
-        a.out[o] = v;
+        if (full) {  // no per-element exec-mask branch
+          float v = acc[i][j][r];
+          if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
+          a.out[o] = v;
+        } else if (img < nimg) {
+          float v = acc[i][j][r];
+          if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
+          a.out[o] = v;
+        }
       }
   }
 }
