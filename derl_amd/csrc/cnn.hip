@@ -366,7 +366,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
         const int rc = launch_conv0_lat_b16(d, planes(c, c->pb_c0f), s);
         if (rc != DX_ENOSUP) return rc;
       }
-      if (obs_is_u8) {  // fp32-MFMA latency kernel
+      if (obs_is_u8 && conv0_f32() && M0 <= 32LL * conv0_lat_max_tiles()) {  // fp32-MFMA latency kernel
         const int rc = launch_nt_lat(a, true, EPI_BIAS_RELU, stage, s);
         if (rc != DX_ENOSUP) return rc;
       }
