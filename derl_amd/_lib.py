@@ -31,6 +31,7 @@ SIGNATURES = {
                                  c_double, P, P],
     "dx_gather_rows": [P, P, P, c_longlong, c_longlong, P],
     "dx_gather_rows_multi": [P, P, P, c_int, P, c_longlong, P],
+    "dx_reward_summary_f32": [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P, P],
     "dx_normalize_step_f32": [P, c_int, c_int, P, P, P, P, P, P, c_longlong, c_float, c_float,
                               c_double, c_double, c_int, P, P, P],
     "dx_categorical_act_f32": [P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],

@@ -8,6 +8,7 @@ from .cartpole import CartPoleBatch
 from .env_batch import EnvBatch, ParallelEnvBatch, SingleEnvBatch, SpaceBatch
 from .bridge import HostEnvBridge
 from .normalize import Normalize
+from .summarize import DeviceSummarize, RewardSummarizer, Summarize
 
 ATARI_ACTIONS = {"Breakout": 4, "SpaceInvaders": 6, "Pong": 6, "BeamRider": 9, "Qbert": 6,
                  "Seaquest": 18, "Enduro": 9}
@@ -34,21 +35,26 @@ def is_mujoco_id(env_id):
   return _base_name(env_id) in MUJOCO_DIMS
 
 
-def make(env_id, nenvs=None, seed=0, device="cuda", rank=0, normalize=False, **kwargs):
+def make(env_id, nenvs=None, seed=0, device="cuda", rank=0, normalize=False, summarize=False,
+         **kwargs):
   """Creates a batched env.  nenvs=None means one env (derl's unbatched case maps to a
   batch of 1 here).  ``normalize=True`` puts the device ``Normalize`` wrapper on a
   MuJoCo-family env like derl's mujoco_wrap does (make_env.py:158-167); the synthetic stand-in
-  already produces observations in the wrapper's output range, so it is off by default."""
+  already produces observations in the wrapper's output range, so it is off by default.
+  ``summarize=True`` adds the reward summaries of derl's Summarize wrapper (make_env.py:108-109,
+  123-124; tags ``<env_id>/total_reward`` ...), advanced on the device once per rollout."""
   del kwargs
   seed = 0 if seed is None else seed
   if env_id.startswith("CartPole"):
     return CartPoleBatch(nenvs or 1, seed)
   if is_atari_id(env_id):
-    return SyntheticAtariEnv(nenvs or 1, ATARI_ACTIONS[_base_name(env_id)], seed,
-                             device=device, rank=rank)
+    env = SyntheticAtariEnv(nenvs or 1, ATARI_ACTIONS[_base_name(env_id)], seed,
+                            device=device, rank=rank)
+    return DeviceSummarize(env, env_id) if summarize else env
   if is_mujoco_id(env_id):
     obs_dim, act_dim = MUJOCO_DIMS[_base_name(env_id)]
     env = SyntheticMuJoCoEnv(nenvs or 1, obs_dim, act_dim, seed, device=device, rank=rank)
+    env = DeviceSummarize(env, env_id) if summarize else env  # raw rewards, like mujoco_wrap
     return Normalize(env) if normalize else env
   raise ValueError(f"unknown env id {env_id!r}: this build provides CartPole-v1 and synthetic "
                    f"stand-ins for {sorted(ATARI_ACTIONS)} / {sorted(MUJOCO_DIMS)}")

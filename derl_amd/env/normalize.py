@@ -42,6 +42,8 @@ class Normalize:
     self._raw_rew = torch.empty(self.nenvs, dtype=torch.float32, device=self.device)
     self._workspace = torch.empty(256 * self.dim, **f64)  # partial moments per row block
 
+  rollout_done = None  # the runner's per-rollout hook stops here: inner statistics are per step
+
   @property
   def unwrapped(self):
     return self.env.unwrapped
@@ -76,6 +78,9 @@ class Normalize:
   def step(self, actions, out=None, rewards_out=None, resets_out=None):
     raw, rewards, resets, infos = self.env.step(actions, out=self._raw_obs, rewards_out=self._raw_rew,
                                                 resets_out=resets_out)
+    inner_stats = getattr(self.env, "rollout_done", None)
+    if inner_stats is not None:  # reward summaries see the RAW rewards (mujoco_wrap order)
+      inner_stats(rewards.reshape(1, -1), resets.reshape(1, -1))
     if rewards_out is None:
       rewards_out = torch.empty(self.nenvs, dtype=torch.float32, device=self.device)
     resets_u8 = resets.view(torch.uint8) if resets.dtype == torch.bool else resets

@@ -248,6 +248,9 @@ def _cnn_loss_forward_backward(model, policy, data, mode, cliprange, value_loss_
 def _cnn_policy_rollout_into(model, policy, env, buffers, horizon):
   """All `horizon` steps of the synthetic device env in one native call."""
   from .env.synthetic import SyntheticAtariEnv  # pylint: disable=import-outside-toplevel
+  from .env.summarize import DeviceSummarize  # pylint: disable=import-outside-toplevel
+  if isinstance(env, DeviceSummarize):  # statistics are taken from the buffers afterwards
+    env = env.env
   if not isinstance(env, SyntheticAtariEnv) or buffers["obs"].dtype != torch.uint8:
     return False
   nenvs = env.nenvs

@@ -93,6 +93,9 @@ class EnvRunner:
           infos=None, next_observations=buf["obs"][1:],
           state=dict(latest_observations=buf["obs"][T]))
       self.step_count += T * self.nenvs
+      hook = getattr(self.env, "rollout_done", None)
+      if hook is not None:  # env-side statistics over the whole rollout (DeviceSummarize)
+        hook(buf["rewards"], buf["resets"])
       yield interactions
       buf["obs"][0].copy_(buf["obs"][T])
 

@@ -121,6 +121,18 @@ int dx_normalize_step_f32(const float *obs, int N, int D, const float *rewards,
                           double gamma, double eps, int update_stats, float *obs_out, float *rew_out,
                           void *stream);
 
+/* Episode-reward statistics of a batched env over the T steps of a rollout -- replaces
+ * RewardSummarizer.step of derl/env/summarize.py:40-52 (and add_summaries :25-38) applied step
+ * by step.  rewards (T, N) f32, resets (T, N) bytes.  State (device, updated in place): acc, ep_len
+ * (N) f64; ended (N) bytes; queue (N, Q) f64 ring with qlen / qpos (N) int32; step_count (1) int64.
+ * With record != 0, every step after which all envs have finished an episode since the last
+ * summary appends a row {total_reward, episode_length, min_reward, max_reward, reward_mean_Q,
+ * step_count} to rows (max_rows, 6) and increments *nrows (clamped to max_rows). */
+int dx_reward_summary_f32(const float *rewards, const uint8_t *resets, int T, int N, int Q, int record,
+                          double *acc, double *ep_len, uint8_t *ended, double *queue, int *qlen,
+                          int *qpos, long long *step_count, double *rows, int max_rows, int *nrows,
+                          void *stream);
+
 /* ---------------------------------------------------------------------------------
  * Categorical head -- replaces the distribution part of derl/policies.py:61-80
  * (ActorCriticPolicy.act with torch Categorical) and derl/alg/ppo.py:24-108 (PPOLoss) /
