@@ -143,18 +143,45 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
     out[o] = v;
   };
   if (!om.enabled && m0 + BM <= a.M && n0 + BN <= a.N) {
-    // interior tile (uniform): no per-element guards -- each guard is an exec-mask branch
+    // Interior tile (uniform): no per-element guards (each is an exec-mask branch), and every
+    // load of the epilogue is issued before the first store -- the compiler must assume the
+    // stores alias bias / mask_src, so a load placed after a store waits for vmcnt(0) each time
+    // (32 serialised round trips per workgroup otherwise).
+    constexpr bool kBias = EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH;
+    constexpr bool kAux = EPI == EPI_MASK || EPI == EPI_DTANH;
+    float bias_n[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + 32 * j + (lane & 31);
+      bias_n[j] = (kBias && (a.ksplit == 1 || blockIdx.z == 0)) ? a.bias[n] : 0.f;
+    }
+    const long long row0 = static_cast<long long>(m0 + wm0 + 4 * (lane >> 5)) * a.ldc + n0 + wn0 + (lane & 31);
+    float aux[kAux ? TM : 1][kAux ? 16 : 1][kAux ? TN : 1];
+    if (kAux && a.ksplit == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            aux[kAux ? i : 0][kAux ? r : 0][kAux ? j : 0] =
+                a.mask_src[row0 + static_cast<long long>(32 * i + (r & 3) + 8 * (r >> 2)) * a.ldc + 32 * j];
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long row = static_cast<long long>(m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * a.ldc;
+      for (int r = 0; r < 16; ++r)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int n = n0 + wn0 + 32 * j + (lane & 31);
-          finish(acc[i][j][r], row + n, n);
+          float v = acc[i][j][r] + bias_n[j];
+          if (a.ksplit == 1) {
+            if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+            if (EPI == EPI_BIAS_TANH) v = tanhf(v);
+            if (EPI == EPI_MASK) v = aux[kAux ? i : 0][kAux ? r : 0][kAux ? j : 0] > 0.f ? v : 0.f;
+            if (EPI == EPI_DTANH) { const float y = aux[kAux ? i : 0][kAux ? r : 0][kAux ? j : 0]; v *= 1.f - y * y; }
+          }
+          out[row0 + static_cast<long long>(32 * i + (r & 3) + 8 * (r >> 2)) * a.ldc + 32 * j] = v;
         }
-      }
     return;
   }
   // per column sub-tile: pixel-group offsets of the output map (uniform per j: scalar division
@@ -305,11 +332,29 @@ __global__ __launch_bounds__(256) void igemm_nt_small_kernel(const NTArgs a) {
     }
     out[o] = v;
   };
-  if (m0 + BM <= a.M && n0 + BN <= a.N) {  // interior tile (uniform): no per-element exec branches
+  if (m0 + BM <= a.M && n0 + BN <= a.N) {
+    // interior tile (uniform): no per-element exec branches; bias / mask loads before the stores
+    // (see igemm_nt_kernel)
+    constexpr bool kBias = EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_TANH;
+    constexpr bool kAux = EPI == EPI_MASK || EPI == EPI_DTANH;
+    const float bias_v = (kBias && (a.ksplit == 1 || blockIdx.z == 0)) ? a.bias[n] : 0.f;
+    const long long row0 = static_cast<long long>(m0 + wm0 + 4 * (lane >> 5)) * a.ldc + n;
+    float aux[kAux ? 16 : 1];
+    if (kAux && a.ksplit == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        aux[kAux ? r : 0] = a.mask_src[row0 + static_cast<long long>((r & 3) + 8 * (r >> 2)) * a.ldc];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      finish(acc[r], static_cast<long long>(m) * a.ldc + n);
+      float v = acc[r] + bias_v;
+      if (a.ksplit == 1) {
+        if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+        if (EPI == EPI_BIAS_TANH) v = tanhf(v);
+        if (EPI == EPI_MASK) v = aux[kAux ? r : 0] > 0.f ? v : 0.f;
+        if (EPI == EPI_DTANH) { const float y = aux[kAux ? r : 0]; v *= 1.f - y * y; }
+      }
+      out[row0 + static_cast<long long>((r & 3) + 8 * (r >> 2)) * a.ldc] = v;
     }
     return;
   }

@@ -113,6 +113,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_nt_lat_kernel(const NTArgs a) {
   if (wave >= 4) return;
   float *out = a.out + (a.ksplit > 1 ? blockIdx.z * a.slab_stride : 0);
   const int nn = blockIdx.y * 32 + r;
+  // one bias load before the stores (a load after a store waits for it: possible alias);
+  // split-K partials: the bias rides on slab 0
+  const bool has_bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && (a.ksplit == 1 || blockIdx.z == 0);
+  const float bias_v = has_bias && nn < a.N ? a.bias[nn] : 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int i = 4 * wave + t;
@@ -121,12 +125,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_nt_lat_kernel(const NTArgs a) {
     for (int w = 1; w < NW; ++w) v += red[(w * 16 + i) * 64 + lane];
     const int mm = blockIdx.x * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
     if (mm >= a.M || nn >= a.N) continue;
-    if (a.ksplit == 1) {
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) v += a.bias[nn];
-      if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
-    } else if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && blockIdx.z == 0) {
-      v += a.bias[nn];  // split-K partials: the bias rides on slab 0
-    }
+    v += bias_v;
+    if (a.ksplit == 1 && EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
     out[static_cast<long long>(mm) * a.ldc + nn] = v;
   }
 }

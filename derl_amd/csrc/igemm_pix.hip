@@ -138,21 +138,36 @@ __global__ __launch_bounds__(256) void igemm_nt_pix_kernel(const NTArgs a, int n
     }
     if (!inside) continue;  // uniform
     const bool full = (grp + 1) * BM <= nimg;  // uniform: all but the last image group
+    if (full) {
+      // no per-element exec-mask branches, and all ReLU-mask loads are in flight before the first
+      // store (stores may alias mask_src for the compiler: a load after a store waits vmcnt(0))
+      float mk[TM][16];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int img = grp * BM + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          mk[i][r] = EPI == EPI_MASK ? a.mask_src[img * imgo + pixo + col] : 1.f;
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int img = grp * BM + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          a.out[img * imgo + pixo + col] = mk[i][r] > 0.f ? acc[i][j][r] : 0.f;
+        }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int img = grp * BM + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (img >= nimg) continue;
         const long long o = img * imgo + pixo + col;
-        if (full) {  // no per-element exec-mask branch
-          float v = acc[i][j][r];
-          if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
-          a.out[o] = v;
-        } else if (img < nimg) {
-          float v = acc[i][j][r];
-          if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
-          a.out[o] = v;
-        }
+        float v = acc[i][j][r];
+        if (EPI == EPI_MASK) v = a.mask_src[o] > 0.f ? v : 0.f;
+        a.out[o] = v;
       }
   }
 }
