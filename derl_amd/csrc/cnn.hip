@@ -211,8 +211,7 @@ int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
   add(w + c->off_w[0], pk + c->pk_c0f, kC0 * 64LL * IC0, 8, 8, IC0, IC0 * 64LL, 8, 1, 64, 0);
   add(w + c->off_w[1], pk + c->pk_c1f, kC1 * 16LL * kC0, 4, 4, kC0, kC0 * 16LL, 4, 1, 16, 0);
   add(w + c->off_w[2], pk + c->pk_c2f, kC2 * 9LL * kC1, 3, 3, kC1, kC1 * 9LL, 3, 1, 9, 0);
-  // linear: dst [n][p][c] <- [n][c*P + p]
-  add(w + c->off_w[3], pk + c->pk_fcf, static_cast<long long>(kHid) * flat, P, kC2, 1, flat, 1, P, 0, 0);
+  // linear layer: launch_fc_pack below (dst [n][p][c] <- [n][c*P + p], and its transpose)
   // heads: rows 0..A-1 policy logits, row A value
   add(w + c->off_w[4], pk + c->pk_hdf, static_cast<long long>(A) * kHid, 1, 1, kHid, kHid, 0, 0, 1, 0);
   add(w + c->off_w[5], pk + c->pk_hdf + static_cast<long long>(A) * kHid, kHid, 1, 1, kHid, kHid, 0, 0, 1, 0);
@@ -224,14 +223,13 @@ int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
         (p >> 1) * 4 + (p & 1));
   // conv2 dgrad: dst [ic][kh][kw][oc]
   add(w + c->off_w[2], pk + c->pk_c2d, kC1 * 9LL * kC2, 3, 3, kC2, 9, 3, 1, kC1 * 9LL, 0);
-  // linear dgrad: dst [p][c][n] <- [n][c*P + p]
-  add(w + c->off_w[3], pk + c->pk_fcd, static_cast<long long>(flat) * kHid, kC2, kHid, 1, 1, P, flat, 0, 0);
   // heads dgrad: dst [k][32] <- heads [j][k] (scatter: the source rows are the contiguous side)
   add(w + c->off_w[4], pk + c->pk_hdd, static_cast<long long>(A) * kHid, kHid, 1, 1, 1, kHeadLd, 0, 0, 0);
   j[n - 1].scatter = 1;
   add(w + c->off_w[5], pk + c->pk_hdd + A, kHid, kHid, 1, 1, 1, kHeadLd, 0, 0, 0);
   j[n - 1].scatter = 1;
   if (int rc = launch_permute_reduce(j, n, s)) return rc;
+  if (int rc = launch_fc_pack(w + c->off_w[3], pk + c->pk_fcf, pk + c->pk_fcd, kHid, P, kC2, s)) return rc;
   // bf16 planes (second launch: reads the mirrors packed above): conv0 for the rollout kernel,
   // the other NT mirrors only for the opt-in bf16-split GEMMs
   const long long wsz0 = kC0 * 64LL * IC0, wsz1 = kC1 * 16LL * kC0, wsz2 = kC2 * 9LL * kC1,
@@ -323,13 +321,15 @@ static int finalize_grads(const dx_cnn_ctx *c, const Plan &plan, int which, hipS
     addb(L_C2, c->off_b[2], kC2, 0, kC2);
   }
   if (which & 2) {
-    // linear: slab [n][p][c] -> canonical [n][c*P + p]
-    addw(L_FC, c->off_w[3], static_cast<long long>(kHid) * flat, P, kC2, 1, flat, 1, P, 0, 0, kHid, flat, 1);
+    // linear weight: launch_fc_grad_finalize below (slab [n][p][c] -> canonical [n][c*P + p])
     addw(L_HD, c->off_w[4], static_cast<long long>(A) * kHid, kHid, 1, 1, kHid, 1, 0, 0, 0, kHeadLd, kHid, 0);
     addw(L_HD, c->off_w[5], kHid, kHid, 1, 1, kHid, 1, 0, 0, static_cast<long long>(A) * kHid, kHeadLd, kHid, 0);
     addb(L_FC, c->off_b[3], kHid, 0, kHid);
     addb(L_HD, c->off_b[4], A, 0, kHeadLd);
     addb(L_HD, c->off_b[5], 1, A, kHeadLd);
+    if (int rc = launch_fc_grad_finalize(c->slabs + plan.s[L_FC].w_off, plan.s[L_FC].msplit,
+                                         static_cast<long long>(kHid) * flat, g + c->off_w[3], kHid, P, kC2, s))
+      return rc;
   }
   return launch_permute_reduce(j, n, s);
 }

@@ -515,42 +515,45 @@ __global__ __launch_bounds__(64 * (BN / WN) * (BKO / WK)) void igemm_tn_kernel(c
 // ------------------------------------------------------------------------------------
 struct JobTable {
   PermuteJob jobs[kMaxJobs];
+  int chunk_begin[kMaxJobs + 1];  // prefix sums of the 64-element chunks per job
+  int njobs;
 };
 
-// A workgroup owns 64 consecutive elements of the contiguous side; its 4 waves split the slabs (wave g sums
-// slabs z = g, g+4, ...) with the 64 lanes on consecutive elements, so every slab read is one
-// coalesced 256-B row when the source is contiguous along the fastest output dimension (all
-// finalize jobs), and the waves combine through LDS.  Loads are issued 8 deep.
+// One workgroup per 64 consecutive elements of the contiguous side of ONE job (the grid is the
+// concatenation of all jobs' chunks: no empty workgroups, no loop -- a second chunk's loads
+// would sit behind the first chunk's store, and vmcnt counts stores).  Its 4 waves split the
+// slabs (wave g sums slabs z = g, g+4, ...) with the 64 lanes on consecutive elements, so every
+// slab read is one coalesced 256-B row when the source is contiguous along the fastest output
+// dimension (all finalize jobs); the waves combine through LDS.  Loads are issued 8 deep.
 __global__ __launch_bounds__(256) void permute_reduce_kernel(const JobTable t) {
   __shared__ float red[4][64];
-  const PermuteJob &j = t.jobs[blockIdx.y];
+  int job = 0;
+  const int b = blockIdx.x;
+  while (job + 1 < t.njobs && b >= t.chunk_begin[job + 1]) ++job;  // uniform, <= kMaxJobs steps
+  const PermuteJob &j = t.jobs[job];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long long nchunks = (j.total + 63) / 64;
-  for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    const long long i = c * 64 + lane;
-    const bool active = i < j.total;
-    long long rest = active ? i : 0;
-    const long long d3 = rest % j.D3; rest /= j.D3;
-    const long long d2 = rest % j.D2; rest /= j.D2;
-    const long long d1 = rest % j.D1; rest /= j.D1;
-    const long long strided = rest * j.s0 + d1 * j.s1 + d2 * j.s2 + d3 * j.s3;
-    const float *src = j.src + j.off + (j.scatter ? (active ? i : 0) : strided);
-    float v = 0.f;
-    int z = g;
-    for (; z + 28 < j.nslab; z += 32) {  // 8 loads in flight
-      float x[8];
+  const long long i = static_cast<long long>(b - t.chunk_begin[job]) * 64 + lane;
+  const bool active = i < j.total;
+  long long rest = active ? i : 0;
+  const long long d3 = rest % j.D3; rest /= j.D3;
+  const long long d2 = rest % j.D2; rest /= j.D2;
+  const long long d1 = rest % j.D1; rest /= j.D1;
+  const long long strided = rest * j.s0 + d1 * j.s1 + d2 * j.s2 + d3 * j.s3;
+  const float *src = j.src + j.off + (j.scatter ? (active ? i : 0) : strided);
+  float v = 0.f;
+  int z = g;
+  for (; z + 28 < j.nslab; z += 32) {  // 8 loads in flight
+    float x[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = src[(z + 4 * u) * j.slab_stride];
+    for (int u = 0; u < 8; ++u) x[u] = src[(z + 4 * u) * j.slab_stride];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v += x[u];
-    }
-    for (; z < j.nslab; z += 4) v += src[z * j.slab_stride];
-    __syncthreads();  // previous chunk's reads of `red` are done
-    red[g][lane] = v;
-    __syncthreads();
-    if (g == 0 && active)
-      j.dst[j.scatter ? strided : i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    for (int u = 0; u < 8; ++u) v += x[u];
   }
+  for (; z < j.nslab; z += 4) v += src[z * j.slab_stride];
+  red[g][lane] = v;
+  __syncthreads();
+  if (g == 0 && active)
+    j.dst[j.scatter ? strided : i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 template <int TAG, int BM, int BN, int WM, int WN, bool AU8, int EPI, int BK = 32>
@@ -697,22 +700,104 @@ int launch_tn(const TNArgs &a, bool a_u8, int stage, hipStream_t stream) {
   }
 }
 
+namespace {
+
+// Packing of the 3136-wide linear layer (95 % of the parameters) with coalesced traffic on both
+// sides.  fcf[n][p*C + c] = W[n][c*P + p] (the reference flattens NCHW, activations here are
+// NHWC): one workgroup per row n stages the row in LDS and writes it permuted.
+__global__ __launch_bounds__(256) void fc_row_permute_kernel(const float *__restrict__ W, float *__restrict__ out,
+                                                            int P, int C) {
+  extern __shared__ float row[];
+  const int K = P * C;
+  const float *src = W + static_cast<long long>(blockIdx.x) * K;
+  float *dst = out + static_cast<long long>(blockIdx.x) * K;
+  for (int i = threadIdx.x; i < K; i += 256) row[i] = src[i];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const int p = k / C, c = k - p * C;
+    dst[k] = row[c * P + p];
+  }
+}
+
+// The inverse for the weight gradient: canonical dW[n][c*P + p] = sum_z slab[z][n][p*C + c]; one
+// workgroup per row n sums the slabs with coalesced reads, permutes through LDS, coalesced write.
+__global__ __launch_bounds__(256) void fc_row_unpermute_reduce_kernel(const float *__restrict__ slab, int nslab,
+                                                                     long long slab_stride,
+                                                                     float *__restrict__ out, int P, int C) {
+  extern __shared__ float row[];
+  const int K = P * C;
+  const float *src = slab + static_cast<long long>(blockIdx.x) * K;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float v = 0.f;
+    for (int z = 0; z < nslab; ++z) v += src[z * slab_stride + k];
+    row[k] = v;
+  }
+  __syncthreads();
+  float *dst = out + static_cast<long long>(blockIdx.x) * K;
+  for (int i = threadIdx.x; i < K; i += 256) {
+    const int c = i / P, p = i - c * P;
+    dst[i] = row[p * C + c];
+  }
+}
+
+// out[k][n] = in[n][k] (in: R x Cn row-major), 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                       int R, int Cn) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ly + 4 * i, c = c0 + lx;
+    tile[ly + 4 * i][lx] = (r < R && c < Cn) ? in[static_cast<long long>(r) * Cn + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ly + 4 * i, r = r0 + lx;
+    if (r < R && c < Cn) out[static_cast<long long>(c) * R + r] = tile[lx][ly + 4 * i];
+  }
+}
+
+}  // namespace
+
+int launch_fc_grad_finalize(const float *slab, int nslab, long long slab_stride, float *grad, int N, int P,
+                            int C, hipStream_t stream) {
+  DX_REQUIRE(slab && grad && nslab >= 1 && N > 0 && P * C * 4 <= 64 * 1024, "fc_grad_finalize: bad arguments");
+  hipLaunchKernelGGL(fc_row_unpermute_reduce_kernel, dim3(N), dim3(256), sizeof(float) * P * C, stream, slab,
+                     nslab, slab_stride, grad, P, C);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+// fcf [N][P*C] (k = p*C + c) and its transpose fcd [P*C][N] from the canonical W [N][C*P]
+int launch_fc_pack(const float *W, float *fcf, float *fcd, int N, int P, int C, hipStream_t stream) {
+  DX_REQUIRE(W && fcf && fcd && N > 0 && P > 0 && C > 0 && P * C * 4 <= 64 * 1024, "fc_pack: bad arguments");
+  hipLaunchKernelGGL(fc_row_permute_kernel, dim3(N), dim3(256), sizeof(float) * P * C, stream, W, fcf, P, C);
+  DX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(P * C, 64), cdiv(N, 64)), dim3(256), 0, stream, fcf, fcd, N,
+                     P * C);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
 int launch_permute_reduce(const PermuteJob *jobs, int njobs, hipStream_t stream) {
   DX_REQUIRE(njobs >= 0 && njobs <= kMaxJobs, "permute_reduce: %d jobs (max %d)", njobs, kMaxJobs);
   if (njobs == 0) return DX_OK;
   JobTable t;
-  long long biggest = 0;
+  long long chunks = 0;
   for (int i = 0; i < njobs; ++i) {
     DX_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].nslab >= 1 && jobs[i].D1 > 0 && jobs[i].D2 > 0 &&
-                   jobs[i].D3 > 0,
+                   jobs[i].D3 > 0 && jobs[i].total > 0,
                "permute_reduce: bad job %d", i);
     t.jobs[i] = jobs[i];
-    if (jobs[i].total > biggest) biggest = jobs[i].total;
+    t.chunk_begin[i] = static_cast<int>(chunks);
+    chunks += (jobs[i].total + 63) / 64;
+    DX_REQUIRE(chunks < (1LL << 30), "permute_reduce: too many elements");
   }
-  int bx = cdiv(biggest, 64);
-  if (bx > 2048) bx = 2048;
-  if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(permute_reduce_kernel, dim3(bx, njobs), dim3(256), 0, stream, t);
+  t.chunk_begin[njobs] = static_cast<int>(chunks);
+  t.njobs = njobs;
+  hipLaunchKernelGGL(permute_reduce_kernel, dim3(static_cast<unsigned>(chunks)), dim3(256), 0, stream, t);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
