@@ -86,10 +86,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
   };
   fetch(kbeg);
 
-  const int abl = a.ablate;
   for (int kt = kbeg; kt < kend; kt += BK) {
-    if (abl < 3) __syncthreads();  // everyone finished reading the previous tile
-    if (abl < 2 || kt == kbeg) {
+    __syncthreads();  // everyone finished reading the previous tile
 #pragma unroll
     for (int p = 0; p < APASS; ++p)
       *reinterpret_cast<float4 *>(&As[(p * RPP + lr) * LD + 4 * l8]) =
@@ -98,9 +96,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void igemm_nt_kernel(co
     for (int p = 0; p < BPASS; ++p)
       if (p * RPP + lr < BN)
         *reinterpret_cast<float4 *>(&Bs[(p * RPP + lr) * LD + 4 * l8]) = masked(braw[p], wvalid[p]);
-    }
-    if (abl < 3) __syncthreads();
-    if (kt + BK < kend && abl < 1) {  // prefetch the next tile; its latency hides under the MFMAs
+    __syncthreads();
+    if (kt + BK < kend) {  // prefetch the next tile; its latency hides under the MFMAs
       q += BK;
       if (q >= g.seglen) { q = 0; ++seg; }
       fetch(kt + BK);
@@ -617,11 +614,6 @@ static int nt_big_min_m() {  // DX_NT_BIG_MIN_M: rows from which the N=64 stages
   if (v < 0) { const char *e = getenv("DX_NT_BIG_MIN_M"); v = e ? atoi(e) : 65536; }
   return v;
 }
-static int nt_ablate() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_ABLATE"); v = e ? atoi(e) : 0; }
-  return v;
-}
 // Small problems (rollout batches) are latency-bound: 64-deep K steps halve the number of
 // barrier / load round trips per tile.
 #define DX_NT_N64(ST, EPI)                                                                      \
@@ -632,7 +624,6 @@ static int nt_ablate() {
 
 int launch_nt(const NTArgs &a_in, bool a_u8, int epi, int stage, hipStream_t stream) {
   NTArgs a = a_in;
-  a.ablate = nt_ablate();
   DX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "igemm_nt: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   DX_REQUIRE(a.g.seglen % 32 == 0 && a.g.nseg * a.g.seglen == a.K && a.g.nseg <= kMaxSeg,
              "igemm_nt: K=%d must be nseg(%d) x seglen(%d), seglen %% 32 == 0", a.K, a.g.nseg,
@@ -649,7 +640,7 @@ int launch_nt(const NTArgs &a_in, bool a_u8, int epi, int stage, hipStream_t str
     const int rc = launch_nt_lat(a, a_u8, epi, stage, stream);
     if (rc != DX_ENOSUP) return rc;
   }
-  if (split_bf16() && !a_u8 && a.M >= split_min_m() && a.ablate == 0) {
+  if (split_bf16() && !a_u8 && a.M >= split_min_m()) {
     const int rc = launch_nt_b3(a, epi, stage, stream);
     if (rc != DX_ENOSUP) return rc;
   }

@@ -78,7 +78,6 @@ struct NTArgs {
   int M, N, K;
   int ksplit;             // > 1: raw partial sums into slabs out + z*slab_stride
   long long slab_stride;
-  int ablate;             // timing experiments only (DX_ABLATE): 1 no global loads in the loop, 2 also no LDS writes, 3 also no barriers
 };
 
 // slab[z][n][k] = sum_{m in slice z} G[m][n] * A(m,k);  bias_slab[z][n] = sum_m G[m][n]

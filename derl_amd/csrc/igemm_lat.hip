@@ -161,7 +161,7 @@ int lat_max_tiles(int stage) {
 int launch_nt_lat(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream) {
   const Gather &g = a.g;
   const long long tiles = static_cast<long long>(cdiv(a.M, 32)) * cdiv(a.N, 32) * a.ksplit;
-  if (tiles > lat_max_tiles(stage) || g.check || a.om.enabled || a.ablate) return DX_ENOSUP;
+  if (tiles > lat_max_tiles(stage) || g.check || a.om.enabled) return DX_ENOSUP;
   for (int s = 1; s < g.nseg; ++s)
     if (g.seg_off[s] != s * g.seg_off[1]) return DX_ENOSUP;
   const int kper = a.K / a.ksplit;

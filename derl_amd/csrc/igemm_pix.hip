@@ -193,7 +193,7 @@ bool pix_enabled() {  // DX_DGRAD_PIX=0: dgrads on the generic kernel (zero taps
 // nimg images of g.OHW gathered pixels each (a.M == nimg * g.OHW).  DX_ENOSUP = not covered.
 int launch_nt_pix(const NTArgs &a, int nimg, int epi, int stage, hipStream_t stream) {
   const Gather &g = a.g;
-  if (!pix_enabled() || a.ablate) return DX_ENOSUP;
+  if (!pix_enabled()) return DX_ENOSUP;
   if (epi != EPI_MASK || a.ksplit != 1 || g.idx || g.seglen % 32 || g.nseg > kMaxSeg || nimg < 64) return DX_ENOSUP;
   if (static_cast<long long>(nimg) * g.OHW != a.M) return DX_ENOSUP;
   if (a.om.enabled && (a.om.OHW != g.OHW || a.om.OW != g.OW || a.om.chan % 32)) return DX_ENOSUP;
