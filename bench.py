@@ -37,6 +37,19 @@ BF16X3_STAGES = ("conv0_fwd", "conv0_wgrad")
 PEAK_HBM_GBPS = 8000.0
 
 
+def pmc_traffic(stage, minibatch):
+  """HBM bytes per launch of `stage` from the committed PMC passes (profiles/r01_pmc_traffic.json:
+  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide
+  prescribes).  Counters cannot be read from inside this process, so the figure is the one measured
+  at minibatch 8192 and only reported for that shape; otherwise null."""
+  path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+  if minibatch != 8192 or not os.path.exists(path):
+    return None
+  with open(path) as f:
+    entry = json.load(f)["stages"].get(stage)
+  return entry["hbm_bytes"] if entry else None
+
+
 def stage_flops(name, batch, num_actions):
   layer = name.split("_")[0]
   if layer == "heads":
@@ -227,7 +240,7 @@ def main():
     result["roofline"] = {
         "bound": "mfma", "kernel": f"{dominant} (minibatch {mb})",
         "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(tf / peak, 4), "traffic": None,
+        "frac": round(tf / peak, 4), "traffic": pmc_traffic(dominant, mb),
         "network_fwd_bwd": {"us": round(total_us, 1),
                             "achieved": round(total_flops / (total_us * 1e-6) / 1e12, 2),
                             "frac": round(total_flops / (total_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
