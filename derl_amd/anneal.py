@@ -1,6 +1,14 @@
-"""Annealing variables (derl/anneal.py:14-86).  ``LinearAnneal.step_to`` uses the closed
-form of the reference's per-step loop -- bit-equal (float32 of the float64 expression,
-clamped), without 32,768 Python iterations per rollout."""
+"""Schedules that move a 0-dim tensor as training progresses -- the contract of derl/anneal.py
+(``AnnealingVariable``: ``get_tensor`` / ``step`` / ``step_to`` / ``summarize``;
+``LinearAnneal(start, nsteps, end=0.)``).
+
+The tensor object is created once and mutated in place, so an optimizer that was given
+``schedule.get_tensor()`` as its learning rate follows the schedule.  ``LinearAnneal.step_to`` jumps
+straight to the target: the reference walks there one ``step()`` at a time (32,768 iterations per
+rollout at the headline config) and only the last assignment survives; the value is the same
+float32 rounding of the same float64 expression, so the jump is bit-equal (checked in
+tests/test_host_logic.py against the recorded reference values).
+"""
 import re
 from abc import ABC, abstractmethod
 
@@ -8,34 +16,39 @@ import torch
 
 from . import summary
 
+_WORD_STARTS = re.compile(r"(?<=[a-z0-9])(?=[A-Z])|(?<=[A-Z])(?=[A-Z][a-z])")
+
 
 def camel2snake(string):
-  sub = re.sub('(.)([A-Z][a-z]+)', r'\1_\2', string)
-  return re.sub('([a-z0-9])([A-Z])', r'\1_\2', sub).lower()
+  """``LinearAnneal`` -> ``linear_anneal`` (default names of the variables)."""
+  return _WORD_STARTS.sub("_", string).lower()
 
 
 class AnnealingVariable(ABC):
-  """Variable the value of which changes after each step (anneal.py:14-43)."""
+  """A value that depends on how many steps have been taken."""
   def __init__(self, name=None):
-    self.name = name or camel2snake(self.__class__.__name__)
+    self.name = camel2snake(type(self).__name__) if name is None else name
     self.step_count = 0
 
   @abstractmethod
   def get_tensor(self):
-    """Returns the torch.Tensor that changes after each call to step."""
+    """The tensor whose value follows the schedule (always the same object)."""
+
+  @abstractmethod
+  def step(self):
+    """Advances the schedule by one step."""
 
   def get_current_value(self):
     return self.get_tensor().clone()
 
-  @abstractmethod
-  def step(self):
-    """Updates the value of the variable."""
+  def _check_forward(self, target):
+    if target < self.step_count:
+      raise ValueError(f"val={target} cannot be smaller than self.step_count={self.step_count}")
 
   def step_to(self, val):
-    if val < self.step_count:
-      raise ValueError(f"val={val} cannot be smaller than "
-                       f"self.step_count={self.step_count}")
-    for _ in range(val - self.step_count):
+    """Advances to step ``val`` (schedules never run backwards)."""
+    self._check_forward(val)
+    while self.step_count < val:
       self.step()
 
   def summarize(self, global_step):
@@ -43,31 +56,27 @@ class AnnealingVariable(ABC):
 
 
 class LinearAnneal(AnnealingVariable):
-  """Linearly annealing variable (anneal.py:65-86)."""
+  """``start`` -> ``end`` over ``nsteps`` steps, clamped to that interval afterwards."""
   def __init__(self, start, nsteps, end=0., name=None):
     super().__init__(name)
-    self.start = start
-    self.nsteps = nsteps
-    self.end = end
-    self.tensor = torch.tensor(self.start)  # 0-dim float32 on the host, like the reference
+    self.start, self.end, self.nsteps = start, end, nsteps
+    self.tensor = torch.tensor(start)  # host, float32 for a Python float: as in the reference
+    self._low, self._high = min(start, end), max(start, end)
 
   def get_tensor(self):
     return self.tensor
 
-  def _value_at(self, step_count):
-    step_frac = step_count / self.nsteps
-    return torch.clamp(torch.tensor(self.start + (self.end - self.start) * step_frac),
-                       min(self.start, self.end), max(self.start, self.end))
+  def _assign(self, step_count):
+    progress = step_count / self.nsteps
+    value = torch.tensor(self.start + (self.end - self.start) * progress)  # f64 math, f32 tensor
+    self.step_count = step_count
+    self.tensor.data = torch.clamp(value, self._low, self._high)
 
   def step(self):
-    self.step_count += 1
-    self.tensor.data = self._value_at(self.step_count)
+    self._assign(self.step_count + 1)
     return self.get_current_value()
 
   def step_to(self, val):
-    if val < self.step_count:
-      raise ValueError(f"val={val} cannot be smaller than "
-                       f"self.step_count={self.step_count}")
-    if val > self.step_count:  # the loop's last iteration is all that survives
-      self.step_count = val
-      self.tensor.data = self._value_at(val)
+    self._check_forward(val)
+    if val != self.step_count:
+      self._assign(val)
