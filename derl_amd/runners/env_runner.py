@@ -100,35 +100,37 @@ class EnvRunner:
       buf["obs"][0].copy_(buf["obs"][T])
 
   # ---- generic rollout (reference contract) -------------------------------------------
+  def _start_episode(self):
+    self.episode_length = 0
+    return self.env.reset()
+
   def _run_generic(self, obs):
+    """Per-key Python lists of length ``horizon``, exactly the dict derl's runner yields
+    (env_runner.py:42-57): every key ``policy.act`` returns, plus observations / rewards /
+    resets / infos / next_observations and ``state.latest_observations``."""
+    single = self.nenvs is None  # an unbatched env must be reset by the runner
     if obs is None:
-      obs = self.env.reset()
-      self.episode_length = 0
+      obs = self._start_episode()
     while not self.is_exhausted():
-      interactions = defaultdict(list)
+      record = defaultdict(list)
       for _ in range(self.horizon):
-        act = self.policy.act(obs)
-        interactions["observations"].append(obs)
-        if "actions" not in act:
+        decision = self.policy.act(obs)
+        if "actions" not in decision:
           raise ValueError("result of policy.act must contain 'actions' "
-                           f"but has keys {list(act.keys())}")
-        for key, val in act.items():
-          interactions[key].append(val)
-        new_obs, rew, done, info = self.env.step(act["actions"])
+                           f"but has keys {list(decision.keys())}")
+        record["observations"].append(obs)
+        for key, val in decision.items():
+          record[key].append(val)
+        obs, reward, done, info = self.env.step(decision["actions"])
         self.episode_length += 1
-        interactions["rewards"].append(rew)
-        interactions["resets"].append(done)
-        interactions["infos"].append(info)
-        interactions["next_observations"].append(new_obs)
-        if self.nenvs is None and (
-            done or self.episode_length == self.time_limit):
-          obs = self.env.reset()
-          self.episode_length = 0
-        else:
-          obs = new_obs
-      interactions["state"] = dict(latest_observations=obs)
-      self.step_count += self.horizon * (self.nenvs or 1)
-      yield dict(interactions)
+        for key, val in (("rewards", reward), ("resets", done), ("infos", info),
+                         ("next_observations", obs)):
+          record[key].append(val)
+        if single and (done or self.episode_length == self.time_limit):
+          obs = self._start_episode()
+      record["state"] = dict(latest_observations=obs)
+      self.step_count += self.horizon * (1 if single else self.nenvs)
+      yield dict(record)
 
 
 class RunnerWrapper(ABC):
