@@ -11,6 +11,7 @@ that ``HostEnvBridge`` (bridge.py) can DMA them into the rollout buffer in HBM.
 Works with any env object that has ``reset()``, ``step(action)``, ``observation_space`` and
 ``action_space`` (gym is not required).
 """
+import gc
 import multiprocessing as mp
 from multiprocessing import shared_memory
 
@@ -121,6 +122,7 @@ class SingleEnvBatch(EnvBatch):
 
 def _worker(conn, make_env, index):
   """Env process: observations go to shared memory, the rest through the pipe."""
+  gc.freeze()  # never finalise anything inherited from the parent (see ParallelEnvBatch.__init__)
   env = make_env()
   conn.send((env.observation_space, env.action_space))
   name, nenvs, shape, dtype = conn.recv()
@@ -158,13 +160,22 @@ class ParallelEnvBatch(EnvBatch):
     self._nenvs = len(functions)
     ctx = mp.get_context("fork")  # env factories are usually closures
     self._conns, self._processes = [], []
-    for index, fn in enumerate(functions):
-      parent, child = ctx.Pipe()
-      proc = ctx.Process(target=_worker, args=(child, fn, index), daemon=True)
-      proc.start()
-      child.close()
-      self._conns.append(parent)
-      self._processes.append(proc)
+    # The parent may already hold device tensors.  A forked child must never run their
+    # finalisers (the HIP runtime is not usable after fork: a garbage-collection pass in the child
+    # that frees an inherited device tensor segfaults), so collect now, then park every live object
+    # in the permanent generation while forking; the children freeze again before doing anything.
+    gc.collect()
+    gc.freeze()
+    try:
+      for index, fn in enumerate(functions):
+        parent, child = ctx.Pipe()
+        proc = ctx.Process(target=_worker, args=(child, fn, index), daemon=True)
+        proc.start()
+        child.close()
+        self._conns.append(parent)
+        self._processes.append(proc)
+    finally:
+      gc.unfreeze()
     self._closed = False
     spaces = [conn.recv() for conn in self._conns]
     self.observation_space = SpaceBatch([s[0] for s in spaces])
