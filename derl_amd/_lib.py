@@ -136,8 +136,11 @@ def stream_ptr(device=None):
     # the raw getter is ~20x cheaper than building a torch.cuda.Stream object per call
     _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)  # pylint: disable=protected-access
   index = getattr(device, "index", device)
-  if _raw_stream and isinstance(index, int):
-    return c_void_p(_raw_stream(index))
+  if _raw_stream:
+    if index is None:  # torch.device("cuda"): the current device
+      index = torch.cuda.current_device()
+    if isinstance(index, int):
+      return c_void_p(_raw_stream(index))
   return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -57,6 +57,11 @@ class _MlpActorCritic(nn.Module):
     self._adopt_engine_storage()
     self._anchor = torch.zeros((), device=self.engine.device, requires_grad=True)
     self._loss_partials = None
+    self._dlogstd = None
+
+  def _logstd_data(self):
+    """The logstd parameter's storage without autograd bookkeeping (a view of the flat buffer)."""
+    return self.logstd.data
 
   def _adopt_engine_storage(self):
     pviews = self.engine.named_views(self.engine.params)
@@ -157,8 +162,12 @@ class _MlpActorCritic(nn.Module):
       need = 40 * ((batch + 255) // 256)
       if self._loss_partials is None or self._loss_partials.numel() < need:
         self._loss_partials = torch.empty(need, dtype=torch.float64, device=eng.device)
-      dlogstd = eng.named_views(eng.grads)["logstd"]
-      terms = ops.normal_loss(head, self.logstd.detach(), actions.to(torch.float32).contiguous(),
+      if self._dlogstd is None or self._dlogstd.data_ptr() != eng.grads.data_ptr() + 4 * eng.ctx.off_logstd:
+        self._dlogstd = eng.named_views(eng.grads)["logstd"]  # cached view of the gradient slice
+      dlogstd = self._dlogstd
+      actions_f32 = actions if (actions.dtype == torch.float32 and actions.is_contiguous()) \
+          else actions.to(torch.float32).contiguous()
+      terms = ops.normal_loss(head, self._logstd_data(), actions_f32,
                               old_log_prob, advantages, old_values, value_targets, mode, cliprange,
                               value_loss_coef, entropy_coef, dhead, dlogstd, global_batch,
                               self._loss_partials)
