@@ -157,15 +157,20 @@ __global__ __launch_bounds__(256) void conv0_wgrad_b16_kernel(const Conv0Args a)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rowB = a.in_w * 4;
   const int lcol = lane & 31, h = lane >> 5;
-  // this wave's two k tiles are kernel rows kh = 2*wave and 2*wave + 1; lane j -> byte j of the row
-  const int koff0 = (2 * wave) * rowB + lcol, koff1 = koff0 + rowB;
+  // Wave roles: kgrp = wave & 1 owns kernel rows 4*kgrp .. 4*kgrp+3 (128 k), mgrp = wave >> 1 owns
+  // pixels 128*mgrp .. +127 of every tile.  A lane reads one DWORD of an input row per pixel --
+  // lane j: row 4*kgrp + j/8, bytes 4*(j%8) .. +3 -- and byte t of it is this lane's operand of k
+  // tile t (k = 32*row + 4*(j%8) + t): one LDS read feeds four k tiles x three planes = 12 MFMAs
+  // (a byte per read fed 3), which is what this kernel was bound by.
+  const int kgrp = wave & 1, mgrp = wave >> 1;
+  const int koff = (4 * kgrp + (lcol >> 3)) * rowB + 4 * (lcol & 7);
   // staging role: thread -> (oc = tid & 31, 32 pixels mg*32 .. mg*32+31)
   const int soc = tid & 31, mg = tid >> 5;
-  f32x16 acc[2];
+  f32x16 acc[4];
 #pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t2][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bias_acc = 0.f;
   u32x4 pre[kPatchRegs];
   float gpre[32];
@@ -217,40 +222,51 @@ __global__ __launch_bounds__(256) void conv0_wgrad_b16_kernel(const Conv0Args a)
     }
     const uint8_t *gl = Gpl + lcol * kGRowB + 16 * h;
 #pragma unroll 2
-    for (int c = 0; c < kTile / 16; ++c) {  // 16 pixels per MFMA: lane half h takes pixels 16c + 8h .. +7
+    for (int cc = 0; cc < kTile / 32; ++cc) {  // 16 pixels per MFMA: lane half h takes pixels 16c + 8h .. +7
+      const int c = mgrp * (kTile / 32) + cc;
       const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(gl + c * 32);
       const bf16x8 am = *reinterpret_cast<const bf16x8 *>(gl + kGPlaneB + c * 32);
       const bf16x8 al = *reinterpret_cast<const bf16x8 *>(gl + 2 * kGPlaneB + c * 32);
-      float x0[8], x1[8];
+      uint32_t w[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int rb = rbtab[16 * c + 8 * h + e];
-        x0[e] = static_cast<float>(patch[rb + koff0]);
-        x1[e] = static_cast<float>(patch[rb + koff1]);
+      for (int e = 0; e < 8; ++e) w[e] = *reinterpret_cast<const uint32_t *>(patch + rbtab[16 * c + 8 * h + e] + koff);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = static_cast<float>((w[e] >> (8 * t)) & 0xff);
+        u32x4 b;
+        b.x = bytes_to_bf16x2(x[0], x[1]); b.y = bytes_to_bf16x2(x[2], x[3]);
+        b.z = bytes_to_bf16x2(x[4], x[5]); b.w = bytes_to_bf16x2(x[6], x[7]);
+        const bf16x8 bf = __builtin_bit_cast(bf16x8, b);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bf, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf, acc[t], 0, 0, 0);
       }
-      u32x4 b0, b1;
-      b0.x = bytes_to_bf16x2(x0[0], x0[1]); b0.y = bytes_to_bf16x2(x0[2], x0[3]);
-      b0.z = bytes_to_bf16x2(x0[4], x0[5]); b0.w = bytes_to_bf16x2(x0[6], x0[7]);
-      b1.x = bytes_to_bf16x2(x1[0], x1[1]); b1.y = bytes_to_bf16x2(x1[2], x1[3]);
-      b1.z = bytes_to_bf16x2(x1[4], x1[5]); b1.w = bytes_to_bf16x2(x1[6], x1[7]);
-      const bf16x8 bf0 = __builtin_bit_cast(bf16x8, b0), bf1 = __builtin_bit_cast(bf16x8, b1);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bf0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bf1, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf1, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf1, acc[1], 0, 0, 0);
     }
   }
+  // The two pixel halves meet in LDS (the dY planes are dead now), then
   // slab[block][oc][k]: rows = oc, cols = k; the input scale 1/255 is applied here
-  float *slab = a.slab + static_cast<long long>(blockIdx.x) * 32 * 256;
+  __syncthreads();
+  float *part = reinterpret_cast<float *>(smem);  // [kgrp][t][r][lane]
+  if (mgrp == 1) {
 #pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int oc = (r & 3) + 8 * (r >> 2) + 4 * h;
-      slab[oc * 256 + (2 * wave + t2) * 32 + lcol] = div255(acc[t2][r]);
-    }
+      for (int r = 0; r < 16; ++r) part[((kgrp * 4 + t) * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (mgrp == 0) {
+    float *slab = a.slab + static_cast<long long>(blockIdx.x) * 32 * 256;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int k = (4 * kgrp + (lcol >> 3)) * 32 + 4 * (lcol & 7) + t;
+        slab[oc * 256 + k] = div255(acc[t][r] + part[((kgrp * 4 + t) * 16 + r) * 64 + lane]);
+      }
+  }
   if (a.bias_slab) {
     __syncthreads();
     red[mg * 32 + soc] = bias_acc;
