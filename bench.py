@@ -182,9 +182,11 @@ def main():
       "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
       "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
       "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-      "config": {"workload": "PPO BreakoutNoFrameskip-v4 nenvs=256 nsteps=128 on 1xMI355X "
-                             "(BASELINE.json configs[1]): NatureCNN(A=4), 3 epochs x 4 minibatches, "
-                             "Adam, synthetic uint8 84x84x4 frames generated on the GPU",
+      "config": {"workload": f"PPO BreakoutNoFrameskip-v4 nenvs={nenvs_total} nsteps={args.nsteps} on "
+                             f"{world}xMI355X (BASELINE.json configs[1]"
+                             f"{', sharded one env shard per GPU' if world > 1 else ''}): NatureCNN(A=4), "
+                             "3 epochs x 4 minibatches, Adam, synthetic uint8 84x84x4 frames generated "
+                             "on the GPU",
                  "nenvs_total": nenvs_total, "nenvs_per_gpu": nenvs, "nsteps": args.nsteps,
                  "minibatch_per_gpu": nenvs * args.nsteps // kwargs["num_minibatches"],
                  "updates_per_step": updates_per_iter, "parallelism": f"dp{world}",
