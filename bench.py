@@ -197,6 +197,17 @@ def main():
                  "final_loss": float(alg.loss_fn.last_terms[0].item())},
   }
 
+  # whole-iteration MFMA roofline: one env step costs the rollout forward, 1/nsteps of
+  # the bootstrap forward and num_epochs x (forward + backward ~ 3 forwards) of the update
+  fwd_mflop = 2.0 * (sum(MACS.values()) + (env.action_space.n + 1) * 512) / 1e6
+  per_step_mflop = fwd_mflop * (1.0 + 1.0 / args.nsteps + 3.0 * kwargs["num_epochs"])
+  bound = PEAK_F32_MFMA_TFLOPS * 1e6 / per_step_mflop * world
+  result["iteration_roofline"] = {
+      "bound": "mfma", "algorithmic_mflop_per_env_step": round(per_step_mflop, 1),
+      "bound_env_steps_per_s": round(bound, 1), "frac": round(value / bound, 4),
+      "note": "fp32-MFMA peak x n_gpus / algorithmic flops per env step; the first conv layer runs on "
+              "bf16 MFMA, so this is a reference line, not a hard ceiling"}
+
   if rank == 0 and not args.no_roofline:
     model = alg.model
     A = model.engine.num_actions
