@@ -23,6 +23,7 @@ SIGNATURES = {
     "dx_device_info": [c_int, c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "dx_gae_f32": [P, P, P, P, c_int, c_int, c_float, c_float, P, P, P],
     "dx_adv_stats_f32": [P, c_longlong, P, P],
+    "dx_adv_stats_segments_f32": [P, P, c_longlong, c_longlong, P, P],
     "dx_adv_normalize_f32": [P, P, c_longlong, c_float, P, c_int, P],
     "dx_grad_sumsq_f32": [P, c_longlong, P, c_int, P],
     "dx_clip_adam_step_f32": [P, P, P, P, c_longlong, P, c_int, c_double, c_double, c_double,

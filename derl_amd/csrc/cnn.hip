@@ -45,13 +45,18 @@ bool conv0_f32() {  // DX_CONV0_F32=1: first layer on the fp32 matrix instructio
 int roundup(long long v, int m) { return static_cast<int>((v + m - 1) / m * m); }
 
 // reduction split of a wgrad over its M rows: ~5 workgroups per CU (2 per CU measured 41 %
-// MFMA utilisation: both resident waves of a SIMD wait at the same time), >= 256 rows each
-void pick_msplit(long long M, int blocks_kn, int *msplit, int *mper) {
+// MFMA utilisation: both resident waves of a SIMD wait at the same time), >= min_rows rows each
+// (256 for the layers whose slabs are big; 64 for the heads, whose few workgroups otherwise walk
+// 256 rows in 8 dependent steps: 22 us for 5 MFLOP)
+long long msplit_bound(long long M, int blocks_kn, int min_rows) {
   long long ms = 1280 / blocks_kn;
-  if (ms < 1) ms = 1;
-  long long cap = (M + 255) / 256;
+  const long long cap = (M + min_rows - 1) / min_rows;
   if (ms > cap) ms = cap;
-  if (ms < 1) ms = 1;
+  return ms < 1 ? 1 : ms;
+}
+
+void pick_msplit(long long M, int blocks_kn, int min_rows, int *msplit, int *mper) {
+  const long long ms = msplit_bound(M, blocks_kn, min_rows);
   *mper = roundup((M + ms - 1) / ms, 32);
   *msplit = static_cast<int>((M + *mper - 1) / *mper);
 }
@@ -106,18 +111,18 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
     int N, K, bkn;
     layer_nk(c, l, &N, &K, &bkn);
     // capacity (offsets) from max_batch, split from the actual batch
-    int ms_cap, mper_cap;
-    pick_msplit(layer_rows(c, l, c->max_batch), bkn, &ms_cap, &mper_cap);
-    pick_msplit(layer_rows(c, l, B), bkn, &p.s[l].msplit, &p.s[l].mper);
+    const int min_rows = l == L_HD ? 64 : 256;
+    const long long ms_cap = msplit_bound(layer_rows(c, l, c->max_batch), bkn, min_rows);
+    pick_msplit(layer_rows(c, l, B), bkn, min_rows, &p.s[l].msplit, &p.s[l].mper);
     if (l == L_C0) {  // one slab per persistent workgroup of the direct conv0 wgrad (<= 512)
       const long long tiles = (layer_rows(c, l, B) + 255) / 256;
       p.s[l].msplit = static_cast<int>(tiles < 512 ? tiles : 512);
       p.s[l].mper = roundup((layer_rows(c, l, B) + p.s[l].msplit - 1) / p.s[l].msplit, 32);
     }
     p.s[l].w_off = off;
-    off += static_cast<long long>(ms_cap) * N * K;
+    off += ms_cap * N * K;
     p.s[l].b_off = off;
-    off += static_cast<long long>(ms_cap) * N;
+    off += ms_cap * N;
     off = (off + 63) / 64 * 64;
   }
   p.total = off;

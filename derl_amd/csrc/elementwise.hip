@@ -48,6 +48,31 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float *x, long lo
   }
 }
 
+// The same statistics for every minibatch of a rollout at once: block s sums the elements
+// x[index[s*seglen ..]] (a minibatch is a contiguous slice of an epoch's composed permutation) in
+// the order adv_stats_kernel sums the gathered minibatch, so the doubles are bit-identical; a
+// sharded run then needs ONE small all-reduce per rollout instead of one per minibatch.
+__global__ __launch_bounds__(1024) void adv_stats_segments_kernel(const float *x, const int *index, long long n,
+                                                                  long long seglen, double *stats) {
+  __shared__ double scratch[16];
+  const long long begin = blockIdx.x * seglen;
+  const long long count = n - begin < seglen ? n - begin : seglen;
+  double s = 0.0, ss = 0.0;
+  for (long long i = threadIdx.x; i < count; i += blockDim.x) {
+    const double v = x[index ? index[begin + i] : begin + i];
+    s += v;
+    ss += v * v;
+  }
+  s = block_sum(s, scratch);
+  ss = block_sum(ss, scratch);
+  if (threadIdx.x == 0) {
+    double *o = stats + 3LL * blockIdx.x;
+    o[0] = s;
+    o[1] = ss;
+    o[2] = static_cast<double>(count);
+  }
+}
+
 // out = (x - mean) / (std + eps): population std from the float64 sums, applied in float32
 // exactly like the NumPy expression (float32 array ops with float32 scalars).
 __global__ __launch_bounds__(kThreads) void adv_apply_kernel(const float *x, float *out, long long n,
@@ -235,6 +260,17 @@ extern "C" int dx_adv_normalize_f32(const float *advantages, float *out, long lo
 extern "C" int dx_adv_stats_f32(const float *advantages, long long n, double *stats, void *stream) {
   DX_REQUIRE(n > 0 && advantages && stats, "dx_adv_stats_f32: bad argument");
   hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, dx::as_stream(stream), advantages, n, stats);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_adv_stats_segments_f32(const float *advantages, const int32_t *index, long long n,
+                                         long long seglen, double *stats, void *stream) {
+  DX_REQUIRE(n > 0 && seglen > 0 && advantages && stats, "dx_adv_stats_segments_f32: bad argument");
+  const long long nseg = (n + seglen - 1) / seglen;
+  DX_REQUIRE(nseg <= 65535, "dx_adv_stats_segments_f32: %lld segments (max 65535)", nseg);
+  hipLaunchKernelGGL(adv_stats_segments_kernel, dim3(static_cast<unsigned>(nseg)), dim3(1024), 0,
+                     dx::as_stream(stream), advantages, index, n, seglen, stats);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -39,10 +39,16 @@ int strided_pad(float *dst, long long R, int Cp, const float *src, int C, long l
   return DX_OK;
 }
 
-void msplit_for(long long M, int *msplit, int *mper) {
-  long long ms = (M + 255) / 256;
+// slices of >= 64 rows: the slabs are tiny (<= 16 KB per slice and layer) and the wgrads are
+// latency chains of 32-row steps on a handful of workgroups, so short slices win
+int msplit_bound(long long M) {  // slab capacity: >= the msplit of every batch <= M
+  long long ms = (M + 63) / 64;
   if (ms > 256) ms = 256;
-  if (ms < 1) ms = 1;
+  return static_cast<int>(ms < 1 ? 1 : ms);
+}
+
+void msplit_for(long long M, int *msplit, int *mper) {
+  const long long ms = msplit_bound(M);
   *mper = static_cast<int>(((M + ms - 1) / ms + 31) / 32 * 32);
   *msplit = static_cast<int>((M + *mper - 1) / *mper);
 }
@@ -100,8 +106,7 @@ int dx_mlp_init(dx_mlp_ctx *c) {
     c->pk_d1[net] = take(kH * kH);
   }
   c->packed_count = po;
-  int ms, mper;
-  msplit_for(c->max_batch, &ms, &mper);
+  const int ms = msplit_bound(c->max_batch);
   // per net: L0 [64][obs_pad]+[64], L1 [64][64]+[64], L2 [32][64]+[32]
   c->slab_per_net = static_cast<long long>(ms) * (kH * c->obs_pad + kH + kH * kH + kH + kHeadLd * kH + kHeadLd);
   c->slab_count = 2 * c->slab_per_net;
@@ -170,9 +175,9 @@ int dx_mlp_backward(const dx_mlp_ctx *c, int B, void *stream) {
   if (int rc = check_mlp(c, "dx_mlp_backward", B, true)) return rc;
   hipStream_t s = as_stream(stream);
   const int D = c->obs_dim, P = c->policy_out, Dp = c->obs_pad;
-  int ms, mper, ms_cap, mper_cap;
+  int ms, mper;
   msplit_for(B, &ms, &mper);
-  msplit_for(c->max_batch, &ms_cap, &mper_cap);
+  const int ms_cap = msplit_bound(c->max_batch);
   PermuteJob jobs[kMaxJobs];
   int nj = 0;
   for (int net = 0; net < 2; ++net) {

@@ -71,6 +71,21 @@ def adv_stats(advantages, stats=None):
   return stats
 
 
+def adv_stats_segments(advantages, index, seglen, stats=None):
+  """{sum, sumsq, count} of every ``seglen``-long slice of ``advantages[index]`` (the minibatches
+  of one epoch; ``index`` int32 or None) -> float64 (ceil(n / seglen), 3)."""
+  _dev(advantages, "advantages", torch.float32)
+  n = advantages.numel() if index is None else index.numel()
+  nseg = -(-n // seglen)
+  if index is not None:
+    _dev(index, "index", torch.int32)
+  if stats is None:
+    stats = torch.empty((nseg, 3), dtype=torch.float64, device=advantages.device)
+  _lib.call("dx_adv_stats_segments_f32", _lib.ptr(advantages), _lib.ptr(index) if index is not None else None,
+            n, seglen, _lib.ptr(stats), _lib.stream_ptr(advantages.device))
+  return stats
+
+
 NORM_PARTIALS = 256
 
 

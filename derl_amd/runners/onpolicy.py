@@ -52,11 +52,15 @@ class IterateWithMinibatches(RunnerWrapper):
   yielded as ``GatheredRows(base, index)`` and gathered inside the conv loader -- same
   samples in the same order (``np.random.permutation`` stream as the reference), no copies
   of the frame buffers."""
-  def __init__(self, runner, num_epochs=3, num_minibatches=4, shuffle_before_epoch=True):
+  def __init__(self, runner, num_epochs=3, num_minibatches=4, shuffle_before_epoch=True, prepare=None):
     super().__init__(runner)
     self.num_epochs = num_epochs
     self.num_minibatches = num_minibatches
     self.shuffle_before_epoch = shuffle_before_epoch
+    # prepare(interactions, orders_dev, mbsize) -> None or f(epoch, k) -> dict merged into the
+    # minibatch's "state": work over ALL minibatches of a rollout once their order is known
+    # (NormalizeAdvantages.prepare: one all-reduce per rollout instead of one per minibatch)
+    self.prepare = prepare
     self._pinned, self._pinned_event = None, None
 
   @staticmethod
@@ -139,14 +143,20 @@ class IterateWithMinibatches(RunnerWrapper):
         drawn = self._draw_orders(sample_size, device)
       last = (sample_size, device)
       _, _, orders, orders_dev = drawn
+      mbsize = sample_size // self.num_minibatches
+      extras = None
+      if self.prepare is not None and orders_dev is not None:
+        extras = self.prepare(interactions, orders_dev, mbsize)
       for epoch, order in enumerate(orders):
         order_dev = orders_dev[epoch] if orders_dev is not None else None
-        mbsize = sample_size // self.num_minibatches
         for start in range(0, sample_size, mbsize):
           stop = min(start + mbsize, sample_size)
           index_host = order[start:stop]
           index_dev = order_dev[start:stop] if order_dev is not None else None
-          yield self._select_all(interactions, index_dev, index_host)
+          minibatch = self._select_all(interactions, index_dev, index_host)
+          if extras is not None:
+            minibatch["state"] = dict(minibatch.get("state") or {}, **extras(epoch, start // mbsize))
+          yield minibatch
 
 
 def ppo_runner_wrap(runner, gamma=0.99, lambda_=0.95, num_epochs=3, num_minibatches=4):
@@ -156,8 +166,9 @@ def ppo_runner_wrap(runner, gamma=0.99, lambda_=0.95, num_epochs=3, num_minibatc
   if not policy.is_recurrent() and getattr(env.unwrapped, "nenvs", None):
     transforms.append(MergeTimeBatch())
   runner = TransformInteractions(runner, transforms)
-  runner = IterateWithMinibatches(runner, num_epochs, num_minibatches)
-  runner = TransformInteractions(runner, [NormalizeAdvantages()])
+  normalize = NormalizeAdvantages()
+  runner = IterateWithMinibatches(runner, num_epochs, num_minibatches, prepare=normalize.prepare)
+  runner = TransformInteractions(runner, [normalize])
   return runner
 
 

@@ -86,17 +86,40 @@ class MergeTimeBatch:
 
 class NormalizeAdvantages:
   """(a - mean) / (std + eps) per minibatch (trajectory_transforms.py:84-92).  When the
-  batch is sharded over ranks the statistics are the GLOBAL ones: one 3-double all-reduce
-  (SURVEY.md 8e)."""
+  batch is sharded over ranks the statistics are the GLOBAL ones: ``prepare``,
+  called by ``IterateWithMinibatches`` once the order of a rollout's minibatches is known,
+  sums {sum, sumsq, count} of ALL of them over the ranks with one small all-reduce; a minibatch
+  that arrives without prepared statistics costs one 3-double all-reduce of its own."""
+  STATE_KEY = "advantage_stats"
+
   def __init__(self, epsilon=1e-8):
     self.epsilon = epsilon
+
+  def prepare(self, interactions, orders_dev, mbsize):
+    """orders_dev: (epochs, samples) int32 composed permutations on the device."""
+    advantages = interactions.get("advantages")
+    if (distributed.world_size() == 1 or not isinstance(advantages, torch.Tensor)
+        or not advantages.is_cuda or advantages.dtype != torch.float32
+        or advantages.numel() != orders_dev.shape[1]):
+      return None
+    flat = advantages.reshape(-1)
+    per_epoch = -(-orders_dev.shape[1] // mbsize)
+    stats = torch.empty((orders_dev.shape[0], per_epoch, 3), dtype=torch.float64, device=flat.device)
+    for epoch in range(orders_dev.shape[0]):
+      ops.adv_stats_segments(flat, orders_dev[epoch], mbsize, stats=stats[epoch])
+    distributed.all_reduce_sum(stats)
+    return lambda epoch, k: {self.STATE_KEY: stats[epoch, k]}
 
   def __call__(self, trajectory):
     advantages = trajectory["advantages"]
     if not isinstance(advantages, torch.Tensor) or not advantages.is_cuda:
       advantages = to_device(advantages, torch.device("cuda"), torch.float32)
     flat = advantages.reshape(-1)
-    if distributed.world_size() > 1:
+    state = trajectory.get("state")
+    ready = state.get(self.STATE_KEY) if isinstance(state, dict) else None
+    if ready is not None:
+      out = ops.adv_normalize(flat, self.epsilon, stats=ready, stats_ready=True)
+    elif distributed.world_size() > 1:
       stats = ops.adv_stats(flat)
       distributed.all_reduce_sum(stats)
       out = ops.adv_normalize(flat, self.epsilon, stats=stats, stats_ready=True)

@@ -69,6 +69,13 @@ int dx_gae_f32(const float *rewards, const uint8_t *resets, const float *values,
  * Algorithmic traffic: 4 B read + 4 B written per element (+ one read for the stats).
  * --------------------------------------------------------------------------------- */
 int dx_adv_stats_f32(const float *advantages, long long n, double *stats, void *stream);
+/* The statistics of ALL minibatches of one epoch in one launch: segment s is the minibatch
+ * advantages[index[s*seglen .. min((s+1)*seglen, n))] (index = the epoch's composed
+ * permutation, derl/runners/onpolicy.py:44-62; NULL = identity), stats = ceil(n/seglen) x 3
+ * doubles, bit-identical to dx_adv_stats_f32 on the gathered minibatch.  Lets a sharded run
+ * sum every minibatch's statistics over the ranks with one all-reduce per rollout. */
+int dx_adv_stats_segments_f32(const float *advantages, const int32_t *index, long long n,
+                              long long seglen, double *stats, void *stream);
 int dx_adv_normalize_f32(const float *advantages, float *out, long long n, float eps,
                          double *stats, int stats_ready, void *stream);
 

@@ -119,7 +119,66 @@ def gpu_step():
   print(f"rank {rank}: gpu_step OK", flush=True)
 
 
+def gpu_minibatch_stats():
+  """Global advantage statistics of every minibatch of a rollout from ONE all-reduce
+  (NormalizeAdvantages.prepare) == the per-minibatch all-reduce path, bit for bit, and == the
+  oracle's normalisation of the concatenated minibatch."""
+  import derl_amd as derl
+  from derl_amd.runners.onpolicy import IterateWithMinibatches, TransformInteractions
+  world, rank = distributed.world_size(), distributed.rank()
+  dev = torch.device("cuda", 0)
+  S, epochs, nmb = 1000, 3, 3  # 333-sample minibatches + a remainder of one sample
+  rng = np.random.RandomState(100 + rank)
+  shard = dict(advantages=rng.randn(S).astype(np.float32) * 3 + rank, observations=np.arange(S, dtype=np.float32))
+
+  class OneRollout:
+    env = policy = None
+    horizon, nsteps, step_count, nenvs = S, S, 0, None
+    def is_exhausted(self):
+      return False
+    def run(self, obs=None):
+      yield {k: torch.from_numpy(v).to(dev) for k, v in shard.items()}
+
+  def collect(prepared):
+    np.random.seed(7 + rank)
+    norm = derl.NormalizeAdvantages()
+    calls = [0]
+    saved = distributed.all_reduce_sum
+    def counting(t):
+      calls[0] += 1
+      return saved(t)
+    distributed.all_reduce_sum = counting
+    try:
+      it = IterateWithMinibatches(OneRollout(), epochs, nmb, prepare=norm.prepare if prepared else None)
+      out = [(mb["advantages"].cpu().numpy(), mb["observations"].cpu().numpy().astype(np.int64))
+             for mb in TransformInteractions(it, [norm]).run()]
+    finally:
+      distributed.all_reduce_sum = saved
+    return out, calls[0]
+
+  fast, fast_calls = collect(True)
+  slow, slow_calls = collect(False)
+  assert len(fast) == len(slow) == epochs * (nmb + 1)
+  assert fast_calls == 1 and slow_calls == len(slow), (fast_calls, slow_calls)
+  for (a, ia), (b, ib) in zip(fast, slow):
+    np.testing.assert_array_equal(ia, ib)
+    np.testing.assert_array_equal(a, b)
+  # against the oracle on the concatenation of both ranks' minibatches
+  for k, (a, idx) in enumerate(fast):
+    mine = torch.zeros(world, 400, dtype=torch.float32)
+    mine[rank, :idx.size] = torch.from_numpy(shard["advantages"][idx])
+    sizes = torch.zeros(world, dtype=torch.int64)
+    sizes[rank] = idx.size
+    torch.distributed.all_reduce(mine)
+    torch.distributed.all_reduce(sizes)
+    whole = np.concatenate([mine[r, :sizes[r]].numpy() for r in range(world)])
+    want = oracle.normalize_advantages(whole)
+    off = int(sizes[:rank].sum())
+    np.testing.assert_allclose(a, want[off:off + idx.size], rtol=2e-6, atol=2e-6, err_msg=f"minibatch {k}")
+  print(f"rank {rank}: gpu_minibatch_stats OK", flush=True)
+
+
 if __name__ == "__main__":
   distributed.init_from_env(backend="gloo")
-  {"cpu_math": cpu_math, "gpu_step": gpu_step}[sys.argv[1]]()
+  {"cpu_math": cpu_math, "gpu_step": gpu_step, "gpu_minibatch_stats": gpu_minibatch_stats}[sys.argv[1]]()
   torch.distributed.destroy_process_group()

@@ -27,3 +27,8 @@ def test_sharding_rules_world_size_2_gloo_cpu():
 @pytest.mark.gpu
 def test_two_ranks_one_gpu_step_matches_single_process():
   launch("gpu_step", 29512)
+
+
+@pytest.mark.gpu
+def test_minibatch_advantage_statistics_with_one_all_reduce_per_rollout():
+  launch("gpu_minibatch_stats", 29513)
