@@ -8,6 +8,8 @@
 //   [logstd (P)]  module_list.0.{0,2,4}.{weight,bias}  module_list.1.{0,2,4}.{weight,bias}
 // The head output is (B, 32): columns 0..P-1 policy outputs, column P the value.
 #include "igemm.hpp"
+#include "mlp_fused.hpp"
+#include <cstdlib>
 #include <cstring>
 
 using namespace dx;
@@ -41,10 +43,43 @@ int strided_pad(float *dst, long long R, int Cp, const float *src, int C, long l
 
 // slices of >= 64 rows: the slabs are tiny (<= 16 KB per slice and layer) and the wgrads are
 // latency chains of 32-row steps on a handful of workgroups, so short slices win
-int msplit_bound(long long M) {  // slab capacity: >= the msplit of every batch <= M
+int msplit_bound(long long M) {  // >= the msplit of every batch <= M
   long long ms = (M + 63) / 64;
   if (ms > 256) ms = 256;
   return static_cast<int>(ms < 1 ? 1 : ms);
+}
+
+// DX_MLP_UNFUSED=1: the layer-by-layer implicit-GEMM path also for narrow observations
+bool use_fused(const dx_mlp_ctx *c) {
+  static int off = -1;
+  if (off < 0) { const char *e = getenv("DX_MLP_UNFUSED"); off = (e && atoi(e)) ? 1 : 0; }
+  return !off && mlp_fused_supported(c->obs_pad);
+}
+
+constexpr int kFusedMaxSlabs = 128;
+
+// slabs per layer the buffers are sized for: the split of the GEMM path or one per workgroup of
+// the fused backward (8-row tiles at the smallest batches)
+int slab_capacity(const dx_mlp_ctx *c) {
+  int cap = msplit_bound(c->max_batch);
+  if (mlp_fused_supported(c->obs_pad)) {
+    const long long tiles = (static_cast<long long>(c->max_batch) + 7) / 8;
+    const int fused = static_cast<int>(tiles < kFusedMaxSlabs ? tiles : kFusedMaxSlabs);
+    if (fused > cap) cap = fused;
+  }
+  return cap;
+}
+
+MlpFusedArgs fused_args(const dx_mlp_ctx *c, int B) {
+  MlpFusedArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.params = c->params;
+  for (int i = 0; i < 6; ++i) { a.off_w[i] = c->off_w[i]; a.off_b[i] = c->off_b[i]; }
+  a.D = c->obs_dim; a.Dp = c->obs_pad; a.P = c->policy_out; a.B = B;
+  a.xpad = c->xpad; a.head = c->head; a.dhead = c->dhead;
+  for (int n = 0; n < 2; ++n) { a.h1[n] = c->h1[n]; a.h2[n] = c->h2[n]; }
+  a.slabs = c->slabs; a.slab_per_net = c->slab_per_net; a.ms_cap = slab_capacity(c);
+  return a;
 }
 
 void msplit_for(long long M, int *msplit, int *mper) {
@@ -106,7 +141,7 @@ int dx_mlp_init(dx_mlp_ctx *c) {
     c->pk_d1[net] = take(kH * kH);
   }
   c->packed_count = po;
-  const int ms = msplit_bound(c->max_batch);
+  const int ms = slab_capacity(c);
   // per net: L0 [64][obs_pad]+[64], L1 [64][64]+[64], L2 [32][64]+[32]
   c->slab_per_net = static_cast<long long>(ms) * (kH * c->obs_pad + kH + kH * kH + kH + kHeadLd * kH + kHeadLd);
   c->slab_count = 2 * c->slab_per_net;
@@ -130,6 +165,7 @@ static int check_mlp(const dx_mlp_ctx *c, const char *who, long long B, bool bwd
 // canonical parameters -> padded / transposed mirrors (after every parameter change)
 int dx_mlp_pack(const dx_mlp_ctx *c, void *stream) {
   if (int rc = check_mlp(c, "dx_mlp_pack", 1, false)) return rc;
+  if (use_fused(c)) return DX_OK;  // the fused kernels read the canonical parameters
   hipStream_t s = as_stream(stream);
   const int D = c->obs_dim, P = c->policy_out;
   for (int net = 0; net < 2; ++net) {
@@ -153,6 +189,11 @@ int dx_mlp_forward(const dx_mlp_ctx *c, const float *obs, int B, void *stream) {
   DX_REQUIRE(obs != nullptr, "dx_mlp_forward: null observations");
   hipStream_t s = as_stream(stream);
   const int D = c->obs_dim, P = c->policy_out;
+  if (use_fused(c)) {
+    MlpFusedArgs f = fused_args(c, B);
+    f.obs = obs;
+    return launch_mlp_forward_fused(f, s);
+  }
   if (int rc = strided_pad(c->xpad, B, c->obs_pad, obs, D, D, 1, 0, s)) return rc;
   for (int net = 0; net < 2; ++net) {
     const float *w = c->params;
@@ -177,7 +218,16 @@ int dx_mlp_backward(const dx_mlp_ctx *c, int B, void *stream) {
   const int D = c->obs_dim, P = c->policy_out, Dp = c->obs_pad;
   int ms, mper;
   msplit_for(B, &ms, &mper);
-  const int ms_cap = msplit_bound(c->max_batch);
+  const int ms_cap = slab_capacity(c);
+  const bool fused = use_fused(c);
+  if (fused) {
+    MlpFusedArgs f = fused_args(c, B);
+    const int tiles = cdiv(B, mlp_fused_tile_rows(B, c->obs_pad));
+    ms = tiles < kFusedMaxSlabs ? tiles : kFusedMaxSlabs;
+    if (ms > ms_cap) ms = ms_cap;
+    f.nslab = ms;
+    if (int rc = launch_mlp_backward_fused(f, s)) return rc;
+  }
   PermuteJob jobs[kMaxJobs];
   int nj = 0;
   for (int net = 0; net < 2; ++net) {
@@ -192,6 +242,7 @@ int dx_mlp_backward(const dx_mlp_ctx *c, int B, void *stream) {
       t.M = B; t.N = N; t.K = K; t.msplit = ms; t.mper = mper;
       return launch_tn(t, false, stage, s);
     };
+    if (!fused) {
     // layer 2 (64 -> head columns of this net)
     if (int rc = tn(rows_of(c->h2[net], kH), c->dhead, kHeadLd, kHeadLd, kH, s2w, s2b, ST_MLP_WGRAD_OUT)) return rc;
     NTArgs a = nt(rows_of(c->dhead, kHeadLd), c->packed + c->pk_d2[net], nullptr, c->da, kH, B, kH, kHeadLd);
@@ -204,6 +255,7 @@ int dx_mlp_backward(const dx_mlp_ctx *c, int B, void *stream) {
     if (int rc = launch_nt(a, false, EPI_DTANH, ST_MLP_DGRAD, s)) return rc;
     // layer 0 (input is data: wgrad only)
     if (int rc = tn(rows_of(c->xpad, Dp), c->db, kH, kH, Dp, s0w, s0b, ST_MLP_WGRAD_HID)) return rc;
+    }
     // slabs -> canonical gradients
     const int outs = net == 0 ? P : 1, col = net == 0 ? 0 : P;
     float *g = c->grads;

@@ -64,29 +64,36 @@ class IterateWithMinibatches(RunnerWrapper):
     self._pinned, self._pinned_event = None, None
 
   @staticmethod
-  def _select_all(interactions, index_dev, index_host):
-    """One minibatch of every array: device arrays with small rows share ONE gather launch,
-    arrays with big rows (frames) are referenced lazily, host arrays are fancy-indexed."""
-    out, small = {}, []
+  def _gather_epoch(interactions, order_dev):
+    """Device arrays with small rows, permuted for a whole epoch by ONE gather launch (per 8
+    arrays): the epoch's minibatches are then contiguous slices, exactly the reference's
+    shuffle-in-place-then-slice (onpolicy.py:44-62) without touching the rollout buffers."""
+    if order_dev is None:
+      return {}
+    small = [key for key, val in interactions.items()
+             if key != "state" and isinstance(val, torch.Tensor) and val.is_cuda
+             and val.element_size() * math.prod(val.shape[1:]) < LAZY_ROW_BYTES]
+    gathered = ops.gather_rows_multi([interactions[key].contiguous() for key in small], order_dev)
+    return dict(zip(small, gathered))
+
+  @staticmethod
+  def _select_all(interactions, shuffled, start, stop, index_dev, index_host):
+    """One minibatch of every array: slices of the epoch's permuted small arrays, lazy index
+    references for arrays with big rows (frames), fancy indexing for host arrays."""
+    out = {}
     for key, val in interactions.items():
-      if key == "state":
+      if key in shuffled:
+        out[key] = shuffled[key][start:stop]
+      elif key == "state":
         out[key] = val
       elif isinstance(val, torch.Tensor) and val.is_cuda:
-        row_bytes = val.element_size() * math.prod(val.shape[1:])
-        if row_bytes >= LAZY_ROW_BYTES:
-          out[key] = GatheredRows(val, index_dev)
-        else:
-          out[key] = None
-          small.append(key)
+        out[key] = GatheredRows(val, index_dev)
       elif isinstance(val, torch.Tensor):
         out[key] = val[torch.from_numpy(index_host.astype(np.int64))]
       elif isinstance(val, np.ndarray):
         out[key] = val[index_host]
       else:
         out[key] = val
-    if small:
-      gathered = ops.gather_rows_multi([interactions[key].contiguous() for key in small], index_dev)
-      out.update(zip(small, gathered))
     return out
 
   def _draw_orders(self, sample_size, device):
@@ -149,11 +156,12 @@ class IterateWithMinibatches(RunnerWrapper):
         extras = self.prepare(interactions, orders_dev, mbsize)
       for epoch, order in enumerate(orders):
         order_dev = orders_dev[epoch] if orders_dev is not None else None
+        shuffled = self._gather_epoch(interactions, order_dev)
         for start in range(0, sample_size, mbsize):
           stop = min(start + mbsize, sample_size)
           index_host = order[start:stop]
           index_dev = order_dev[start:stop] if order_dev is not None else None
-          minibatch = self._select_all(interactions, index_dev, index_host)
+          minibatch = self._select_all(interactions, shuffled, start, stop, index_dev, index_host)
           if extras is not None:
             minibatch["state"] = dict(minibatch.get("state") or {}, **extras(epoch, start // mbsize))
           yield minibatch

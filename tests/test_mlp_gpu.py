@@ -135,7 +135,8 @@ def test_upstream_ppo_pybullet_fixture():
       nt.assert_allclose(p.grad.cpu().numpy(), eg[f"grad_{i}"], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("batch,obs_dim,act_dim", [(1, 3, 2), (37, 17, 6), (4096, 17, 6), (300, 111, 8)])
+@pytest.mark.parametrize("batch,obs_dim,act_dim", [(1, 3, 2), (37, 17, 6), (4096, 17, 6), (300, 111, 8), (1500, 17, 6),
+                          (5000, 26, 6), (1000, 40, 3), (2500, 50, 6)])
 def test_mlp_gradients_ragged_shapes(batch, obs_dim, act_dim):
   import derl_amd as derl
   weights = gi.mujoco_weights(obs_dim, act_dim, batch)
