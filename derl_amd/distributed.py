@@ -66,4 +66,7 @@ def broadcast_(tensor, src=0):
 
 def barrier():
   if world_size() > 1:
-    dist.barrier()
+    if dist.get_backend() == "nccl":  # name the device: no guess from the rank, no warning
+      dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+      dist.barrier()
