@@ -242,19 +242,19 @@ int dx_mlp_backward(const dx_mlp_ctx *c, int B, void *stream) {
       t.M = B; t.N = N; t.K = K; t.msplit = ms; t.mper = mper;
       return launch_tn(t, false, stage, s);
     };
-    if (!fused) {
-    // layer 2 (64 -> head columns of this net)
-    if (int rc = tn(rows_of(c->h2[net], kH), c->dhead, kHeadLd, kHeadLd, kH, s2w, s2b, ST_MLP_WGRAD_OUT)) return rc;
-    NTArgs a = nt(rows_of(c->dhead, kHeadLd), c->packed + c->pk_d2[net], nullptr, c->da, kH, B, kH, kHeadLd);
-    a.mask_src = c->h2[net];
-    if (int rc = launch_nt(a, false, EPI_DTANH, ST_MLP_DGRAD, s)) return rc;
-    // layer 1
-    if (int rc = tn(rows_of(c->h1[net], kH), c->da, kH, kH, kH, s1w, s1b, ST_MLP_WGRAD_HID)) return rc;
-    a = nt(rows_of(c->da, kH), c->packed + c->pk_d1[net], nullptr, c->db, kH, B, kH, kH);
-    a.mask_src = c->h1[net];
-    if (int rc = launch_nt(a, false, EPI_DTANH, ST_MLP_DGRAD, s)) return rc;
-    // layer 0 (input is data: wgrad only)
-    if (int rc = tn(rows_of(c->xpad, Dp), c->db, kH, kH, Dp, s0w, s0b, ST_MLP_WGRAD_HID)) return rc;
+    if (!fused) {  // layer by layer on the implicit-GEMM kernels
+      // layer 2 (64 -> head columns of this net)
+      if (int rc = tn(rows_of(c->h2[net], kH), c->dhead, kHeadLd, kHeadLd, kH, s2w, s2b, ST_MLP_WGRAD_OUT)) return rc;
+      NTArgs a = nt(rows_of(c->dhead, kHeadLd), c->packed + c->pk_d2[net], nullptr, c->da, kH, B, kH, kHeadLd);
+      a.mask_src = c->h2[net];
+      if (int rc = launch_nt(a, false, EPI_DTANH, ST_MLP_DGRAD, s)) return rc;
+      // layer 1
+      if (int rc = tn(rows_of(c->h1[net], kH), c->da, kH, kH, kH, s1w, s1b, ST_MLP_WGRAD_HID)) return rc;
+      a = nt(rows_of(c->da, kH), c->packed + c->pk_d1[net], nullptr, c->db, kH, B, kH, kH);
+      a.mask_src = c->h1[net];
+      if (int rc = launch_nt(a, false, EPI_DTANH, ST_MLP_DGRAD, s)) return rc;
+      // layer 0 (input is data: wgrad only)
+      if (int rc = tn(rows_of(c->xpad, Dp), c->db, kH, kH, Dp, s0w, s0b, ST_MLP_WGRAD_HID)) return rc;
     }
     // slabs -> canonical gradients
     const int outs = net == 0 ? P : 1, col = net == 0 ? 0 : P;
