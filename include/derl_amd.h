@@ -311,6 +311,12 @@ int dx_synth_atari_step(void *frames, long long frame_bytes_total, float *reward
 int dx_diag_mfma_f32(int blocks, int iters, float *out, void *stream);
 /* The same flop count as one dependent accumulation chain per wave. */
 int dx_diag_mfma_f32_chain(int blocks, int iters, float *out, void *stream);
+/* The K loop of the 128x64 GEMM tile fed from LDS only (no global loads, LDS writes or barriers):
+ * blocks x 4 waves x iters x 32 MFMAs; mode 0 reads fragments right before use, 1 one step ahead. */
+int dx_diag_lds_mfma_f32(int blocks, int iters, int mode, float *out, void *stream);
+/* The NT GEMM K loop rebuilt step by step on plain row-major operands (tools/gemm_loop.py). */
+int dx_diag_gemm_loop_f32(const float *A, const float *B, int tiles, int ktiles, int what, float *out,
+                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -27,3 +27,19 @@ for entry in ("dx_diag_mfma_f32", "dx_diag_mfma_f32_chain"):
     flops = blocks * 4 * iters * 4 * 4096.0
     print(json.dumps(dict(kernel=entry, waves_per_simd=blocks_per_cu, ms=round(ms, 3),
                           TFLOPs=round(flops / ms / 1e9, 1))), flush=True)
+
+for mode in (0, 1):
+  for blocks_per_cu in (1, 2, 4):
+    blocks, iters = 256 * blocks_per_cu, 4000
+    for _ in range(2):
+      _lib.call("dx_diag_lds_mfma_f32", blocks, iters, mode, _lib.ptr(out), stream)
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(5):
+      _lib.call("dx_diag_lds_mfma_f32", blocks, iters, mode, _lib.ptr(out), stream)
+    end.record()
+    end.synchronize()
+    ms = start.elapsed_time(end) / 5
+    flops = blocks * 4 * iters * 32 * 4096.0
+    print(json.dumps(dict(kernel="dx_diag_lds_mfma_f32", mode=mode, waves_per_simd=blocks_per_cu,
+                          ms=round(ms, 3), TFLOPs=round(flops / ms / 1e9, 1))), flush=True)
