@@ -259,13 +259,80 @@ __global__ __launch_bounds__(256) void gemm_loop_db_kernel(const float *A, const
   if (s == 12345.678f) out[0] = s;
 }
 
+// LDS fed by global_load_lds_dwordx4 (no staging registers, no ds_write): three stages of
+// (BM + 64) rows x 128 B, unpadded with the 16-byte chunks XOR-swizzled by (row & 7) on the SOURCE
+// address; two K tiles in flight, ONE raw s_barrier per tile behind a counted s_waitcnt vmcnt.
+template <int BM>
+__device__ __forceinline__ void gemm_loop_glds_body(const float *A, const float *B, int ktiles, float *out) {
+  constexpr int NW = BM / 32, ROWS = BM + 64, ST = ROWS * 32, PER_WAVE = ROWS / 8 / NW;
+  static_assert(ROWS / 8 % NW == 0, "rows must split evenly over the waves");
+  __shared__ __attribute__((aligned(16))) float smem[3 * ST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long K = 32LL * ktiles;
+  // this lane's source rows: instruction j of this wave fills stage rows (j*NW + wave)*8 .. +8
+  const float *src[PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int r = (j * NW + wave) * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ (r & 7);
+    src[j] = (r < BM ? A + (static_cast<long long>(blockIdx.x) * BM + r) * K : B + static_cast<long long>(r - BM) * K) +
+             4 * logical;
+  }
+#define DX_ISSUE(kt_)                                                                                   \
+  do {                                                                                                  \
+    float *dst_ = smem + ((kt_) % 3) * ST;                                                              \
+    _Pragma("unroll") for (int j = 0; j < PER_WAVE; ++j)                                                \
+        __builtin_amdgcn_global_load_lds(src[j] + 32 * (kt_), dst_ + (j * NW + wave) * 8 * 32, 16, 0, 0); \
+  } while (0)
+  DX_ISSUE(0);
+  if (ktiles > 1) DX_ISSUE(1);
+  const int wm0 = (wave >> 1) * 64, wn0 = BM + (wave & 1) * 32, row = lane & 31, kh = lane >> 5;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+  for (int kt = 0; kt < ktiles; ++kt) {
+    if (kt + 1 < ktiles) {
+      if (PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // tile kt has landed for every wave; stage (kt+2)%3 is no longer read
+    if (kt + 2 < ktiles) DX_ISSUE(kt + 2);
+    const float *st = smem + (kt % 3) * ST;
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+      const int ch = ((2 * ss + kh) ^ (row & 7)) * 4;
+      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(st + (wm0 + row) * 32 + ch);
+      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(st + (wm0 + 32 + row) * 32 + ch);
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(st + (wn0 + row) * 32 + ch);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b[q], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b[q], acc1, 0, 0, 0);
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += acc0[j] + acc1[j];
+  if (s == 12345.678f) out[0] = s;
+#undef DX_ISSUE
+}
+__global__ __launch_bounds__(256) void gemm_loop_glds128_kernel(const float *A, const float *B, int ktiles, float *out) {
+  gemm_loop_glds_body<128>(A, B, ktiles, out);
+}
+__global__ __launch_bounds__(512) void gemm_loop_glds256_kernel(const float *A, const float *B, int ktiles, float *out) {
+  gemm_loop_glds_body<256>(A, B, ktiles, out);
+}
+
 }  // namespace
 
 // tiles x (128 x 64 x 32*ktiles) GEMM tiles; what: 0 = LDS reads + MFMA only, 1 = + LDS writes and
 // barriers, 2 = + global loads (the full K loop), 3 = the same with the loads two K tiles ahead.  A must hold tiles*128*32*ktiles floats, B 64*32*ktiles.
 extern "C" int dx_diag_gemm_loop_f32(const float *A, const float *B, int tiles, int ktiles, int what, float *out,
                                      void *stream) {
-  DX_REQUIRE(A && B && out && tiles >= 1 && ktiles >= 1 && what >= 0 && what <= 6, "dx_diag_gemm_loop_f32: bad argument");
+  DX_REQUIRE(A && B && out && tiles >= 1 && ktiles >= 1 && what >= 0 && what <= 8, "dx_diag_gemm_loop_f32: bad argument");
   hipStream_t s = dx::as_stream(stream);
   if (what == 0) hipLaunchKernelGGL((gemm_loop_kernel<false, false>), dim3(tiles), dim3(256), 0, s, A, B, ktiles, out);
   if (what == 1) hipLaunchKernelGGL((gemm_loop_kernel<true, false>), dim3(tiles), dim3(256), 0, s, A, B, ktiles, out);
@@ -274,6 +341,8 @@ extern "C" int dx_diag_gemm_loop_f32(const float *A, const float *B, int tiles, 
     hipLaunchKernelGGL((gemm_loop_kernel<true, true, true>), dim3(tiles), dim3(256), 0, s, A, B, ktiles, out);
   if (what == 5) hipLaunchKernelGGL(gemm_loop_db_kernel<32>, dim3(tiles), dim3(256), 0, s, A, B, ktiles, out);
   if (what == 6) hipLaunchKernelGGL(gemm_loop_db_kernel<16>, dim3(tiles), dim3(256), 0, s, A, B, 2 * ktiles, out);
+  if (what == 7) hipLaunchKernelGGL(gemm_loop_glds128_kernel, dim3(tiles), dim3(256), 0, s, A, B, ktiles, out);
+  if (what == 8) hipLaunchKernelGGL(gemm_loop_glds256_kernel, dim3(tiles / 2), dim3(512), 0, s, A, B, ktiles, out);
   if (what == 3) hipLaunchKernelGGL(gemm_loop_ahead2_kernel, dim3(tiles), dim3(256), 0, s, A, B, ktiles, out);
   DX_LAUNCH_CHECK();
   return DX_OK;
