@@ -27,6 +27,29 @@ def test_advantage_normalisation(n):
   nt.assert_allclose(out2, out, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("n,seglen,indexed", [(1000, 333, True), (8192, 2048, True), (77, 77, False), (5, 2, True)])
+def test_advantage_statistics_of_all_minibatches_in_one_launch(n, seglen, indexed):
+  """dx_adv_stats_segments_f32: {sum, sumsq, count} of every minibatch slice of a permuted
+  epoch == dx_adv_stats_f32 on the gathered minibatch, bit for bit (same summation order), and
+  == float64 NumPy sums."""
+  from derl_amd import ops
+  rs = np.random.RandomState(n)
+  a = (rs.randn(n) * 2 + 0.5).astype(np.float32)
+  perm = rs.permutation(n).astype(np.int32) if indexed else None
+  adv = torch.from_numpy(a).to(DEV)
+  index = torch.from_numpy(perm).to(DEV) if indexed else None
+  stats = ops.adv_stats_segments(adv, index, seglen).cpu().numpy()
+  order = perm if indexed else np.arange(n)
+  nseg = -(-n // seglen)
+  assert stats.shape == (nseg, 3)
+  for k in range(nseg):
+    piece = a[order[k * seglen:(k + 1) * seglen]]
+    single = ops.adv_stats(torch.from_numpy(piece).to(DEV)).cpu().numpy()
+    nt.assert_array_equal(stats[k], single)
+    p64 = piece.astype(np.float64)
+    nt.assert_allclose(stats[k], [p64.sum(), (p64 ** 2).sum(), piece.size], rtol=1e-12, atol=1e-9)
+
+
 @pytest.mark.parametrize("n,max_norm", [(11085, 0.5), (1686693, 0.5), (1000, None), (37, 100.0)])
 def test_clip_adam_steps(n, max_norm):
   from derl_amd import ops
