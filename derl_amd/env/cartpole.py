@@ -21,6 +21,7 @@ class CartPoleBatch:
     self.rng = np.random.RandomState(seed)
     self.state = np.zeros((self.nenvs, 4), np.float64)
     self.steps = np.zeros(self.nenvs, np.int64)
+    self.episodes_done = 0  # finished episodes so far (learning-curve checks)
 
   def _reset_rows(self, rows):
     self.state[rows] = self.rng.uniform(-0.05, 0.05, size=(int(rows.sum()), 4))
@@ -51,5 +52,6 @@ class CartPoleBatch:
             | (self.steps >= self.max_steps))
     rewards = np.ones(self.nenvs, np.float64)
     if done.any():
+      self.episodes_done += int(done.sum())
       self._reset_rows(done)
     return self.state.astype(np.float32), rewards, done, [{} for _ in range(self.nenvs)]

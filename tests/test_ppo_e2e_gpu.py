@@ -271,3 +271,15 @@ def test_fused_native_rollout_equals_per_step_loop():
   for x, y in zip(a, b):
     for k in x:
       assert torch.equal(x[k], y[k]), k
+
+
+def test_ppo_learns_cartpole():
+  """The whole path as a learner, not only as arithmetic: PPO with BASELINE config 1's
+  hyper-parameters (factory/ppo.py atari preset, nenvs 8 x 128 steps) on the built-in CartPole-v1
+  -- rollout, GAE, minibatches, fused loss, backward, clip + Adam with the annealed rate -- raises
+  the mean episode length from ~30 steps to several hundred.  60 iterations (61 k env steps)."""
+  from tools.cartpole_learns import run
+  lengths, _ = run(iterations=60, seed=0)
+  first, last = float(np.mean(lengths[:5])), float(np.mean(lengths[-10:]))
+  assert first < 60, lengths[:5]
+  assert last > 100 and last > 3 * first, (first, last)
