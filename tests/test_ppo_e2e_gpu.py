@@ -283,3 +283,14 @@ def test_ppo_learns_cartpole():
   first, last = float(np.mean(lengths[:5])), float(np.mean(lengths[-10:]))
   assert first < 60, lengths[:5]
   assert last > 100 and last > 3 * first, (first, last)
+
+
+def test_ppo_cnn_learns_image_bandit():
+  """The conv path as a learner (tools/quadrant_learns.py): device-resident runner, frames gathered
+  by index inside the conv loader, fused categorical loss, conv backward, clip + Adam.  The frames
+  show a bright quadrant = the rewarded action; the mean reward goes from chance (0.25) to > 0.9
+  in 40 iterations of 64 envs x 16 steps."""
+  from tools.quadrant_learns import run
+  curve, _ = run(iterations=40, nenvs=64, horizon=16, seed=0, lr=1e-3)
+  assert np.mean(curve[:2]) < 0.4, curve[:2]
+  assert np.mean(curve[-5:]) > 0.9, curve[-5:]
