@@ -123,8 +123,8 @@ def time_gae(T, N, iters=20):
 def main():
   parser = argparse.ArgumentParser()
   parser.add_argument("--gpus", type=int, default=1)
-  parser.add_argument("--steps", type=int, default=5)
-  parser.add_argument("--warmup", type=int, default=2)
+  parser.add_argument("--steps", type=int, default=20)
+  parser.add_argument("--warmup", type=int, default=3)
   parser.add_argument("--nenvs", type=int, default=256)
   parser.add_argument("--nsteps", type=int, default=128)
   parser.add_argument("--weak", action="store_true", help="256 envs per rank instead of in total")
