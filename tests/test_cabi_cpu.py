@@ -56,3 +56,13 @@ def test_ops_refuse_cpu_tensors(lib):
   z = torch.zeros(2, 3)
   with pytest.raises(ValueError, match="no CPU path"):
     ops.gae(z, torch.zeros(2, 3, dtype=torch.bool), z, torch.zeros(3), 0.99, 0.95)
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch, tmp_path):
+  """No fallback: without libderl_amd.so every native call raises NativeError naming the build."""
+  monkeypatch.setattr(lib, "_lib", None)
+  monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "libderl_amd.so"))
+  with pytest.raises(lib.NativeError, match="no CPU fallback"):
+    lib.load()
+  with pytest.raises(lib.NativeError):
+    lib.call("dx_abi_version")
