@@ -1,5 +1,7 @@
 // Two-net tanh MLP actor-critic (MuJoCo Gaussian policy / vector-observation categorical
-// policy) on the implicit-GEMM kernels: packing, forward, backward.
+// policy): C-ABI entry points, buffer layout, and the layer-by-layer path on the implicit-GEMM
+// kernels (packing, forward, backward).  Observations up to 64 wide take the fused kernels of
+// mlp_fused.hip instead (one launch per direction).
 //
 // Restates derl/models.py:224-237 (MLP: Linear-Tanh-Linear-Tanh-Linear, hidden 64-64) and
 // :240-271 (MuJoCoModel: one independent MLP per output -- policy mean / logits and value --

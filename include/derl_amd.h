@@ -253,7 +253,10 @@ int dx_cnn_stage(const dx_cnn_ctx *ctx, int stage, const void *obs, int obs_is_u
  *   [logstd (P) if has_logstd] module_list.0.{0,2,4}.{weight,bias} module_list.1.{0,2,4}.{...}
  * with module_list.0 = policy net (obs_dim -> 64 -> 64 -> P), module_list.1 = value net
  * (-> 1).  Head output (B, 32): columns 0..P-1 policy outputs (Gaussian mean or logits),
- * column P the value.  dx_mlp_pack after every parameter change.
+ * column P the value.  dx_mlp_pack after every parameter change (a no-op when the observation fits
+ * 64 columns: forward and backward then run as ONE launch each for both nets, csrc/mlp_fused.hip,
+ * straight from the canonical parameters; wider observations go layer by layer through the
+ * implicit-GEMM kernels and need the packed mirrors).
  * --------------------------------------------------------------------------------- */
 typedef struct dx_mlp_ctx {
   int struct_bytes;
