@@ -294,3 +294,34 @@ def test_ppo_cnn_learns_image_bandit():
   curve, _ = run(iterations=40, nenvs=64, horizon=16, seed=0, lr=1e-3)
   assert np.mean(curve[:2]) < 0.4, curve[:2]
   assert np.mean(curve[-5:]) > 0.9, curve[-5:]
+
+
+def test_bench_line_contract():
+  """bench.py prints ONE JSON line with the driver's keys, the roofline and cpu_baseline objects."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1",
+                        "--cpu-nsteps", "4"], capture_output=True, text=True, timeout=600, cwd=root)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.strip()]
+  assert len(lines) == 1, out.stdout[-2000:]
+  d = json.loads(lines[0])
+  for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    assert key in d, key
+  assert d["unit"] == "env-steps/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["vs_baseline"] is None
+  assert d["higher_is_better"] is True and d["dtype"] == "f32" and d["data"] == "synthetic"
+  assert "workload" in d["config"] and "model" not in d["config"]
+  roof = d["roofline"]
+  for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    assert key in roof, key
+  assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s"
+  assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.2 < roof["frac"] < 1.0
+  base = d["cpu_baseline"]
+  for key in ("value", "unit", "cores", "kind", "sample"):
+    assert key in base, key
+  assert base["kind"] == "port" and base["cores"] >= 1 and base["value"] > 0
+  assert d["value"] > 10 * base["value"]  # BASELINE.json: >= 10x the reference CPU path
+  assert d["gae_roofline"]["asymptote"]["frac"] > 0.55
