@@ -249,3 +249,25 @@ def test_backward_in_two_parts_equals_whole_backward():
   assert torch.isnan(eng.grads[:off]).all()
   eng.backward(obs, part=1)
   assert torch.equal(eng.grads, whole)
+
+
+@pytest.mark.parametrize("switch", ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_SPLIT_BF16=1 DX_SPLIT_MIN_M=1",
+                                    "DX_TN_SWIZZLE=0", "DX_LAT_MAX_TILES=0"])
+def test_diagnostic_switches_keep_parity(switch):
+  """Every alternative kernel route behind an environment switch (diagnostic switches)
+  passes the same golden / oracle comparisons: the switches are read once per process, so a subset
+  of this file runs in a child process per setting."""
+  import subprocess
+  import sys
+  env = dict(os.environ)
+  for item in switch.split():
+    key, val = item.split("=")
+    env[key] = val
+  here = os.path.abspath(__file__)
+  subset = ("test_forward_matches_reference_golden or test_loss_and_gradients_match_reference_golden or "
+            "(test_backward_ragged_batches_with_gather and (130 or 1024)) or test_fused_rollout_act_matches_unfused_path")
+  out = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-k", subset],
+                       env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(here)))
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+  assert " passed" in out.stdout and "failed" not in out.stdout

@@ -186,3 +186,18 @@ def test_ppo_gaussian_mlp_learns_reaching_task():
   curve, _ = run(iterations=30, nenvs=64, horizon=64, seed=0)
   assert curve[0] < -1.1, curve[:3]
   assert np.mean(curve[-3:]) > -0.7, curve[-3:]
+
+
+def test_layer_by_layer_path_keeps_parity_for_narrow_observations():
+  """DX_MLP_UNFUSED=1 (read once per process, hence a child process): the implicit-GEMM MLP path on
+  the shapes the fused kernels normally take passes the same golden comparisons."""
+  import subprocess
+  import sys
+  here = os.path.abspath(__file__)
+  subset = ("test_mlp_act_matches_reference_golden or test_ppo_mlp_trainer_steps_match_reference_golden or "
+            "test_upstream_ppo_pybullet_fixture or (test_mlp_gradients_ragged_shapes and (37 or 1500))")
+  out = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-k", subset],
+                       env=dict(os.environ, DX_MLP_UNFUSED="1"), capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(here)))
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+  assert " passed" in out.stdout and "failed" not in out.stdout
