@@ -178,7 +178,42 @@ def gpu_minibatch_stats():
   print(f"rank {rank}: gpu_minibatch_stats OK", flush=True)
 
 
+def gpu_learns():
+  """Data-parallel PPO as a learner: every rank owns half of the envs of the image bandit
+  (tools/quadrant_learns.py); with the gradient all-reduce (overlapped with the backward) and the
+  per-rollout statistics all-reduce the replicas stay bit-identical and the mean reward reaches
+  > 0.9 as in the single-process run."""
+  from tools.quadrant_learns import run
+  import derl_amd as derl
+  world, rank = distributed.world_size(), distributed.rank()
+  kept = {}
+  original = derl.PPOFactory.make
+
+  def make(self, env, *args, **kwargs):  # keep a handle on the algorithm the tool builds
+    alg = original(self, env, *args, **kwargs)
+    distributed.broadcast_(alg.model.engine.params)
+    alg.model.engine.mark_dirty()
+    kept["alg"] = alg
+    return alg
+
+  derl.PPOFactory.make = make
+  try:
+    curve, _ = run(iterations=40, nenvs=64 // world, horizon=16, seed=rank, lr=1e-3)
+  finally:
+    derl.PPOFactory.make = original
+  reward = torch.tensor([float(np.mean(curve[-5:]))], dtype=torch.float64)
+  torch.distributed.all_reduce(reward)
+  assert reward.item() / world > 0.9, (curve[-5:], reward.item() / world)
+  params = kept["alg"].model.engine.params.detach().double().cpu()
+  low, high = params.clone(), params.clone()
+  torch.distributed.all_reduce(low, op=torch.distributed.ReduceOp.MIN)
+  torch.distributed.all_reduce(high, op=torch.distributed.ReduceOp.MAX)
+  assert torch.equal(low, high), "replicas diverged"
+  print(f"rank {rank}: gpu_learns OK", flush=True)
+
+
 if __name__ == "__main__":
   distributed.init_from_env(backend="gloo")
-  {"cpu_math": cpu_math, "gpu_step": gpu_step, "gpu_minibatch_stats": gpu_minibatch_stats}[sys.argv[1]]()
+  {"cpu_math": cpu_math, "gpu_step": gpu_step, "gpu_minibatch_stats": gpu_minibatch_stats,
+   "gpu_learns": gpu_learns}[sys.argv[1]]()
   torch.distributed.destroy_process_group()

@@ -32,3 +32,8 @@ def test_two_ranks_one_gpu_step_matches_single_process():
 @pytest.mark.gpu
 def test_minibatch_advantage_statistics_with_one_all_reduce_per_rollout():
   launch("gpu_minibatch_stats", 29513)
+
+
+@pytest.mark.gpu
+def test_two_rank_data_parallel_ppo_learns_and_replicas_stay_identical():
+  launch("gpu_learns", 29514)
