@@ -52,15 +52,16 @@ class QuadrantEnv:
     return obs, rewards, resets, None
 
 
-def run(iterations=40, nenvs=64, horizon=16, seed=0, lr=1e-3):
+def run(iterations=40, nenvs=64, horizon=16, seed=0, lr=1e-3, algorithm="ppo"):
   derl.summary.stop_recording()
   torch.manual_seed(seed)
   np.random.seed(seed)
   env = QuadrantEnv(nenvs, seed)
-  kwargs = derl.PPOFactory.get_kwargs("atari")
+  factory = derl.PPOFactory if algorithm == "ppo" else derl.A2CFactory
+  kwargs = factory.get_kwargs("atari") if algorithm == "ppo" else factory.get_kwargs()
   kwargs.update(nenvs=nenvs, num_runner_steps=horizon, num_train_steps=nenvs * horizon * iterations, lr=lr)
-  alg = derl.PPOFactory(**kwargs).make(env)
-  updates = kwargs["num_epochs"] * kwargs["num_minibatches"]
+  alg = factory(**kwargs).make(env)
+  updates = kwargs["num_epochs"] * kwargs["num_minibatches"] if algorithm == "ppo" else 1
   data, curve = alg.runner.run(), []
   start = time.perf_counter()
   for _ in range(iterations):
@@ -75,5 +76,7 @@ def run(iterations=40, nenvs=64, horizon=16, seed=0, lr=1e-3):
 
 if __name__ == "__main__":
   its = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-  curve, seconds = run(its)
-  print(json.dumps(dict(iterations=its, seconds=round(seconds, 2), mean_reward=[round(c, 3) for c in curve])))
+  algo = sys.argv[2] if len(sys.argv) > 2 else "ppo"
+  curve, seconds = run(its, algorithm=algo) if algo == "ppo" else run(its, horizon=5, lr=7e-4, algorithm=algo)
+  print(json.dumps(dict(algorithm=algo, iterations=its, seconds=round(seconds, 2),
+                        mean_reward=[round(float(np.mean(curve[i:i + 10])), 3) for i in range(0, its, max(its // 20, 1))])))
