@@ -2,7 +2,7 @@
 
 Import surface mirrors ``derl/__init__.py`` for the on-policy path (PPO / A2C); the DQN and
 SAC families of the reference are out of scope."""
-from . import env, summary
+from . import distributed, env, summary
 from .alg import Alg, Loss, Trainer, PPO, PPOLoss, A2C, A2CLoss
 from .anneal import AnnealingVariable, LinearAnneal
 from .factory import Factory, KwargsDict, PPOFactory, A2CFactory

@@ -8,16 +8,22 @@ from ..optim import _FlatOptimizer
 
 
 def r_squared(targets, predictions):
-  """Coefficient of determination (alg/common.py:9-12)."""
-  variance = torch.pow(predictions.std(), 2)
-  return 1. - torch.mean(torch.pow(predictions - targets, 2)) / variance
+  """Coefficient of determination 1 - MSE / Var[predictions] with the unbiased variance, the
+  quantity the reference logs (alg/common.py:9-12); off the hot path (the fused loss kernels
+  produce the same number among their eight outputs)."""
+  residual = (predictions - targets).square().mean()
+  return 1. - residual / predictions.var(unbiased=True)
 
 
 def total_norm(tensors, norm_type=2):
-  """Total norm of the tensors as if concatenated (alg/common.py:15-20)."""
-  if norm_type == float('inf'):
-    return max(t.abs().max() for t in tensors)
-  return sum(t.norm(norm_type) ** norm_type for t in tensors) ** (1. / norm_type)
+  """p-norm of all tensors taken as ONE vector (alg/common.py:15-20); ``inf`` gives the largest
+  magnitude.  Fallback for torch optimizers -- flat-buffer optimizers get the norm from
+  ``dx_grad_sumsq_f32``."""
+  tensors = list(tensors)
+  if norm_type == float("inf"):
+    return torch.stack([t.detach().abs().max() for t in tensors]).max()
+  powered = torch.stack([t.detach().abs().pow(norm_type).sum() for t in tensors])
+  return powered.sum().pow(1. / norm_type)
 
 
 class _LossBackward(torch.autograd.Function):
@@ -83,9 +89,9 @@ class Trainer:
     if isinstance(self.optimizer, _FlatOptimizer):
       self.optimizer.max_grad_norm = self.max_grad_norm
       self.optimizer.reduce_and_norm()
-      if summary.should_record():
-        # the fused step writes the pre-clip norm; read back lazily by the summary writer
-        summary.add_scalar(tag, self.optimizer.grad_norm, global_step=self.step_count)
+      # the pre-clip norm is formed inside the fused optimizer launch: ``step`` records it
+      # afterwards (recording the buffer here would log the PREVIOUS step's norm)
+      self._pending_norm_tag = tag if summary.should_record() else None
       return
     parameters = list(parameters)
     if self.max_grad_norm is not None:
@@ -118,6 +124,12 @@ class Trainer:
         anneal.summarize(alg.runner.step_count)
       anneal.step_to(alg.runner.step_count)
     self.optimizer.step()
+    if getattr(self, "_pending_norm_tag", None) is not None:
+      # this step's pre-clip gradient norm (the reference logs it before optimizer.step(),
+      # alg/common.py:61-64: same value, same global_step); a copy, the buffer is reused
+      summary.add_scalar(self._pending_norm_tag, self.optimizer.grad_norm[0].clone(),
+                         global_step=self.step_count)
+      self._pending_norm_tag = None
     if not isinstance(self.optimizer, _FlatOptimizer):
       engine = getattr(alg.model, "engine", None)
       if engine is not None:

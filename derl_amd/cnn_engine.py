@@ -36,6 +36,7 @@ class CnnEngine:
     self._backward_allocated = False
     ctx.params, ctx.grads, ctx.packed = (t.data_ptr() for t in (self.params, self.grads, self.packed))
     self._packed_version = None
+    self._watched = [self.params]
     self.shapes = self._param_shapes()
 
   def _forward_buffers(self, ctx, f32):
@@ -106,10 +107,21 @@ class CnnEngine:
   def mark_dirty(self):
     self._packed_version = None
 
+  def watch(self, tensors):
+    """Registers tensors that alias the flat parameter buffer with their OWN version counter
+    (an ``nn.Parameter`` whose ``.data`` was re-pointed at a view does not share the buffer's):
+    ``pack`` looks at all of them, so an in-place write through ``model.parameters()`` -- a
+    torch optimizer, ``nn.init``, ``dist.broadcast(p)``, ``p.copy_()`` -- refreshes the mirrors."""
+    self._watched = [self.params] + [t for t in tensors if t is not self.params]
+
+  def _version(self):
+    return sum(t._version for t in self._watched)
+
   def pack(self, force=False):
-    """Refreshes the packed mirrors if the flat parameters changed (torch bumps
-    ``_version`` on every in-place write through any view; native steps call mark_dirty)."""
-    version = self.params._version
+    """Refreshes the packed mirrors if the parameters changed: torch bumps ``_version`` on
+    every in-place write (of the flat buffer and of each watched Parameter); native steps
+    write through raw pointers and call mark_dirty."""
+    version = self._version()
     if force or self._packed_version != version:
       _lib.call("dx_cnn_pack", ctypes.byref(self.ctx), _lib.stream_ptr(self.device))
       self._packed_version = version

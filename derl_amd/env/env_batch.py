@@ -11,8 +11,10 @@ that ``HostEnvBridge`` (bridge.py) can DMA them into the rollout buffer in HBM.
 Works with any env object that has ``reset()``, ``step(action)``, ``observation_space`` and
 ``action_space`` (gym is not required).
 """
-import gc
 import multiprocessing as mp
+import os
+import pickle
+import sys
 from multiprocessing import shared_memory
 
 import numpy as np
@@ -120,9 +122,49 @@ class SingleEnvBatch(EnvBatch):
     return np.asarray(self.env.reset())[None]
 
 
+class _Shipped:
+  """An env factory on its way to a worker started WITHOUT fork: factories are usually closures /
+  lambdas, which the standard pickle refuses, so they travel as cloudpickle bytes (by value) when
+  cloudpickle is importable and as a plain pickle otherwise (module-level callables only)."""
+  def __init__(self, fn):
+    self.fn = fn
+
+  def __getstate__(self):
+    try:
+      import cloudpickle  # pylint: disable=import-outside-toplevel
+      return cloudpickle.dumps(self.fn)
+    except ImportError:
+      return pickle.dumps(self.fn)
+
+  def __setstate__(self, payload):
+    self.fn = pickle.loads(payload)  # cloudpickle output is loadable by pickle
+
+  def __call__(self):
+    return self.fn()
+
+
+def _gpu_in_use():
+  """True once this process has initialised the GPU runtime.  Every HIP call of this package goes
+  through torch-allocated tensors, so torch's own flag covers the native library too."""
+  torch = sys.modules.get("torch")
+  return bool(torch is not None and torch.cuda.is_initialized())
+
+
+def worker_start_method():
+  """How env workers are created.  ``fork`` (cheap; closures work as they are) ONLY while this
+  process has not touched the GPU: a forked child of a GPU process inherits device objects whose
+  release -- by a garbage-collection pass, a dropped reference, an unwinding exception -- calls
+  into a HIP runtime that does not survive fork (a recorded segfault, round 1).  Afterwards
+  ``forkserver``: workers are forked from a clean server process that never saw the GPU and only
+  receive their (pickled) factory.  ``DERL_AMD_ENV_START_METHOD`` overrides the choice."""
+  forced = os.environ.get("DERL_AMD_ENV_START_METHOD")
+  if forced:
+    return forced
+  return "forkserver" if _gpu_in_use() else "fork"
+
+
 def _worker(conn, make_env, index):
   """Env process: observations go to shared memory, the rest through the pipe."""
-  gc.freeze()  # never finalise anything inherited from the parent (see ParallelEnvBatch.__init__)
   env = make_env()
   conn.send((env.observation_space, env.action_space))
   name, nenvs, shape, dtype = conn.recv()
@@ -154,28 +196,29 @@ def _worker(conn, make_env, index):
 
 
 class ParallelEnvBatch(EnvBatch):
-  """One process per env (env_batch.py:137-199); observations through shared memory."""
-  def __init__(self, make_env, nenvs=None):  # pylint: disable=super-init-not-called
+  """One process per env (env_batch.py:137-199); observations through shared memory.
+  ``start_method`` None picks ``worker_start_method()``."""
+  def __init__(self, make_env, nenvs=None, start_method=None):  # pylint: disable=super-init-not-called
     functions = _make_env_functions(make_env, nenvs)
     self._nenvs = len(functions)
-    ctx = mp.get_context("fork")  # env factories are usually closures
+    self.start_method = start_method or worker_start_method()
+    if self.start_method == "fork" and _gpu_in_use():
+      raise RuntimeError("refusing to fork env workers from a process that has initialised the GPU "
+                         "(inherited device objects crash the child); use forkserver or spawn")
+    ctx = mp.get_context(self.start_method)
+    if self.start_method == "forkserver":
+      # the server imports this module once; every worker is then a fork of the server
+      ctx.set_forkserver_preload([__name__])
+    if self.start_method != "fork":
+      functions = [_Shipped(fn) for fn in functions]
     self._conns, self._processes = [], []
-    # The parent may already hold device tensors.  A forked child must never run their
-    # finalisers (the HIP runtime is not usable after fork: a garbage-collection pass in the child
-    # that frees an inherited device tensor segfaults), so collect now, then park every live object
-    # in the permanent generation while forking; the children freeze again before doing anything.
-    gc.collect()
-    gc.freeze()
-    try:
-      for index, fn in enumerate(functions):
-        parent, child = ctx.Pipe()
-        proc = ctx.Process(target=_worker, args=(child, fn, index), daemon=True)
-        proc.start()
-        child.close()
-        self._conns.append(parent)
-        self._processes.append(proc)
-    finally:
-      gc.unfreeze()
+    for index, fn in enumerate(functions):
+      parent, child = ctx.Pipe()
+      proc = ctx.Process(target=_worker, args=(child, fn, index), daemon=True)
+      proc.start()
+      child.close()
+      self._conns.append(parent)
+      self._processes.append(proc)
     self._closed = False
     spaces = [conn.recv() for conn in self._conns]
     self.observation_space = SpaceBatch([s[0] for s in spaces])

@@ -19,6 +19,8 @@ class SyntheticAtariEnv:
   {-1,0,1}; resets Bernoulli(0.01) (derl/env/make_env.py:132-133 obs contract,
   derl/env/atari_wrappers.py:189-192 reward contract)."""
 
+  host_rng_free = True  # never touches the global np.random stream (see IterateWithMinibatches)
+
   def __init__(self, nenvs, num_actions=4, seed=0, obs_shape=(84, 84, 4), p_reset=0.01,
                device="cuda", rank=0):
     self.nenvs = int(nenvs)
@@ -59,6 +61,8 @@ class SyntheticMuJoCoEnv:
   """float32 (nenvs, obs_dim) N(0,1) observations clipped to +-10 (the range
   derl/env/mujoco_wrappers.py:64-124 Normalize produces), rewards N(0,1), resets
   Bernoulli(0.001)."""
+
+  host_rng_free = True  # draws from its own device generator only
 
   def __init__(self, nenvs, obs_dim=17, act_dim=6, seed=0, p_reset=0.001, device="cuda", rank=0):
     self.nenvs = int(nenvs)

@@ -6,7 +6,7 @@ from ..alg.common import Trainer
 from ..anneal import LinearAnneal
 from ..models import make_model
 from ..optim import RMSprop
-from ..policies import ActorCriticPolicy
+from ..policies import ActorCriticPolicy, sampling_seed
 from ..runners import env_runner, onpolicy, summary as runner_summary, trajectory_transforms
 from .factory import Factory
 
@@ -39,7 +39,7 @@ class A2CFactory(Factory):
     with self.override_context(**kwargs):
       model = self.get_arg("model") if self.has_arg("model") else make_model(
           env.observation_space, env.action_space, 1)
-      policy = ActorCriticPolicy(model)
+      policy = ActorCriticPolicy(model, seed=sampling_seed(env))
       steps = env_runner.EnvRunner(env, policy, self.get_arg("num_runner_steps"),
                                    nsteps=self.get_arg("num_train_steps"))
       logged = runner_summary.PeriodicSummaries.make_with_nlogs(steps, nlogs)

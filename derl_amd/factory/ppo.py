@@ -6,7 +6,7 @@ from ..alg.ppo import PPO
 from ..anneal import LinearAnneal
 from ..models import make_model
 from ..optim import Adam
-from ..policies import ActorCriticPolicy
+from ..policies import ActorCriticPolicy, sampling_seed
 from ..runners.onpolicy import make_ppo_runner
 from .factory import Factory
 
@@ -49,9 +49,9 @@ class PPOFactory(Factory):
     return super().from_args(args_type, ignore_unused, args)
 
   def _policy(self, env):
-    if self.has_arg("model"):
-      return ActorCriticPolicy(self.get_arg("model"))
-    return ActorCriticPolicy(make_model(env.observation_space, env.action_space, 1))
+    model = self.get_arg("model") if self.has_arg("model") else make_model(
+        env.observation_space, env.action_space, 1)
+    return ActorCriticPolicy(model, seed=sampling_seed(env))
 
   def make_runner(self, env, nlogs=1e5, **kwargs):
     with self.override_context(**kwargs):

@@ -29,6 +29,7 @@ class MlpEngine:
     ctx.params, ctx.grads, ctx.packed = (t.data_ptr() for t in (self.params, self.grads, self.packed))
     self._allocate_workspaces()
     self._packed_version = None
+    self._watched = [self.params]
 
   def _allocate_workspaces(self):
     ctx = self.ctx
@@ -77,8 +78,15 @@ class MlpEngine:
   def mark_dirty(self):
     self._packed_version = None
 
+  def watch(self, tensors):
+    """See CnnEngine.watch: Parameters aliasing the flat buffer keep their own version counter."""
+    self._watched = [self.params] + [t for t in tensors if t is not self.params]
+
+  def _version(self):
+    return sum(t._version for t in self._watched)
+
   def pack(self, force=False):
-    version = self.params._version
+    version = self._version()
     if force or self._packed_version != version:
       _lib.call("dx_mlp_pack", ctypes.byref(self.ctx), _lib.stream_ptr(self.device))
       self._packed_version = version

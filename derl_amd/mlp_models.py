@@ -72,6 +72,7 @@ class _MlpActorCritic(nn.Module):
         view.copy_(param.detach())
         param.data = view
         param.grad = gviews[name]
+    self.engine.watch(list(self.parameters()))
     self.engine.mark_dirty()
 
   def load_state_dict(self, state_dict, strict=True):

@@ -115,6 +115,7 @@ class NatureCNNModel(nn.Module):
           view.copy_(param.detach())
           param.data = view
           param.grad = gviews[f"{name}.{kind}"]
+    self.engine.watch(list(self.parameters()))
     self.engine.mark_dirty()
 
   def reserve(self, max_batch):

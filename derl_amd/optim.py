@@ -26,6 +26,10 @@ class _FlatOptimizer:
     self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.engine.device)
     self.param_groups = [dict(params=list(model.parameters()), lr=lr)]
     self._pending = []
+    if distributed.world_size() > 1:
+      # replicas start from rank 0's parameters whatever each process seeded its init with
+      distributed.broadcast_(self.engine.params)
+      self.engine.mark_dirty()
 
   def current_lr(self):
     return float(self.lr)

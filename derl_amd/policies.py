@@ -81,6 +81,18 @@ class ActorCriticPolicy(Policy):
     return bool(fused and fused(self, env, buffers, horizon))
 
 
+def sampling_seed(env):
+  """Seed of a policy's action-sampling stream for a given env shard: the env's own integer seed
+  when it has one (``derl.env.make`` folds the run seed and the data-parallel rank into it), else
+  the rank -- so the shards of a data-parallel run never draw the same uniforms for the same
+  local env index, and ``--seed`` reaches action sampling."""
+  from . import distributed  # pylint: disable=import-outside-toplevel
+  seed = getattr(getattr(env, "unwrapped", env), "seed", None)
+  if isinstance(seed, bool) or not isinstance(seed, int):
+    seed = 0
+  return (seed * 8191 + distributed.rank()) & 0x7FFFFFFFFFFFFFFF
+
+
 def numpy_like_input(observations):
   return isinstance(observations, np.ndarray) or (
       isinstance(observations, torch.Tensor) and not observations.is_cuda)

@@ -120,14 +120,18 @@ class IterateWithMinibatches(RunnerWrapper):
     return sample_size, device, orders, orders_dev
 
   def _prefetch_allowed(self):
-    """With the device-resident runner no env or policy code touches np.random during a rollout,
-    so the permutations of the NEXT rollout can be drawn (same stream order as the reference)
-    while the GPU still works on the current one -- otherwise the GPU idles ~1.5 ms per PPO
-    iteration behind np.random.permutation."""
+    """The permutations of the NEXT rollout may be drawn while the GPU still works on the current
+    one (otherwise it idles ~1.5 ms per PPO iteration behind np.random.permutation) only if that
+    cannot reorder the global np.random stream against the reference's: the runner is
+    device-resident AND the env declares ``host_rng_free`` (the built-in synthetic envs; a host
+    env behind HostEnvBridge / ParallelEnvBatch may draw from np.random inside ``step``, and then
+    the permutations must be drawn after the rollout, like the reference does)."""
     base = getattr(self.runner, "unwrapped", self.runner)
     check = getattr(base, "_device_resident", None)
     exhausted = getattr(base, "is_exhausted", None)
-    return check is not None and check() and exhausted is not None and not exhausted()
+    if check is None or not check() or exhausted is None or exhausted():
+      return False
+    return bool(getattr(getattr(base, "env", None), "host_rng_free", False))
 
   def run(self, obs=None):
     inner = self.runner.run(obs=obs)

@@ -135,9 +135,9 @@ def _cast_data(data, dtype):
   return out
 
 
-def _forward_dist(params, data, kind):
+def _forward_dist(params, data, kind, relu_masks=None):
   if kind == "cnn":
-    logits, values = nature_cnn_forward(params, data["observations"])
+    logits, values = nature_cnn_forward(params, data["observations"], relu_masks)
     log_prob, entropy, _ = categorical_log_prob_entropy(logits, data["actions"])
   else:
     mean, std, values = mujoco_forward(params, data["observations"])
@@ -147,7 +147,7 @@ def _forward_dist(params, data, kind):
 
 
 def ppo_loss_and_grads(params, data, kind="cnn", cliprange=0.1, value_loss_coef=0.25,
-                       entropy_coef=0.01, dtype=torch.float32):
+                       entropy_coef=0.01, dtype=torch.float32, relu_masks=None):
   """Full model forward + PPOLoss + autograd backward on CPU (ppo.py:100-108,
   common.py:68-70).  ``data`` holds observations, actions, log_prob, advantages,
   values (B,1), value_targets (B,1).  Returns (terms, grads dict keyed like params).
@@ -156,10 +156,10 @@ def ppo_loss_and_grads(params, data, kind="cnn", cliprange=0.1, value_loss_coef=
   for large batches, where some pre-activation inevitably lies within float32 rounding of
   zero and float32 evaluations with different summation orders disagree on its ReLU mask
   (measured: torch-CPU's NCHW and channels-last float32 paths differ on one unit at batch
-  130)."""
+  130).  ``relu_masks``: see ``nature_cnn_forward``."""
   leaf = _leaf_params(params, dtype)
   data = _cast_data(data, dtype)
-  log_prob, entropy, values = _forward_dist(leaf, data, kind)
+  log_prob, entropy, values = _forward_dist(leaf, data, kind, relu_masks)
   terms = ppo_loss_terms(log_prob, entropy, values, data["log_prob"], data["advantages"],
                          data["values"], data["value_targets"], cliprange,
                          value_loss_coef, entropy_coef)
@@ -170,11 +170,11 @@ def ppo_loss_and_grads(params, data, kind="cnn", cliprange=0.1, value_loss_coef=
 
 
 def a2c_loss_and_grads(params, data, kind="cnn", value_loss_coef=0.5, entropy_coef=0.01,
-                       dtype=torch.float32):
+                       dtype=torch.float32, relu_masks=None):
   """Full model forward + A2CLoss + autograd backward on CPU (a2c.py:68-79)."""
   leaf = _leaf_params(params, dtype)
   data = _cast_data(data, dtype)
-  log_prob, entropy, values = _forward_dist(leaf, data, kind)
+  log_prob, entropy, values = _forward_dist(leaf, data, kind, relu_masks)
   terms = a2c_loss_terms(log_prob, entropy, values, data["advantages"],
                          data["value_targets"], value_loss_coef, entropy_coef)
   terms["loss"].backward()

@@ -20,13 +20,19 @@ def _t(x):
   return x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x))
 
 
-def nature_cnn_forward(params, observations):
+def nature_cnn_forward(params, observations, relu_masks=None):
   """observations (B,84,84,4) uint8 or float -> list of head outputs.
 
   models.py:117-124: NHWC -> NCHW permute, uint8 -> float()/255, then
   conv(k8,s4)+ReLU, conv(k4,s2)+ReLU, conv(k3,s1)+ReLU, flatten (NCHW order),
   linear 3136->512 with NO ReLU after it (:112-115), then one linear per head
   (:198-202).  Returns [head_0, head_1, ...] with shapes (B, units).
+
+  ``relu_masks`` (three bool arrays, NCHW, one per conv layer) replaces each ReLU by a
+  multiplication with the given 0/1 mask: the same piecewise-linear function evaluated on a
+  PRESCRIBED branch.  Large-batch parity tests pass the masks the device kernels used, so that
+  a pre-activation within float32 rounding of zero (whose side depends on summation order)
+  does not decide the comparison; the tests separately bound how many units may differ.
   """
   x = _t(observations)
   x = x.permute(0, 3, 1, 2)
@@ -36,8 +42,9 @@ def nature_cnn_forward(params, observations):
   # large batches (the float32 dequantisation above is kept: it is part of the semantics)
   x = x.to(_t(params["base.conv-0.weight"]).dtype).contiguous()
   for i, stride in enumerate((4, 2, 1)):
-    x = F.relu(F.conv2d(x, _t(params[f"base.conv-{i}.weight"]),
-                        _t(params[f"base.conv-{i}.bias"]), stride=stride))
+    x = F.conv2d(x, _t(params[f"base.conv-{i}.weight"]),
+                 _t(params[f"base.conv-{i}.bias"]), stride=stride)
+    x = F.relu(x) if relu_masks is None else x * _t(relu_masks[i]).to(x.dtype)
   x = torch.flatten(x, 1)
   hidden = F.linear(x, _t(params["base.linear.weight"]), _t(params["base.linear.bias"]))
   outputs = []

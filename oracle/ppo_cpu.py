@@ -148,16 +148,29 @@ def available_cores():
   return min(cores, int(os.environ.get("DERL_AMD_CPU_THREADS", "16")))
 
 
-def time_cpu_baseline(nenvs=256, nsteps=32, iterations=1, threads=None, **kwargs):
-  """Returns dict(value env-steps/s, seconds, cores, sample)."""
+def time_cpu_baseline(nenvs=256, nsteps=128, iterations=3, warmup=1, threads=None, budget_s=None,
+                      **kwargs):
+  """BASELINE.md section 3.1 protocol: same shapes as the GPU run, ``warmup`` untimed iteration(s)
+  then ``iterations`` timed ones on ``threads`` host cores (default: every core this process may
+  use).  ``budget_s`` bounds the timed part on a slow box: the number of timed iterations is cut
+  (never below 1) so that it fits, and the returned ``sample`` string says what was run.
+  Returns dict(value env-steps/s, seconds, cores, sample, iterations, warmup)."""
   threads = threads or available_cores()
   ppo = CpuPPO(nenvs=nenvs, nsteps=nsteps, threads=threads, **kwargs)
+  warm_seconds = 0.0
+  for _ in range(warmup):
+    start = time.perf_counter()
+    ppo.iteration()
+    warm_seconds = time.perf_counter() - start
+  if budget_s is not None and warmup and warm_seconds > 0:
+    iterations = max(1, min(iterations, int(budget_s / warm_seconds)))
   start = time.perf_counter()
   for _ in range(iterations):
     ppo.iteration()
   seconds = time.perf_counter() - start
   steps = iterations * nenvs * nsteps
-  return dict(value=steps / seconds, seconds=seconds, cores=threads,
-              sample=f"{iterations} PPO iteration(s) of nenvs={nenvs} x nsteps={nsteps} "
-                     f"(3 epochs x 4 minibatches of {nenvs * nsteps // 4}), NatureCNN, "
-                     "synthetic frames, torch-CPU fp32")
+  return dict(value=steps / seconds, seconds=seconds, cores=threads, iterations=iterations,
+              warmup=warmup,
+              sample=f"{warmup} warm-up + {iterations} timed PPO iteration(s) of nenvs={nenvs} x "
+                     f"nsteps={nsteps} (3 epochs x 4 minibatches of {nenvs * nsteps // 4}), NatureCNN, "
+                     f"synthetic frames, torch-CPU fp32 on {threads} threads")

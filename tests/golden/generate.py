@@ -118,8 +118,24 @@ class FakeRunner:
     self.step_count = step_count
 
 
-def gen_steps():
+def relu_margin(model, observations):
+  """Smallest |conv pre-activation| relative to its layer's largest one (float64 evaluation of
+  the reference model's CURRENT weights): how far the closest ReLU unit is from changing side."""
+  import torch.nn.functional as F
+  weights = {k: v.detach().double() for k, v in model.state_dict().items()}
+  x = (torch.from_numpy(observations).permute(0, 3, 1, 2).float() / 255).double().contiguous()
+  margin = np.inf
+  for i, stride in enumerate((4, 2, 1)):
+    x = F.conv2d(x, weights[f"base.conv-{i}.weight"], weights[f"base.conv-{i}.bias"], stride=stride)
+    margin = min(margin, float(x.abs().min() / x.abs().max()))
+    x = F.relu(x)
+  return margin
+
+
+def gen_steps(only=None):
   for name, cfg in gi.STEP_CASES.items():
+    if only is not None and name not in only:
+      continue
     out = {}
     if cfg["kind"] == "cnn":
       model = load_cnn(cfg["num_actions"], cfg["seed"])
@@ -186,6 +202,9 @@ def gen_steps():
       # rollout boundary between step 1 and 2 so the LR changes once
       if step == 2:
         alg.runner.step_count += 4096
+      if "min_relu_margin" in cfg:
+        out[f"relu_margin.{step}"] = np.float64(relu_margin(model, mb["observations"]))
+        assert out[f"relu_margin.{step}"] >= cfg["min_relu_margin"], (name, step, out[f"relu_margin.{step}"])
       losses.append(alg.step(data).item())
       out[f"lr.{step}"] = np.float32(lr.get_tensor().item())
       for pname, p in model.named_parameters():
@@ -311,6 +330,9 @@ def copy_upstream_fixtures():
 
 
 if __name__ == "__main__":
+  if len(sys.argv) > 1:  # python generate.py <step case> ...: only those fixtures
+    gen_steps(only=sys.argv[1:])
+    sys.exit(0)
   gen_gae()
   gen_act()
   gen_steps()

@@ -37,3 +37,33 @@ def test_minibatch_advantage_statistics_with_one_all_reduce_per_rollout():
 @pytest.mark.gpu
 def test_two_rank_data_parallel_ppo_learns_and_replicas_stay_identical():
   launch("gpu_learns", 29514)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_reports_ranks_seen_and_refuses_non_rccl_backend():
+  """bench.py under torch.distributed.run: the JSON line carries what lets a reader check the
+  multi-GPU run (ranks_seen from an all-reduce of ones, the backend, the all-reduce bytes per
+  update).  Two ranks share this box's one GPU, so the backend is gloo: refused without
+  --allow-gloo (a scaling number must come from RCCL), accepted as a rehearsal with it."""
+  import json
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", DERL_AMD_DIST_BACKEND="gloo")
+  base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+          "--master-addr", "127.0.0.1", "--master-port", "29515", os.path.join(ROOT, "bench.py"),
+          "--gpus", "2", "--steps", "1", "--warmup", "1", "--nenvs", "16", "--nsteps", "8",
+          "--no-roofline", "--no-cpu-baseline"]
+  refused = subprocess.run(base, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert refused.returncode != 0 and "RCCL" in refused.stderr + refused.stdout
+  out = subprocess.run(base + ["--allow-gloo"], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, out.stdout[-2000:]
+  d = json.loads(lines[0])
+  cfg = d["config"]
+  assert d["n_gpus"] == 2 and cfg["ranks_seen"] == 2 and cfg["backend"] == "gloo"
+  assert cfg["nenvs_per_gpu"] == 8 and cfg["parallelism"] == "dp2" and d["scaling"] == "strong"
+  reduce = cfg["allreduce_bytes_per_update"]
+  assert reduce["issued"] and reduce["gradient_total"] == 4 * 1_686_693 == sum(reduce["pieces"])
+  mismatch = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                            env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert mismatch.returncode != 0 and "WORLD_SIZE" in mismatch.stderr

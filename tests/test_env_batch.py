@@ -36,10 +36,14 @@ def test_single_env_batch_matches_reference():
   check(SingleEnvBatch(ScriptedEnv(9, 4)), 1, "single")
 
 
-@pytest.mark.parametrize("shared", [False, True])
-def test_parallel_env_batch_matches_reference(shared):
-  batch = ParallelEnvBatch(factories())
+@pytest.mark.parametrize("shared,start_method", [(False, None), (True, None), (False, "forkserver"),
+                                                 (True, "spawn")])
+def test_parallel_env_batch_matches_reference(shared, start_method):
+  """fork (the default while the process has not touched the GPU) and the fork-free start methods
+  a GPU process must use: closures travel to the workers by value (cloudpickle)."""
+  batch = ParallelEnvBatch(factories(), start_method=start_method)
   try:
+    assert batch.start_method == (start_method or "fork")
     assert batch.nenvs == 4 and batch.observation_space.shape == (3,)
     if shared:
       check(batch, 4, "parallel", step="step_shared", reset="reset_shared")
@@ -88,3 +92,16 @@ def test_space_batch_checks():
     SpaceBatch([Other((3,), np.float32), a])
   space = SpaceBatch([_PlainSpace((), np.int64, n=5)] * 2)
   assert space.n == 5 and space.shape == () and space.sample().shape == (2,)
+
+
+def test_worker_start_method_follows_gpu_state(monkeypatch):
+  """fork only while the GPU runtime is untouched; forkserver afterwards; env override wins; an
+  explicit fork from a GPU process is refused."""
+  from derl_amd.env import env_batch
+  assert env_batch.worker_start_method() == "fork"  # the CPU suite never initialises the GPU
+  monkeypatch.setattr(env_batch, "_gpu_in_use", lambda: True)
+  assert env_batch.worker_start_method() == "forkserver"
+  with pytest.raises(RuntimeError, match="refusing to fork"):
+    ParallelEnvBatch(factories(), start_method="fork")
+  monkeypatch.setenv("DERL_AMD_ENV_START_METHOD", "spawn")
+  assert env_batch.worker_start_method() == "spawn"

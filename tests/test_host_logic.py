@@ -128,3 +128,42 @@ def test_env_runner_generic_contract_matches_reference():
   assert wrapped.horizon == 6 and wrapped.nenvs == 4
   with pytest.raises(AttributeError):
     wrapped.no_such_attribute  # pylint: disable=pointless-statement
+
+
+def test_derl_import_name_is_an_alias_not_a_copy():
+  """`import derl` (the reference's import name) binds the SAME module objects as derl_amd."""
+  import derl
+  import derl_amd
+  import derl.env
+  import derl.runners.onpolicy as aliased
+  import derl_amd.runners.onpolicy as real
+  from derl.alg.ppo import PPOLoss
+  assert derl.PPOFactory is derl_amd.PPOFactory and PPOLoss is derl_amd.PPOLoss
+  assert aliased is real and derl.env is derl_amd.env
+
+
+def test_package_installs_with_launcher(tmp_path):
+  """setup.py (reference: setup.py:11-12): `pip install .` offline into a scratch target gives the
+  packages, the native library and an executable `derl` launcher."""
+  import os
+  import shutil
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  target = tmp_path / "site"
+  try:
+    out = subprocess.run([sys.executable, "-m", "pip", "install", "--no-deps", "--no-build-isolation",
+                          "--no-index", "--quiet", "--target", str(target), root],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+  finally:
+    for left in ("build", "derl_amd.egg-info"):
+      shutil.rmtree(os.path.join(root, left), ignore_errors=True)
+  assert (target / "derl_amd" / "libderl_amd.so").exists() and (target / "derl" / "__init__.py").exists()
+  env = dict(os.environ, PYTHONPATH=str(target))
+  usage = subprocess.run([sys.executable, str(target / "bin" / "derl"), "dqn"], capture_output=True,
+                         text=True, cwd=str(tmp_path), env=env, timeout=300)
+  assert usage.returncode == 2 and "a2c" in usage.stderr and "ppo" in usage.stderr
+  where = subprocess.run([sys.executable, "-c", "import derl; print(derl.__file__)"], capture_output=True,
+                         text=True, cwd=str(tmp_path), env=env, timeout=300)
+  assert where.stdout.strip().startswith(str(target)), where.stdout + where.stderr

@@ -46,7 +46,7 @@ def build_case(name):
   return cfg, g, names, data, model, alg, lr
 
 
-@pytest.mark.parametrize("name", ["ppo_step_cnn", "a2c_step_cnn"])
+@pytest.mark.parametrize("name", ["ppo_step_cnn", "a2c_step_cnn", "a2c_step_cnn_late"])
 def test_trainer_steps_match_reference_golden(name):
   """alg/test.py:35-69 style: gradients after loss.backward(), then consecutive alg.step
   losses, learning rates and post-step parameters against the reference's own run."""
@@ -201,34 +201,120 @@ def test_minibatch_order_matches_reference():
       assert f"{tag}.{count}" not in g.files
 
 
-def test_a2c_factory_config5_shape_runs_and_matches_oracle_first_step():
-  """A2C (BASELINE config 5 shape, scaled down): nsteps=5, lambda=1, no minibatching, RMSprop.
-  The first update's loss equals the oracle's A2C loss on the same rollout."""
+@pytest.mark.parametrize("nenvs", [64, 512])  # 512 = the per-GPU shard of BASELINE config 5
+def test_a2c_factory_config5_shard_matches_oracle_update(nenvs):
+  """A2C at BASELINE config 5's shape (nenvs 4096 x nsteps 5 over 8 GPUs = 512 x 5 = 2560
+  samples per GPU; lambda 1, no minibatching, RMSprop): GAE on the rollout, the first update's
+  loss, its clipped gradients and the post-step parameters against the oracle evaluated on the
+  same rollout (float64, on the ReLU branch the engine took -- see test_cnn_gpu)."""
   import derl_amd as derl
+  from tests.test_cnn_gpu import engine_relu_masks, mask_disagreement, count_ambiguous_relu_units
   derl.summary.stop_recording()
   torch.manual_seed(0)
-  env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=64, seed=3)
+  env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=nenvs, seed=3)
   kwargs = derl.A2CFactory.get_kwargs()
-  kwargs.update(nenvs=64, num_train_steps=64 * 5 * 3)
+  kwargs.update(nenvs=nenvs, num_train_steps=nenvs * 5 * 3)
   alg = derl.A2CFactory(**kwargs).make(env)
+  engine = alg.model.engine
   weights0 = {k: v.detach().cpu().numpy().copy() for k, v in alg.model.state_dict().items()}
+  names = list(weights0)
   losses = []
+  batch = nenvs * 5
   for i, data in enumerate(alg.runner.run()):
-    assert data["observations"].shape == (320, 84, 84, 4) and data["advantages"].shape == (320,)
+    assert data["observations"].shape == (batch, 84, 84, 4) and data["advantages"].shape == (batch,)
     if i == 0:
       host = {k: v.cpu().numpy() for k, v in data.items() if isinstance(v, torch.Tensor)}
-      terms, _ = oracle.a2c_loss_and_grads(weights0, host, "cnn", 0.5, 0.01)
       buf = alg.runner.unwrapped._buffers
       logits, last = oracle.nature_cnn_forward(weights0, buf["obs"][5].cpu().numpy())
       adv_ref, vt_ref = oracle.gae_advantages(buf["rewards"].cpu().numpy(), buf["resets"].cpu().numpy(),
                                               buf["values"].cpu().numpy(), last.numpy(), 0.99, 1.0)
       nt.assert_allclose(host["advantages"], adv_ref.reshape(-1), rtol=1e-4, atol=1e-4)
       nt.assert_allclose(host["value_targets"], vt_ref.reshape(-1, 1), rtol=1e-4, atol=1e-4)
+      step_count = alg.runner.step_count
     losses.append(alg.step(data).item())
     if i == 0:
-      nt.assert_allclose(losses[0], terms["loss"], rtol=1e-4, atol=1e-5)
-  assert len(losses) == 3 and np.all(np.isfinite(losses)) and alg.runner.step_count == 960
+      masks = engine_relu_masks(engine, batch)
+      flipped, worst = mask_disagreement(weights0, host["observations"], masks)
+      assert worst < 3e-6 and flipped <= count_ambiguous_relu_units(weights0, host["observations"])
+      terms, grads = oracle.a2c_loss_and_grads(weights0, host, "cnn", 0.5, 0.01,
+                                               dtype=torch.float64, relu_masks=masks)
+      nt.assert_allclose(losses[0], terms["loss"], rtol=1e-5, atol=1e-5)  # a2c_test.py:27 is 1e-4
+      clipped, norm = oracle.clip_grad_norm([grads[k] for k in names], 0.5)
+      nt.assert_allclose(alg.trainer.optimizer.grad_norm.item(), norm, rtol=1e-5)
+      got = engine.named_views(engine.grads)  # the fused step writes the clipped gradient back
+      lr = oracle.linear_anneal(7e-4, nenvs * 5 * 3, step_count)
+      assert lr == np.float32(alg.trainer.optimizer.current_lr())
+      after = alg.model.state_dict()
+      for k, g in zip(names, clipped):
+        scale = np.abs(g).max()
+        nt.assert_allclose(got[k].cpu().numpy(), g, rtol=1e-4, atol=1e-5 * scale + 1e-9, err_msg=k)
+        expect, _ = oracle.rmsprop_step(weights0[k], g, np.zeros_like(g), lr, 0.99, 1e-5)
+        nt.assert_allclose(after[k].cpu().numpy(), expect, rtol=0, atol=2e-6, err_msg=k)
+  assert len(losses) == 3 and np.all(np.isfinite(losses)) and alg.runner.step_count == nenvs * 15
   assert alg.trainer.optimizer.step_count == 3
+
+
+def test_ppo_factory_config3_first_epoch_matches_oracle():
+  """BASELINE config 3 end to end: PPO HalfCheetah-v3 nenvs 2048 x nsteps 64 through PPOFactory
+  (mujoco preset: 10 epochs x 32 minibatches of 4096, Gaussian MLP policy, Adam).  The first
+  epoch's 32 updates against the oracle stepping the SAME minibatches in the same order from the
+  same initial weights: minibatch order = the reference's shuffle of the rollout
+  (runners/onpolicy.py:44-62), normalised advantages, every loss, the learning rate and the
+  parameters after the 32 steps."""
+  import derl_amd as derl
+  derl.summary.stop_recording()
+  torch.manual_seed(0)
+  np.random.seed(7)
+  nenvs, horizon, nmb = 2048, 64, 32
+  env = derl.env.make("HalfCheetah-v3", nenvs=nenvs, seed=1)
+  kwargs = derl.PPOFactory.get_kwargs("mujoco")
+  kwargs.update(nenvs=nenvs, num_runner_steps=horizon, num_train_steps=nenvs * horizon * 2)
+  assert kwargs["num_epochs"] == 10 and kwargs["num_minibatches"] == nmb
+  alg = derl.PPOFactory(**kwargs).make(env)
+  names = [k for k, _ in alg.model.named_parameters()]
+  params = {k: v.detach().cpu().numpy().astype(np.float32).copy()
+            for k, v in alg.model.state_dict().items()}
+  state = {k: dict(m=np.zeros_like(v), v=np.zeros_like(v)) for k, v in params.items()}
+  np.random.seed(7)
+  order = next(iter(oracle.minibatch_indices(nenvs * horizon, 1, 1)))[2]  # epoch 0's permutation
+  np.random.seed(7)
+  worst = 0.0
+  for i, data in enumerate(alg.runner.run()):
+    if i == nmb:
+      break
+    assert data["actions"].shape == (4096, 6) and data["observations"].shape == (4096, 17)
+    host = {k: (v.materialize() if isinstance(v, derl.GatheredRows) else v).cpu().numpy()
+            for k, v in data.items() if isinstance(v, (torch.Tensor, derl.GatheredRows))}
+    if i == 0:
+      buf = alg.runner.unwrapped._buffers
+      rollout = {k: buf[k].reshape((nenvs * horizon,) + tuple(buf[k].shape[2:])).cpu().numpy()
+                 for k in ("actions", "log_prob", "values")}
+      raw_adv, _ = oracle.gae_advantages(
+          buf["rewards"].cpu().numpy(), buf["resets"].cpu().numpy(), buf["values"].cpu().numpy(),
+          alg.runner.policy.act(buf["obs"][horizon])["values"].cpu().numpy(), 0.99, 0.95)
+      raw_adv = raw_adv.reshape(-1)
+      step_count = alg.runner.step_count
+      assert step_count == nenvs * horizon
+    idx = order[i * 4096:(i + 1) * 4096]
+    for k in ("actions", "log_prob", "values"):  # the reference's shuffle-then-slice
+      nt.assert_array_equal(host[k], rollout[k][idx], err_msg=k)
+    nt.assert_allclose(host["advantages"], oracle.normalize_advantages(raw_adv[idx]),
+                       rtol=1e-4, atol=2e-5)
+    loss = alg.step(data).item()
+    terms, grads = oracle.ppo_loss_and_grads(params, host, "mlp", 0.2, 0.25, 0.0)
+    nt.assert_allclose(loss, terms["loss"], rtol=1e-4, atol=1e-5, err_msg=f"minibatch {i}")
+    worst = max(worst, abs(loss - terms["loss"]) / max(abs(terms["loss"]), 1e-3))
+    clipped, _ = oracle.clip_grad_norm([grads[k] for k in names], 0.5)
+    lr = oracle.linear_anneal(3e-4, nenvs * horizon * 2, step_count)
+    assert lr == np.float32(alg.trainer.optimizer.current_lr())
+    for k, g in zip(names, clipped):
+      params[k], state[k]["m"], state[k]["v"] = oracle.adam_step(
+          params[k], g, state[k]["m"], state[k]["v"], i + 1, lr, eps=1e-5)
+  assert alg.trainer.step_count == nmb
+  after = alg.model.state_dict()
+  for k in names:  # 32 Adam steps of <= lr each: differences stay at rounding level
+    nt.assert_allclose(after[k].cpu().numpy(), params[k], rtol=0, atol=2e-5, err_msg=k)
+  print("config 3 first epoch: worst relative loss deviation", worst)
 
 
 def test_cli_entry_point_runs_ppo(tmp_path):
@@ -336,3 +422,47 @@ def test_a2c_cnn_learns_image_bandit():
   curve, _ = run(iterations=300, nenvs=64, horizon=5, seed=0, lr=1e-4, algorithm="a2c")
   assert np.mean(curve[:5]) < 0.6, curve[:5]
   assert np.mean(curve[-20:]) > 0.9, curve[-20:]
+
+
+@pytest.mark.parametrize("kind", ["cnn", "mlp"])
+def test_inplace_writes_through_parameters_refresh_packed_weights(kind):
+  """A Parameter re-pointed at a view of the flat buffer keeps its OWN version counter, so the
+  engines watch every Parameter: writes through model.parameters() by a torch optimizer,
+  nn.init, p.copy_() ... must reach the packed mirrors the kernels read (forward == oracle on
+  the new weights, every time)."""
+  import derl_amd as derl
+  torch.manual_seed(0)
+  if kind == "cnn":
+    model = derl.NatureCNNModel([4, 1], max_batch=16)
+    obs = gi.frames(8, 3)
+    reference = lambda w: [o.numpy() for o in oracle.nature_cnn_forward(w, obs)]
+  else:
+    model = derl.MuJoCoModel(17, [6, 1])
+    obs = gi.mlp_minibatch(8, 17, 6, 3)["observations"]
+    reference = lambda w: [o.numpy() for o in oracle.mujoco_forward(w, obs)[::2]]
+
+  def check(what):
+    outs = model(obs)
+    first, last = (outs[0], outs[-1]) if kind == "cnn" else (outs[0], outs[2])
+    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    expect = reference(weights)
+    nt.assert_allclose(first.detach().cpu().numpy(), expect[0], rtol=1e-4, atol=2e-5, err_msg=what)
+    nt.assert_allclose(last.detach().cpu().numpy(), expect[1], rtol=1e-4, atol=2e-5, err_msg=what)
+    return first.detach().clone()
+
+  before = check("initial")
+  sgd = torch.optim.SGD(model.parameters(), lr=0.5)
+  for p in model.parameters():
+    p.grad.copy_(torch.randn_like(p) * 0.05)
+  sgd.step()
+  after = check("torch.optim.SGD.step on model.parameters()")
+  assert (after - before).abs().max().item() > 1e-3
+  with torch.no_grad():
+    for p in model.parameters():
+      if p.ndim >= 2:
+        torch.nn.init.normal_(p, std=0.03)
+  again = check("nn.init on the parameters")
+  assert (again - after).abs().max().item() > 1e-4
+  with torch.no_grad():
+    next(iter(model.parameters())).mul_(0.5)
+  check("in-place op on one parameter")

@@ -4,6 +4,7 @@
 set -e
 TAG=$1; BATCH=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for group in "$@"; do

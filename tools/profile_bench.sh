@@ -5,6 +5,7 @@
 set -e
 TAG=${1:-prof}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o bench -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.json
