@@ -42,6 +42,19 @@ bool conv0_f32() {  // DX_CONV0_F32=1: first layer on the fp32 matrix instructio
   return v != 0;
 }
 
+// DX_WGRAD_DIRECT=0: conv1 / conv2 weight gradients on the implicit-GEMM kernel instead of the
+// image-resident one (wgrad_direct.hip); DX_WGRAD_DIRECT_MIN_B: smallest batch routed to it
+bool wgrad_direct_on() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_WGRAD_DIRECT"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+int wgrad_direct_min_batch() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_WGRAD_DIRECT_MIN_B"); v = e ? atoi(e) : 512; }
+  return v;
+}
+
 int roundup(long long v, int m) { return static_cast<int>((v + m - 1) / m * m); }
 
 // reduction split of a wgrad over its M rows: ~5 workgroups per CU (2 per CU measured 41 %
@@ -63,6 +76,7 @@ void pick_msplit(long long M, int blocks_kn, int min_rows, int *msplit, int *mpe
 
 struct SlabPlan {
   int msplit, mper;
+  int direct;  // conv1 / conv2: image-resident wgrad with `msplit` persistent workgroups
   long long w_off, b_off;  // offsets (floats) of the weight / bias slabs inside ctx->slabs
 };
 
@@ -104,6 +118,13 @@ static long long layer_rows(const dx_cnn_ctx *c, int layer, long long B) {
   }
 }
 
+static bool layer_direct_supported(const dx_cnn_ctx *c, int layer) {
+  if (!wgrad_direct_on()) return false;
+  if (layer == L_C1) return wgrad_direct_supported(c->h0, c->w0, kC0, c->h1, c->w1, kC1, 4, 4, 2);
+  if (layer == L_C2) return wgrad_direct_supported(c->h1, c->w1, kC1, c->h2, c->w2, kC2, 3, 3, 1);
+  return false;
+}
+
 static Plan make_plan(const dx_cnn_ctx *c, long long B) {
   Plan p;
   long long off = 0;
@@ -112,8 +133,17 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
     layer_nk(c, l, &N, &K, &bkn);
     // capacity (offsets) from max_batch, split from the actual batch
     const int min_rows = l == L_HD ? 64 : 256;
-    const long long ms_cap = msplit_bound(layer_rows(c, l, c->max_batch), bkn, min_rows);
+    long long ms_cap = msplit_bound(layer_rows(c, l, c->max_batch), bkn, min_rows);
     pick_msplit(layer_rows(c, l, B), bkn, min_rows, &p.s[l].msplit, &p.s[l].mper);
+    p.s[l].direct = 0;
+    if (layer_direct_supported(c, l)) {
+      const int nwg = wgrad_direct_workgroups(l == L_C1 ? ST_CONV1_WGRAD : ST_CONV2_WGRAD);
+      if (ms_cap < nwg) ms_cap = nwg;
+      if (B >= wgrad_direct_min_batch()) {
+        p.s[l].direct = 1;
+        p.s[l].msplit = static_cast<int>(B < nwg ? B : nwg);
+      }
+    }
     if (l == L_C0) {  // one slab per persistent workgroup of the direct conv0 wgrad (<= 512)
       const long long tiles = (layer_rows(c, l, B) + 255) / 256;
       p.s[l].msplit = static_cast<int>(tiles < 512 ? tiles : 512);
@@ -426,6 +456,11 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a.mask_src = c->y2;
       return launch_nt(a, false, EPI_MASK, stage, s);
     case ST_CONV2_WGRAD:
+      if (plan.s[L_C2].direct) {
+        const WgradDirectArgs d{c->y1, c->dy2, c->slabs + plan.s[L_C2].w_off, c->slabs + plan.s[L_C2].b_off,
+                                B, c->h1, c->w1, c->h2, c->w2, 0};
+        return launch_wgrad_direct(d, stage, plan.s[L_C2].msplit, s);
+      }
       return tn(L_C2, conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), c->dy2, kC2, M2,
                 kC2, 9 * kC1, false);
     case ST_CONV2_DGRAD:
@@ -436,6 +471,11 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       if (const int rc = launch_nt_pix(a, B, EPI_MASK, stage, s); rc != DX_ENOSUP) return rc;
       return launch_nt(a, false, EPI_MASK, stage, s);
     case ST_CONV1_WGRAD:
+      if (plan.s[L_C1].direct) {
+        const WgradDirectArgs d{c->y0, c->dy1, c->slabs + plan.s[L_C1].w_off, c->slabs + plan.s[L_C1].b_off,
+                                B, c->h0, c->w0, c->h1, c->w1, 0};
+        return launch_wgrad_direct(d, stage, plan.s[L_C1].msplit, s);
+      }
       return tn(L_C1, conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), c->dy1, kC1, M1,
                 kC1, 16 * kC0, false);
     case ST_CONV1_DGRAD: {

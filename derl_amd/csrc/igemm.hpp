@@ -134,6 +134,20 @@ int launch_fc_pack(const float *W, float *fcf, float *fcd, int N, int P, int C, 
 int launch_fc_grad_finalize(const float *slab, int nslab, long long slab_stride, float *grad, int N, int P,
                             int C, hipStream_t stream);
 
+// image-resident weight gradients of the 4x4/2 and 3x3/1 convolutions (wgrad_direct.hip): one
+// persistent workgroup per slab, x = layer input [B][IH][IW][IC], g = output gradient [B][OH][OW][OC]
+struct WgradDirectArgs {
+  const float *x;
+  const float *g;
+  float *slab;       // [workgroups][OC][KH*KW*IC]
+  float *bias_slab;  // [workgroups][OC]
+  int B, IH, IW, OH, OW;
+  int diag;  // timing experiments only (DX_WD_DIAG): bit 0 copy only the first image, bit 1 skip the slab store
+};
+bool wgrad_direct_supported(int IH, int IW, int IC, int OH, int OW, int OC, int KH, int KW, int S);
+int launch_wgrad_direct(const WgradDirectArgs &a, int stage, int nwg, hipStream_t stream);
+int wgrad_direct_workgroups(int stage);  // persistent workgroups that fill the chip for this layer
+
 // direct first-layer convolution on uint8 frames (conv0.hip)
 struct Conv0Args {
   const uint8_t *obs;     // (imgs, in_h, in_w, 4) uint8
