@@ -42,8 +42,9 @@ bool conv0_f32() {  // DX_CONV0_F32=1: first layer on the fp32 matrix instructio
   return v != 0;
 }
 
-// DX_WGRAD_DIRECT=0: conv1 / conv2 weight gradients on the implicit-GEMM kernel instead of the
-// image-resident one (wgrad_direct.hip); DX_WGRAD_DIRECT_MIN_B: smallest batch routed to it
+// DX_WGRAD_DIRECT=0: conv1 / conv2 / linear-layer weight gradients on the implicit-GEMM kernel
+// instead of the dedicated ones (wgrad_direct.hip, wgrad_fc.hip); DX_WGRAD_DIRECT_MIN_B: smallest
+// batch routed to them
 bool wgrad_direct_on() {
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_WGRAD_DIRECT"); v = e ? atoi(e) : 1; }
@@ -54,6 +55,8 @@ int wgrad_direct_min_batch() {
   if (v < 0) { const char *e = getenv("DX_WGRAD_DIRECT_MIN_B"); v = e ? atoi(e) : 512; }
   return v;
 }
+
+constexpr int kBiasChunks = 256;  // row chunks of the linear layer's bias-gradient launch (512 workgroups)
 
 int roundup(long long v, int m) { return static_cast<int>((v + m - 1) / m * m); }
 
@@ -76,7 +79,9 @@ void pick_msplit(long long M, int blocks_kn, int min_rows, int *msplit, int *mpe
 
 struct SlabPlan {
   int msplit, mper;
-  int direct;  // conv1 / conv2: image-resident wgrad with `msplit` persistent workgroups
+  int bsplit;  // bias-gradient partials (= msplit unless the bias comes from its own launch)
+  int direct;  // conv1 / conv2: image-resident wgrad with `msplit` persistent workgroups;
+               // linear layer: wgrad_fc.hip with `msplit` row slices
   long long w_off, b_off;  // offsets (floats) of the weight / bias slabs inside ctx->slabs
 };
 
@@ -136,6 +141,18 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
     long long ms_cap = msplit_bound(layer_rows(c, l, c->max_batch), bkn, min_rows);
     pick_msplit(layer_rows(c, l, B), bkn, min_rows, &p.s[l].msplit, &p.s[l].mper);
     p.s[l].direct = 0;
+    p.s[l].bsplit = 0;  // 0 = msplit (set below)
+    long long b_cap = 0;  // bias partials beyond the weight slabs' count
+    if (l == L_FC && wgrad_direct_on()) {  // capacity for the dedicated kernel's slices / bias chunks
+      const long long slices = fc_wgrad_slices(c->max_batch >= 256 ? c->max_batch : 256, K);
+      if (ms_cap < slices) ms_cap = slices;
+      b_cap = kBiasChunks;
+      if (B >= wgrad_direct_min_batch() && fc_wgrad_supported(static_cast<int>(B), N, K)) {
+        p.s[l].direct = 1;
+        p.s[l].msplit = fc_wgrad_slices(static_cast<int>(B), K);
+        p.s[l].bsplit = kBiasChunks;
+      }
+    }
     if (layer_direct_supported(c, l)) {
       const int nwg = wgrad_direct_workgroups(l == L_C1 ? ST_CONV1_WGRAD : ST_CONV2_WGRAD);
       if (ms_cap < nwg) ms_cap = nwg;
@@ -149,10 +166,11 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
       p.s[l].msplit = static_cast<int>(tiles < 512 ? tiles : 512);
       p.s[l].mper = roundup((layer_rows(c, l, B) + p.s[l].msplit - 1) / p.s[l].msplit, 32);
     }
+    if (p.s[l].bsplit == 0) p.s[l].bsplit = p.s[l].msplit;
     p.s[l].w_off = off;
     off += ms_cap * N * K;
     p.s[l].b_off = off;
-    off += ms_cap * N;
+    off += (b_cap > ms_cap ? b_cap : ms_cap) * N;
     off = (off + 63) / 64 * 64;
   }
   p.total = off;
@@ -343,7 +361,7 @@ static int finalize_grads(const dx_cnn_ctx *c, const Plan &plan, int which, hipS
   };
   auto addb = [&](int layer, long long off_dst, long long total, long long off, int N) {
     j[n++] = PermuteJob{c->slabs + plan.s[layer].b_off, g + off_dst, total, 1, 1, 1, 1, 0, 0, 0, off,
-                        plan.s[layer].msplit, N, 0};
+                        plan.s[layer].bsplit, N, 0};
   };
   if (which & 1) {
     // conv: iterate the slab [oc][kh][kw][ic] in its own order (coalesced slab reads) and
@@ -449,6 +467,11 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a = nt_args(rows_gather(c->dhead, kHeadLd), pk + c->pk_hdd, nullptr, c->dhid, kHid, B, kHid, kHeadLd);
       return launch_nt(a, false, EPI_NONE, stage, s);
     case ST_FC_WGRAD:
+      if (plan.s[L_FC].direct) {
+        if (int rc = launch_colsum(c->dhid, c->slabs + plan.s[L_FC].b_off, B, kHid, plan.s[L_FC].bsplit, s)) return rc;
+        const FcWgradArgs d{c->dhid, c->y2, c->slabs + plan.s[L_FC].w_off, B, flat, plan.s[L_FC].msplit, 0, 0};
+        return launch_fc_wgrad(d, s);
+      }
       return tn(L_FC, rows_gather(c->y2, flat), c->dhid, kHid, B, kHid, flat, false);
     case ST_FC_DGRAD:
       a = nt_args(rows_gather(c->dhid, kHid), pk + c->pk_fcd, nullptr, c->dy2, flat, B, flat, kHid);

@@ -37,7 +37,14 @@ template <int MODE>
 __global__ __launch_bounds__(256) void lds_mfma_loop_kernel(int iters, float *out) {
   constexpr int LD = 36;
   __shared__ __attribute__((aligned(16))) float smem[192 * LD];
-  for (int i = threadIdx.x; i < 192 * LD; i += 256) smem[i] = 1.f + (i & 7) * 0.125f;
+  // DX_DIAG_RANDOM (iters < 0): full-range pseudo-random operands instead of 8 distinct values --
+  // the matrix pipe's power, and with it the clock the chip holds, depends on the data
+  const bool random_data = iters < 0;
+  if (random_data) iters = -iters;
+  for (int i = threadIdx.x; i < 192 * LD; i += 256) {
+    unsigned h = (i + 1) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    smem[i] = random_data ? (static_cast<float>(h & 0xffffff) / 8388608.f - 1.f) * 1e-3f : 1.f + (i & 7) * 0.125f;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float *pa = smem + ((wave >> 1) * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
@@ -83,6 +90,60 @@ __global__ __launch_bounds__(256) void lds_mfma_loop_kernel(int iters, float *ou
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < 16; ++j) s += acc0[j] + acc1[j];
+  if (s == 12345.678f) out[0] = s;
+}
+
+// The same LDS-fed loop with EIGHT accumulator tiles per wave (the register shape of the wgrad
+// kernels).  MODE 2: every MFMA goes to another tile (a tile is revisited after 8 MFMAs);
+// MODE 3: the 4 MFMAs of a tile in a row (accumulate chains), tile after tile.
+template <int MODE>
+__global__ __launch_bounds__(256) void lds_mfma8_loop_kernel(int iters, float *out) {
+  constexpr int LD = 36;
+  __shared__ __attribute__((aligned(16))) float smem[192 * LD];
+  for (int i = threadIdx.x; i < 192 * LD; i += 256) {
+    unsigned h = (i + 1) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    smem[i] = (static_cast<float>(h & 0xffffff) / 8388608.f - 1.f) * 1e-3f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *pa = smem + ((wave >> 1) * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+  const float *pb = smem + (128 + (wave & 1) * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+  f32x4 a0 = *reinterpret_cast<const f32x4 *>(pa), a1 = *reinterpret_cast<const f32x4 *>(pa + 32 * LD),
+        b = *reinterpret_cast<const f32x4 *>(pb);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+      const int nx = ((ss + 1) & 3) * 8;
+      const f32x4 na0 = *reinterpret_cast<const f32x4 *>(pa + nx);
+      const f32x4 na1 = *reinterpret_cast<const f32x4 *>(pa + 32 * LD + nx);
+      const f32x4 nb = *reinterpret_cast<const f32x4 *>(pb + nx);
+      if (MODE == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[2 * q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b[q], acc[2 * q], 0, 0, 0);
+          acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b[q], acc[2 * q + 1], 0, 0, 0);
+        }
+      } else {
+        const int t0 = (ss & 1) * 4;  // two tiles per sub-step, four chained MFMAs each
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b[q], acc[t0], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t0 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b[q], acc[t0 + 1], 0, 0, 0);
+      }
+      a0 = na0; a1 = na1; b = nb;
+    }
+    asm volatile("" ::: "memory");
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += acc[t][j];
   if (s == 12345.678f) out[0] = s;
 }
 
@@ -351,8 +412,12 @@ extern "C" int dx_diag_gemm_loop_f32(const float *A, const float *B, int tiles, 
 // LDS-fed variant: blocks x 4 waves x iters K tiles of 32 MFMAs (4096 flop each).  mode 0 = reads
 // right before use, 1 = one sub-step ahead.
 extern "C" int dx_diag_lds_mfma_f32(int blocks, int iters, int mode, float *out, void *stream) {
-  DX_REQUIRE(blocks >= 1 && iters >= 1 && out && (mode == 0 || mode == 1), "dx_diag_lds_mfma_f32: bad argument");
-  if (mode == 0)
+  DX_REQUIRE(blocks >= 1 && iters != 0 && out && mode >= 0 && mode <= 3, "dx_diag_lds_mfma_f32: bad argument");
+  if (mode == 2)
+    hipLaunchKernelGGL(lds_mfma8_loop_kernel<2>, dim3(blocks), dim3(256), 0, dx::as_stream(stream), iters, out);
+  else if (mode == 3)
+    hipLaunchKernelGGL(lds_mfma8_loop_kernel<3>, dim3(blocks), dim3(256), 0, dx::as_stream(stream), iters, out);
+  else if (mode == 0)
     hipLaunchKernelGGL(lds_mfma_loop_kernel<0>, dim3(blocks), dim3(256), 0, dx::as_stream(stream), iters, out);
   else
     hipLaunchKernelGGL(lds_mfma_loop_kernel<1>, dim3(blocks), dim3(256), 0, dx::as_stream(stream), iters, out);

@@ -148,6 +148,22 @@ bool wgrad_direct_supported(int IH, int IW, int IC, int OH, int OW, int OC, int 
 int launch_wgrad_direct(const WgradDirectArgs &a, int stage, int nwg, hipStream_t stream);
 int wgrad_direct_workgroups(int stage);  // persistent workgroups that fill the chip for this layer
 
+// weight gradient of the 512-wide linear layer (wgrad_fc.hip): slab[slice][512][K] partial sums
+// over `msplit` row slices; the bias gradient partials come from launch_colsum
+struct FcWgradArgs {
+  const float *G;  // [M][512]
+  const float *A;  // [M][K]
+  float *slab;
+  int M, K, msplit;
+  int gk;          // set by the launcher
+  int diag;        // timing experiments (DX_FC_DIAG): bit 0 no copies after the prologue, bit 1 no barrier, bit 2 no store
+};
+bool fc_wgrad_supported(int M, int N, int K);
+int fc_wgrad_slices(int M, int K);
+int launch_fc_wgrad(const FcWgradArgs &a, hipStream_t stream);
+// out[chunk][N] = column sums of G over `chunks` row chunks
+int launch_colsum(const float *G, float *out, int M, int N, int chunks, hipStream_t stream);
+
 // direct first-layer convolution on uint8 frames (conv0.hip)
 struct Conv0Args {
   const uint8_t *obs;     // (imgs, in_h, in_w, 4) uint8

@@ -28,18 +28,18 @@ for entry in ("dx_diag_mfma_f32", "dx_diag_mfma_f32_chain"):
     print(json.dumps(dict(kernel=entry, waves_per_simd=blocks_per_cu, ms=round(ms, 3),
                           TFLOPs=round(flops / ms / 1e9, 1))), flush=True)
 
-for mode in (0, 1):
+for mode, rnd in ((0, 1), (1, 1), (1, -1), (2, 1), (3, 1)):  # modes 2 / 3: eight accumulator tiles, scattered / chained  # rnd = -1: pseudo-random operands (power / clock depend on the data)
   for blocks_per_cu in (1, 2, 4):
     blocks, iters = 256 * blocks_per_cu, 4000
-    for _ in range(2):
-      _lib.call("dx_diag_lds_mfma_f32", blocks, iters, mode, _lib.ptr(out), stream)
+    for _ in range(2 if rnd > 0 else 40):
+      _lib.call("dx_diag_lds_mfma_f32", blocks, rnd * iters, mode, _lib.ptr(out), stream)
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     for _ in range(5):
-      _lib.call("dx_diag_lds_mfma_f32", blocks, iters, mode, _lib.ptr(out), stream)
+      _lib.call("dx_diag_lds_mfma_f32", blocks, rnd * iters, mode, _lib.ptr(out), stream)
     end.record()
     end.synchronize()
     ms = start.elapsed_time(end) / 5
     flops = blocks * 4 * iters * 32 * 4096.0
-    print(json.dumps(dict(kernel="dx_diag_lds_mfma_f32", mode=mode, waves_per_simd=blocks_per_cu,
+    print(json.dumps(dict(kernel="dx_diag_lds_mfma_f32", mode=mode, random_data=rnd < 0, waves_per_simd=blocks_per_cu,
                           ms=round(ms, 3), TFLOPs=round(flops / ms / 1e9, 1))), flush=True)
