@@ -39,6 +39,9 @@ SIGNATURES = {
     "dx_reward_summary_f32": [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P, P],
     "dx_normalize_step_f32": [P, c_int, c_int, P, P, P, P, P, P, c_longlong, c_float, c_float,
                               c_double, c_double, c_int, P, P, P],
+    "dx_frame_max_u8": [P, P, P, P, P, c_int, c_longlong, P],
+    "dx_frame_queue_u8": [P, P, P, P, P, c_int, c_longlong, c_int, c_int, c_int, P],
+    "dx_gray_resize_u8": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "dx_categorical_act_f32": [P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
     "dx_categorical_loss_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float,
                                 c_float, c_longlong, P, P, c_int, P, P],

@@ -7,6 +7,7 @@ from .synthetic import SyntheticAtariEnv, SyntheticMuJoCoEnv
 from .cartpole import CartPoleBatch
 from .env_batch import EnvBatch, ParallelEnvBatch, SingleEnvBatch, SpaceBatch
 from .bridge import HostEnvBridge
+from .atari_device import DeviceAtariFrames
 from .normalize import Normalize
 from .summarize import DeviceSummarize, RewardSummarizer, Summarize
 

@@ -128,6 +128,27 @@ int dx_normalize_step_f32(const float *obs, int N, int D, const float *rewards,
                           double gamma, double eps, int update_stats, float *obs_out, float *rew_out,
                           void *stream);
 
+/* Atari frame pipeline of a batched env, uint8, batch-first.  `dones` (N bytes)
+ * with `reset` frames reproduces the auto-reset of derl/env/env_batch.py:66-70; both NULL = no
+ * env finished.
+ *  dx_frame_max_u8   -- derl/env/atari_wrappers.py:121-137 (MaxBetweenFrames): out = max(raw,
+ *                       last); last := raw, or the reset frame of an env that finished.
+ *                       per_env = bytes of one frame (a multiple of 4).
+ *  dx_frame_queue_u8 -- :140-163 (QueueFrames): the K most recent frames on the last axis,
+ *                       stacked (H, W[, C], K) or concatenated (H, W, C*K); an env that finished
+ *                       gets K copies of its reset frame.  elems = H*W*C of one frame; prev and
+ *                       out are different buffers (rollout slots t and t + 1).
+ *  dx_gray_resize_u8 -- :95-118 (ImagePreprocessing): BT.601 luma + bilinear resize as the
+ *                       reference's cv2 calls resolve; cv2 is absent here: PARITY UNPINNED.
+ * max and queue are pinned bit for bit to the reference's classes (tests/golden/atari_frames.npz). */
+int dx_frame_max_u8(const uint8_t *raw, uint8_t *last, const uint8_t *dones, const uint8_t *reset,
+                    uint8_t *out, int N, long long per_env, void *stream);
+int dx_frame_queue_u8(const uint8_t *prev, const uint8_t *frame, const uint8_t *dones,
+                      const uint8_t *reset, uint8_t *out, int N, long long elems, int C, int K,
+                      int concat, void *stream);
+int dx_gray_resize_u8(const uint8_t *in, uint8_t *out, int N, int H, int W, int C, int OH, int OW,
+                      int gray, void *stream);
+
 /* Episode-reward statistics of a batched env over the T steps of a rollout -- replaces
  * RewardSummarizer.step of derl/env/summarize.py:40-52 (and add_summaries :25-38) applied step
  * by step.  rewards (T, N) f32, resets (T, N) bytes.  State (device, updated in place): acc, ep_len

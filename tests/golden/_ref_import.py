@@ -121,7 +121,13 @@ def import_reference():
   install_stubs()
   if REFERENCE_ROOT not in sys.path:
     sys.path.insert(0, REFERENCE_ROOT)
+  stale = sys.modules.get("derl")
+  if stale is not None and not getattr(stale, "__file__", "").startswith(REFERENCE_ROOT):
+    # the repo's own `derl` alias package (import name of derl_amd) must not shadow the reference
+    for name in [n for n in sys.modules if n == "derl" or n.startswith("derl.")]:
+      del sys.modules[name]
   import derl  # pylint: disable=import-error
+  assert derl.__file__.startswith(REFERENCE_ROOT), derl.__file__
   import derl.summary as summary
   summary.stop_recording()
   summary.should_record = lambda *a, **k: False

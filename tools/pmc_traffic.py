@@ -1,0 +1,62 @@
+"""Turns the two rocprofv3 --pmc passes of tools/stage_bench.py (FETCH_SIZE and WRITE_SIZE, separate
+runs as MI355X_MICROARCH.md prescribes) into profiles/<tag>_pmc_traffic.json: HBM-side bytes per
+launch of every network stage.  Counter unit: KiB; FETCH_SIZE is doubled (gfx950 tallies the 128-B
+requests of wide streaming reads at 64 B).
+
+  bash tools/pmc_passes.sh <tag>pmc 8192 "FETCH_SIZE" "WRITE_SIZE"
+  python3 tools/pmc_traffic.py gpurun_out/<tag>pmc_0 gpurun_out/<tag>pmc_1 profiles/<tag>_pmc_traffic.json"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+STAGE_OF = [  # substring of the kernel name -> stage
+    ("conv0_fwd_b16", "conv0_fwd"), ("igemm_nt_kernel<1,", "conv1_fwd"), ("igemm_nt_kernel<2,", "conv2_fwd"),
+    ("igemm_nt_small_kernel<3,", "fc_fwd"), ("fc_wgrad_kernel", "fc_wgrad"), ("colsum_kernel", "fc_wgrad_bias"),
+    ("igemm_tn_kernel<7,", "fc_wgrad"), ("igemm_nt_small_kernel<8,", "fc_dgrad"),
+    ("conv_wgrad_direct_kernel<9,", "conv2_wgrad"), ("igemm_tn_kernel<9,", "conv2_wgrad"),
+    ("igemm_nt_pix_kernel<10,", "conv2_dgrad"), ("conv_wgrad_direct_kernel<11,", "conv1_wgrad"),
+    ("igemm_tn_kernel<11,", "conv1_wgrad"), ("igemm_nt_pix_kernel<12,", "conv1_dgrad"),
+    ("conv0_wgrad_b16", "conv0_wgrad"), ("permute_reduce_kernel", "finalize"),
+    ("fc_row_unpermute_reduce", "finalize_fc"),
+]
+
+
+def mean_per_kernel(root, counter):
+  acc = collections.defaultdict(lambda: [0, 0.0])
+  for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    with open(path) as f:
+      for row in csv.DictReader(f):
+        if row["Counter_Name"] != counter:
+          continue
+        acc[row["Kernel_Name"]][0] += 1
+        acc[row["Kernel_Name"]][1] += float(row["Counter_Value"])
+  return {k: v[1] / v[0] for k, v in acc.items()}
+
+
+def main(fetch_dir, write_dir, out_path):
+  fetch = mean_per_kernel(fetch_dir, "FETCH_SIZE")
+  write = mean_per_kernel(write_dir, "WRITE_SIZE")
+  stages = {}
+  for kernel in sorted(set(fetch) | set(write)):
+    stage = next((s for key, s in STAGE_OF if key in kernel), None)
+    if stage is None:
+      continue
+    raw = fetch.get(kernel, 0.0) * 1024
+    wr = write.get(kernel, 0.0) * 1024
+    stages[stage] = {"kernel": kernel, "FETCH_SIZE_bytes_raw": int(raw), "FETCH_SIZE_bytes_x2_gfx950": int(2 * raw),
+                     "WRITE_SIZE_bytes": int(wr), "hbm_bytes": int(2 * raw + wr)}
+  doc = {"what": "HBM-side traffic per launch at minibatch 8192 (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
+                 "separate passes over tools/stage_bench.py 8192; counter unit KiB; FETCH_SIZE doubled per "
+                 "MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B)",
+         "stages": stages}
+  with open(out_path, "w") as f:
+    json.dump(doc, f, indent=1)
+  for name, s in stages.items():
+    print(f"{name:16s} fetch {s['FETCH_SIZE_bytes_x2_gfx950'] / 1e6:8.1f} MB  write {s['WRITE_SIZE_bytes'] / 1e6:8.1f} MB")
+
+
+if __name__ == "__main__":
+  main(*sys.argv[1:4])
