@@ -22,10 +22,6 @@ SIGNATURES = {
     "dx_last_error": [],
     "dx_device_info": [c_int, c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "dx_gae_f32": [P, P, P, P, c_int, c_int, c_float, c_float, P, P, P],
-    "dx_diag_mfma_f32": [c_int, c_int, P, P],
-    "dx_diag_mfma_f32_chain": [c_int, c_int, P, P],
-    "dx_diag_lds_mfma_f32": [c_int, c_int, c_int, P, P],
-    "dx_diag_gemm_loop_f32": [P, P, c_int, c_int, c_int, P, P],
     "dx_adv_stats_f32": [P, c_longlong, P, P],
     "dx_adv_stats_segments_f32": [P, P, c_longlong, c_longlong, P, P],
     "dx_adv_normalize_f32": [P, P, c_longlong, c_float, P, c_int, P],

@@ -103,6 +103,7 @@ extern "C" {
 
 int dx_frame_max_u8(const uint8_t *raw, uint8_t *last, const uint8_t *dones, const uint8_t *reset,
                     uint8_t *out, int N, long long per_env, void *stream) {
+  DX_TRACE("dx_frame_max_u8");
   DX_REQUIRE(raw && last && out && N >= 1 && per_env >= 4 && per_env % 4 == 0,
              "dx_frame_max_u8: bad arguments (N=%d, bytes per env=%lld: a multiple of 4)", N, per_env);
   DX_REQUIRE((dones == nullptr) == (reset == nullptr), "dx_frame_max_u8: dones and reset frames come together");
@@ -117,6 +118,7 @@ int dx_frame_max_u8(const uint8_t *raw, uint8_t *last, const uint8_t *dones, con
 
 int dx_frame_queue_u8(const uint8_t *prev, const uint8_t *frame, const uint8_t *dones, const uint8_t *reset,
                       uint8_t *out, int N, long long elems, int C, int K, int concat, void *stream) {
+  DX_TRACE("dx_frame_queue_u8");
   DX_REQUIRE(prev && frame && out && N >= 1 && elems >= 1 && C >= 1 && K >= 1 && elems % C == 0,
              "dx_frame_queue_u8: bad arguments (N=%d, elements per frame=%lld, C=%d, K=%d)", N, elems, C, K);
   DX_REQUIRE((dones == nullptr) == (reset == nullptr), "dx_frame_queue_u8: dones and reset frames come together");
@@ -131,6 +133,7 @@ int dx_frame_queue_u8(const uint8_t *prev, const uint8_t *frame, const uint8_t *
 
 int dx_gray_resize_u8(const uint8_t *in, uint8_t *out, int N, int H, int W, int C, int OH, int OW, int gray,
                       void *stream) {
+  DX_TRACE("dx_gray_resize_u8");
   DX_REQUIRE(in && out && N >= 1 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1 && (C == 1 || C == 3),
              "dx_gray_resize_u8: bad arguments (N=%d, %dx%dx%d -> %dx%d)", N, H, W, C, OH, OW);
   const long long total = static_cast<long long>(N) * OH * OW * (gray ? 1 : C);

@@ -22,10 +22,14 @@ struct Derived {
 
 int conv_out(int n, int k, int s) { return (n - k) / s + 1; }
 
-bool use_b3() {  // DX_SPLIT_BF16=1: big NT stages on the bf16 matrix cores (exact 3-term split)
+bool use_b3() {  // experiment build + DX_SPLIT_BF16=1: big NT stages on the bf16 matrix cores
+#ifdef DX_EXPERIMENT_B3
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_SPLIT_BF16"); v = e ? atoi(e) : 0; }
   return v != 0;
+#else
+  return false;
+#endif
 }
 
 // DX_C0LAT_MAX_TILES: largest 32-pixel tile count of the rollout conv0 kernel.  Measured crossover
@@ -178,6 +182,7 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
 }
 
 int dx_cnn_init(dx_cnn_ctx *c) {
+  DX_TRACE("dx_cnn_init");
   DX_REQUIRE(c != nullptr, "dx_cnn_init: null ctx");
   DX_REQUIRE(c->struct_bytes == static_cast<int>(sizeof(dx_cnn_ctx)),
              "dx_cnn_init: struct size mismatch (caller %d, library %d)", c->struct_bytes,
@@ -247,6 +252,7 @@ static uint16_t *planes(const dx_cnn_ctx *c, long long off) {
 
 // canonical parameters -> packed mirrors (call after every parameter change)
 int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
+  DX_TRACE("dx_cnn_pack");
   if (int rc = check_ctx(c, "dx_cnn_pack", 1, false)) return rc;
   hipStream_t s = as_stream(stream);
   const int A = c->num_actions, IC0 = c->in_c, P = c->h2 * c->w2, flat = c->flat;
@@ -542,6 +548,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
 // ctx->head (B,32): columns 0..A-1 logits, column A value.  Keeps y0,y1,y2,hid for backward.
 int dx_cnn_forward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const int32_t *sample_idx,
                    int B, void *stream) {
+  DX_TRACE("dx_cnn_forward");
   if (int rc = check_ctx(c, "dx_cnn_forward", B, false)) return rc;
   DX_REQUIRE(obs != nullptr, "dx_cnn_forward: null observations");
   const Plan plan = make_plan(c, B);
@@ -554,6 +561,7 @@ int dx_cnn_forward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const in
 // dx_cnn_forward on the SAME observations / sample_idx.
 int dx_cnn_backward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const int32_t *sample_idx,
                     int B, void *stream) {
+  DX_TRACE("dx_cnn_backward");
   if (int rc = check_ctx(c, "dx_cnn_backward", B, true)) return rc;
   DX_REQUIRE(obs != nullptr, "dx_cnn_backward: null observations");
   const Plan plan = make_plan(c, B);
@@ -568,6 +576,7 @@ int dx_cnn_backward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const i
 // conv layers (grads[0 .. off_w[3])).  Part 0 must be enqueued first.
 int dx_cnn_backward_part(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const int32_t *sample_idx,
                          int B, int part, void *stream) {
+  DX_TRACE("dx_cnn_backward_part");
   if (int rc = check_ctx(c, "dx_cnn_backward_part", B, true)) return rc;
   DX_REQUIRE(obs != nullptr, "dx_cnn_backward_part: null observations");
   DX_REQUIRE(part == 0 || part == 1, "dx_cnn_backward_part: part must be 0 or 1, got %d", part);
@@ -588,53 +597,61 @@ static int fc_ksplit(int B, int flat) {
   return ks;
 }
 
-int dx_cnn_act(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B, const float *uniforms,
-               uint64_t seed, uint64_t counter, int64_t *actions, float *log_prob, float *values,
-               void *stream) {
-  if (int rc = check_ctx(c, "dx_cnn_act", B, false)) return rc;
-  DX_REQUIRE(obs != nullptr && c->hid_slabs != nullptr, "dx_cnn_act: null observations / hid_slabs");
-  hipStream_t s = as_stream(stream);
+// conv0 .. linear layer (split-K slabs) of a rollout step; the caller finishes with a heads launch
+static int act_trunk(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B, NTArgs *fc, hipStream_t s) {
   const Plan plan = make_plan(c, B);
   for (int st = ST_CONV0_FWD; st <= ST_CONV2_FWD; ++st)
     if (int rc = run_stage(c, st, obs, obs_is_u8, nullptr, B, plan, s)) return rc;
   const int ks = fc_ksplit(B, c->flat);
   DX_REQUIRE(static_cast<long long>(ks) * B * kHid <= c->hid_slab_count, "dx_cnn_act: hid_slabs too small");
-  NTArgs a = nt_args(rows_gather(c->y2, c->flat), c->packed + c->pk_fcf, c->params + c->off_b[3],
-                     c->hid_slabs, kHid, B, kHid, c->flat);
-  a.ksplit = ks;
-  a.slab_stride = static_cast<long long>(B) * kHid;
-  if (int rc = launch_nt(a, false, EPI_BIAS, ST_FC_FWD, s)) return rc;
-  return launch_heads_act_fused(c->hid_slabs, ks, a.slab_stride, c->packed + c->pk_hdf,
+  *fc = nt_args(rows_gather(c->y2, c->flat), c->packed + c->pk_fcf, c->params + c->off_b[3],
+                c->hid_slabs, kHid, B, kHid, c->flat);
+  fc->ksplit = ks;
+  fc->slab_stride = static_cast<long long>(B) * kHid;
+  return launch_nt(*fc, false, EPI_BIAS, ST_FC_FWD, s);
+}
+
+int dx_cnn_act(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B, const float *uniforms,
+               uint64_t seed, uint64_t counter, int64_t *actions, float *log_prob, float *values,
+               void *stream) {
+  DX_TRACE("dx_cnn_act");
+  if (int rc = check_ctx(c, "dx_cnn_act", B, false)) return rc;
+  DX_REQUIRE(obs != nullptr && c->hid_slabs != nullptr, "dx_cnn_act: null observations / hid_slabs");
+  hipStream_t s = as_stream(stream);
+  NTArgs a;
+  if (int rc = act_trunk(c, obs, obs_is_u8, B, &a, s)) return rc;
+  return launch_heads_act_fused(c->hid_slabs, a.ksplit, a.slab_stride, c->packed + c->pk_hdf,
                                 c->packed + c->pk_hdb, B, c->num_actions, uniforms, seed, counter,
                                 actions, log_prob, values, s);
 }
 
-extern "C" int dx_synth_atari_step(void *frames, long long frame_bytes_total, float *rewards,
-                                   uint8_t *resets, int nenvs, uint64_t seed, uint64_t counter,
-                                   float p_reward, float p_reset, void *stream);
-
-// T rollout steps against the synthetic device env enqueued from one call (the per-step
-// launches are identical to calling dx_cnn_act + dx_synth_atari_step T times; this only
-// removes the host interpreter from between them).  Buffers are time-major:
+// T rollout steps against the synthetic device env enqueued from one call.  Per step: the policy
+// trunk (4 launches) and ONE launch that finishes the policy (slab sum + heads + sampling) and
+// generates the next observation batch, rewards and resets -- bit-identical to dx_cnn_act +
+// dx_synth_atari_step (the synthetic dynamics ignore the action, so the env's part of the grid
+// does not wait for the policy's), one dependent launch shorter.  Buffers are time-major:
 // obs (T+1, N, H, W, 4) uint8 with obs[0] given, actions (T, N) int64, log_prob / values /
 // rewards (T, N) float32, resets (T, N) bytes.
 int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_t *actions,
                          float *log_prob, float *values, float *rewards, uint8_t *resets,
                          uint64_t policy_seed, uint64_t policy_counter, uint64_t env_seed,
                          uint64_t env_counter, float p_reward, float p_reset, void *stream) {
+  DX_TRACE("dx_cnn_rollout_synth");
   if (int rc = check_ctx(c, "dx_cnn_rollout_synth", N, false)) return rc;
-  DX_REQUIRE(T >= 1 && obs && actions && log_prob && values && rewards && resets,
+  DX_REQUIRE(T >= 1 && obs && actions && log_prob && values && rewards && resets && c->hid_slabs,
              "dx_cnn_rollout_synth: bad arguments");
   const long long frame = static_cast<long long>(c->in_h) * c->in_w * c->in_c * N;
   DX_REQUIRE(frame % 16 == 0, "dx_cnn_rollout_synth: frame batch must be a multiple of 16 bytes");
+  hipStream_t s = as_stream(stream);
   for (int t = 0; t < T; ++t) {
-    if (int rc = dx_cnn_act(c, obs + t * frame, 1, N, nullptr, policy_seed, policy_counter + t,
-                            actions + static_cast<long long>(t) * N, log_prob + static_cast<long long>(t) * N,
-                            values + static_cast<long long>(t) * N, stream))
-      return rc;
-    if (int rc = dx_synth_atari_step(obs + (t + 1) * frame, frame, rewards + static_cast<long long>(t) * N,
-                                     resets + static_cast<long long>(t) * N, N, env_seed, env_counter + t,
-                                     p_reward, p_reset, stream))
+    NTArgs a;
+    if (int rc = act_trunk(c, obs + t * frame, 1, N, &a, s)) return rc;
+    const long long row = static_cast<long long>(t) * N;
+    if (int rc = launch_heads_act_synth(c->hid_slabs, a.ksplit, a.slab_stride, c->packed + c->pk_hdf,
+                                        c->packed + c->pk_hdb, N, c->num_actions, policy_seed,
+                                        policy_counter + t, actions + row, log_prob + row, values + row,
+                                        obs + (t + 1) * frame, frame, rewards + row, resets + row, env_seed,
+                                        env_counter + t, p_reward, p_reset, s))
       return rc;
   }
   return DX_OK;
@@ -643,6 +660,7 @@ int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_
 // A single stage, for per-kernel timing (bench.py roofline) and layer-level tests.
 int dx_cnn_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is_u8,
                  const int32_t *sample_idx, int B, void *stream) {
+  DX_TRACE("dx_cnn_stage");
   if (int rc = check_ctx(c, "dx_cnn_stage", B, stage >= ST_HEADS_WGRAD)) return rc;
   DX_REQUIRE(obs != nullptr, "dx_cnn_stage: null observations");
   const Plan plan = make_plan(c, B);

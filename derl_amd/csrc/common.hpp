@@ -32,6 +32,17 @@ inline int fail(int code, const char *fmt, ...) {
 // after a kernel launch: catches bad launch configurations without synchronising
 #define DX_LAUNCH_CHECK() DX_HIP(hipGetLastError())
 
+// roctx range around a C-ABI call (tracing): DX_ROCTX=1 resolves
+// roctxRangePushA / roctxRangePop from libroctx64.so at first use, so that a rocprofv3
+// --marker-trace shows which entry point every kernel belongs to.  Off (the default) it is one
+// predictable branch per call.
+struct TraceRange {
+  explicit TraceRange(const char *name);
+  ~TraceRange();
+  bool active;
+};
+#define DX_TRACE(name) ::dx::TraceRange dx_trace_range_(name)
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 inline int cdiv(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }

@@ -1,8 +1,40 @@
 // ABI version, error string and device probe.
 #include "common.hpp"
+#include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 
 namespace dx {
+namespace {
+using PushFn = int (*)(const char *);
+using PopFn = int (*)();
+PushFn g_push = nullptr;
+PopFn g_pop = nullptr;
+bool trace_enabled() {
+  static int state = -1;  // -1 unknown, 0 off, 1 on
+  if (state < 0) {
+    state = 0;
+    const char *e = getenv("DX_ROCTX");
+    if (e && atoi(e) != 0) {
+      void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+      if (h) {
+        g_push = reinterpret_cast<PushFn>(dlsym(h, "roctxRangePushA"));
+        g_pop = reinterpret_cast<PopFn>(dlsym(h, "roctxRangePop"));
+        state = (g_push && g_pop) ? 1 : 0;
+      }
+    }
+  }
+  return state == 1;
+}
+}  // namespace
+TraceRange::TraceRange(const char *name) : active(trace_enabled()) {
+  if (active) g_push(name);
+}
+TraceRange::~TraceRange() {
+  if (active) g_pop();
+}
+
 char *error_buffer() {
   static thread_local char buf[512] = "";
   return buf;
@@ -14,6 +46,7 @@ extern "C" int dx_abi_version(void) { return DX_ABI_VERSION; }
 extern "C" const char *dx_last_error(void) { return dx::error_buffer(); }
 
 extern "C" int dx_device_info(int device, char *name_host, int *cu_count, int *lds_bytes) {
+  DX_TRACE("dx_device_info");
   DX_REQUIRE(name_host != nullptr, "dx_device_info: name_host is NULL");
   hipDeviceProp_t prop;
   DX_HIP(hipGetDeviceProperties(&prop, device));

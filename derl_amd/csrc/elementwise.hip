@@ -243,6 +243,7 @@ int grid_for(long long n, int per_thread) {
 
 extern "C" int dx_adv_normalize_f32(const float *advantages, float *out, long long n, float eps,
                                     double *stats, int stats_ready, void *stream) {
+  DX_TRACE("dx_adv_normalize_f32");
   DX_REQUIRE(n >= 0, "dx_adv_normalize_f32: negative n");
   if (n == 0) return DX_OK;
   DX_REQUIRE(advantages && out && stats, "dx_adv_normalize_f32: null pointer");
@@ -258,6 +259,7 @@ extern "C" int dx_adv_normalize_f32(const float *advantages, float *out, long lo
 }
 
 extern "C" int dx_adv_stats_f32(const float *advantages, long long n, double *stats, void *stream) {
+  DX_TRACE("dx_adv_stats_f32");
   DX_REQUIRE(n > 0 && advantages && stats, "dx_adv_stats_f32: bad argument");
   hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, dx::as_stream(stream), advantages, n, stats);
   DX_LAUNCH_CHECK();
@@ -266,6 +268,7 @@ extern "C" int dx_adv_stats_f32(const float *advantages, long long n, double *st
 
 extern "C" int dx_adv_stats_segments_f32(const float *advantages, const int32_t *index, long long n,
                                          long long seglen, double *stats, void *stream) {
+  DX_TRACE("dx_adv_stats_segments_f32");
   DX_REQUIRE(n > 0 && seglen > 0 && advantages && stats, "dx_adv_stats_segments_f32: bad argument");
   const long long nseg = (n + seglen - 1) / seglen;
   DX_REQUIRE(nseg <= 65535, "dx_adv_stats_segments_f32: %lld segments (max 65535)", nseg);
@@ -277,6 +280,7 @@ extern "C" int dx_adv_stats_segments_f32(const float *advantages, const int32_t 
 
 extern "C" int dx_grad_sumsq_f32(const float *grads, long long n, double *partials, int npartials,
                                  void *stream) {
+  DX_TRACE("dx_grad_sumsq_f32");
   DX_REQUIRE(n > 0 && grads && partials, "dx_grad_sumsq_f32: bad argument");
   DX_REQUIRE(npartials >= 1 && npartials <= 4096, "dx_grad_sumsq_f32: npartials=%d out of [1,4096]", npartials);
   DX_REQUIRE(dx::aligned(grads, 16), "dx_grad_sumsq_f32: grads must be 16-byte aligned");
@@ -298,6 +302,7 @@ extern "C" int dx_clip_adam_step_f32(float *params, float *grads, float *exp_avg
                                      long long n, const double *sumsq_partials, int npartials,
                                      double max_norm, double lr, double beta1, double beta2,
                                      double eps, long long step, float *norm_out, void *stream) {
+  DX_TRACE("dx_clip_adam_step_f32");
   if (int rc = check_opt("dx_clip_adam_step_f32", params, grads, exp_avg_sq, n, sumsq_partials, npartials))
     return rc;
   DX_REQUIRE(exp_avg && step >= 1, "dx_clip_adam_step_f32: exp_avg null or step < 1");
@@ -321,6 +326,7 @@ extern "C" int dx_clip_rmsprop_step_f32(float *params, float *grads, float *squa
                                         const double *sumsq_partials, int npartials, double max_norm,
                                         double lr, double alpha, double eps, float *norm_out,
                                         void *stream) {
+  DX_TRACE("dx_clip_rmsprop_step_f32");
   if (int rc = check_opt("dx_clip_rmsprop_step_f32", params, grads, square_avg, n, sumsq_partials, npartials))
     return rc;
   OptArgs a{params, grads, nullptr, square_avg, n, sumsq_partials, npartials,
@@ -334,6 +340,7 @@ extern "C" int dx_clip_rmsprop_step_f32(float *params, float *grads, float *squa
 
 extern "C" int dx_gather_rows_multi(const void *const *src, void *const *dst, const long long *row_bytes,
                                     int narrays, const int32_t *idx, long long nrows, void *stream) {
+  DX_TRACE("dx_gather_rows_multi");
   DX_REQUIRE(narrays >= 0 && narrays <= kMaxGather, "dx_gather_rows_multi: %d arrays (max %d)", narrays,
              kMaxGather);
   DX_REQUIRE(nrows >= 0, "dx_gather_rows_multi: negative row count");
@@ -360,6 +367,7 @@ extern "C" int dx_gather_rows_multi(const void *const *src, void *const *dst, co
 
 extern "C" int dx_gather_rows(const void *src, const int32_t *idx, void *dst, long long nrows,
                               long long row_bytes, void *stream) {
+  DX_TRACE("dx_gather_rows");
   DX_REQUIRE(nrows >= 0 && row_bytes > 0, "dx_gather_rows: bad shape");
   if (nrows == 0) return DX_OK;
   DX_REQUIRE(src && idx && dst, "dx_gather_rows: null pointer");

@@ -1,6 +1,7 @@
 // Diagnostics: what the fp32 matrix pipe of this part sustains with no memory traffic at all
 // (the ceiling the GEMM stages are judged against in DESIGN.md next to the data-sheet peak).
-#include "common.hpp"
+#include "../common.hpp"
+#include "../../../include/derl_amd_diag.h"
 
 namespace {
 

@@ -11,41 +11,12 @@
 // Same interface, gathers and epilogues as igemm_nt_kernel; only the tile staging (split while
 // writing LDS, three planes of [rows][32 k] bf16 with 80-byte rows: conflict-free ds_read_b128)
 // and the MFMA body differ.
-#include "igemm_dev.hpp"
+#include "../bf16_split.hpp"
 
 namespace dx {
 namespace {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-__device__ __forceinline__ uint32_t pack2(float a, float b) {  // round-to-nearest-even
-  bf16x2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};
-  return __builtin_bit_cast(uint32_t, v);
-}
-__device__ __forceinline__ float lo_f32(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float hi_f32(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-struct Split4 {
-  uint2 hi, mid, lo;  // 4 bf16 each
-};
-
-__device__ __forceinline__ void split2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
-  h = pack2(x0, x1);
-  const float r0 = x0 - lo_f32(h), r1 = x1 - hi_f32(h);  // exact
-  m = pack2(r0, r1);
-  l = pack2(r0 - lo_f32(m), r1 - hi_f32(m));             // exact residual, exact conversion
-}
-
-__device__ __forceinline__ Split4 split4(f32x4 v) {
-  Split4 s;
-  split2(v.x, v.y, s.hi.x, s.mid.x, s.lo.x);
-  split2(v.z, v.w, s.hi.y, s.mid.y, s.lo.y);
-  return s;
-}
-
 constexpr int kRowB = 80;  // bytes per LDS row: 32 bf16 + 16 pad
 
 template <int TAG, int BM, int BN, int WM, int WN, int EPI>
@@ -291,45 +262,6 @@ int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream) {
     case ST_CONV1_DGRAD: return epi == EPI_MASK ? launch_b3<ST_CONV1_DGRAD, EPI_MASK>(a, stream) : DX_ENOSUP;
     default: return DX_ENOSUP;
   }
-}
-
-// fp32 [n] -> three bf16 planes dst[0..n), dst[n..2n), dst[2n..3n) with src == hi + mid + lo exactly
-namespace {
-struct SplitTable {
-  const float *src[kMaxSplitJobs];
-  uint16_t *dst[kMaxSplitJobs];
-  long long count[kMaxSplitJobs];
-};
-__global__ __launch_bounds__(256) void split_planes_kernel(const SplitTable t) {
-  const float *src = t.src[blockIdx.y];
-  uint16_t *dst = t.dst[blockIdx.y];
-  const long long n = t.count[blockIdx.y];  // multiple of 4
-  for (long long i = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 4; i < n;
-       i += static_cast<long long>(gridDim.x) * 1024) {
-    const Split4 s = split4(*reinterpret_cast<const f32x4 *>(src + i));
-    *reinterpret_cast<uint2 *>(dst + i) = s.hi;
-    *reinterpret_cast<uint2 *>(dst + n + i) = s.mid;
-    *reinterpret_cast<uint2 *>(dst + 2 * n + i) = s.lo;
-  }
-}
-}  // namespace
-
-int launch_split_planes(const float *const *src, uint16_t *const *dst, const long long *count, int njobs,
-                        hipStream_t stream) {
-  DX_REQUIRE(njobs >= 0 && njobs <= kMaxSplitJobs, "split_planes: %d jobs (max %d)", njobs, kMaxSplitJobs);
-  if (njobs == 0) return DX_OK;
-  SplitTable t;
-  long long biggest = 0;
-  for (int i = 0; i < njobs; ++i) {
-    DX_REQUIRE(src[i] && dst[i] && count[i] > 0 && count[i] % 4 == 0, "split_planes: bad job %d", i);
-    t.src[i] = src[i]; t.dst[i] = dst[i]; t.count[i] = count[i];
-    if (count[i] > biggest) biggest = count[i];
-  }
-  int bx = cdiv(biggest, 1024);
-  if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(split_planes_kernel, dim3(bx, njobs), dim3(256), 0, stream, t);
-  DX_LAUNCH_CHECK();
-  return DX_OK;
 }
 
 }  // namespace dx

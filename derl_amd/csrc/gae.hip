@@ -177,6 +177,7 @@ int launch(const float *rewards, const uint8_t *resets, const float *values,
 extern "C" int dx_gae_f32(const float *rewards, const uint8_t *resets, const float *values,
                           const float *last_values, int T, int N, float gamma, float lambda,
                           float *advantages, float *value_targets, void *stream) {
+  DX_TRACE("dx_gae_f32");
   DX_REQUIRE(T >= 0 && N >= 0, "dx_gae_f32: negative shape T=%d N=%d", T, N);
   if (T == 0 || N == 0) return DX_OK;
   DX_REQUIRE(rewards && resets && values && last_values && advantages && value_targets,

@@ -10,7 +10,7 @@
 //             (derl/alg/ppo.py:45-64,82-98,104; derl/alg/a2c.py:32-33,57,74; closed forms
 //             in SURVEY.md Appendix A.1-A.5)
 // Diagonal-Gaussian head for the MLP policy: thread per row (derl/policies.py:40-42,66).
-#include "common.hpp"
+#include "synth_dev.hpp"
 
 namespace {
 
@@ -112,13 +112,32 @@ __device__ __forceinline__ float lane_value(float v, int lane_uniform) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_uniform));
 }
 
-__global__ __launch_bounds__(256) void heads_act_fused_kernel(
-    const float *__restrict__ hid_slabs, int nslab, long long slab_stride,
-    const float *__restrict__ Wh, const float *__restrict__ bh, int B, int A,
-    const float *__restrict__ uniforms, uint64_t seed, uint64_t counter,
-    int64_t *__restrict__ actions, float *__restrict__ log_prob, float *__restrict__ values) {
+struct HeadsActArgs {
+  const float *hid_slabs;
+  int nslab;
+  long long slab_stride;
+  const float *Wh, *bh;
+  int B, A;
+  const float *uniforms;
+  uint64_t seed, counter;
+  int64_t *actions;
+  float *log_prob, *values;
+};
+
+__device__ __forceinline__ void heads_act_fused_block(const HeadsActArgs &p, int block) {
+  const float *__restrict__ hid_slabs = p.hid_slabs;
+  const int nslab = p.nslab;
+  const long long slab_stride = p.slab_stride;
+  const float *__restrict__ Wh = p.Wh;
+  const float *__restrict__ bh = p.bh;
+  const int B = p.B, A = p.A;
+  const float *__restrict__ uniforms = p.uniforms;
+  const uint64_t seed = p.seed, counter = p.counter;
+  int64_t *__restrict__ actions = p.actions;
+  float *__restrict__ log_prob = p.log_prob;
+  float *__restrict__ values = p.values;
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = block * 4 + (threadIdx.x >> 6);
   if (b >= B) return;  // whole wave exits together
   // the head weights of outputs 0..7, the bias and the uniform do not depend on the slabs:
   // issue them first, one memory round trip in all
@@ -190,6 +209,20 @@ __global__ __launch_bounds__(256) void heads_act_fused_kernel(
     log_prob[b] = la;
     values[b] = val;
   }
+}
+
+__global__ __launch_bounds__(256) void heads_act_fused_kernel(const HeadsActArgs p) {
+  heads_act_fused_block(p, blockIdx.x);
+}
+
+// The rollout step's last launch against the synthetic device env: workgroups [0, heads_blocks)
+// finish the policy (slab sum + heads + sampling), the others generate the NEXT observation
+// batch, rewards and resets -- the env of the measurement ignores the action, so the two halves
+// are independent and the step loses one dependent launch (rollout).
+__global__ __launch_bounds__(256) void heads_act_synth_kernel(const HeadsActArgs p, const dx::SynthArgs e,
+                                                             int heads_blocks) {
+  if (static_cast<int>(blockIdx.x) < heads_blocks) heads_act_fused_block(p, blockIdx.x);
+  else dx::synth_atari_block(e, blockIdx.x - heads_blocks, gridDim.x - heads_blocks);
 }
 
 struct LossArgs {
@@ -494,6 +527,7 @@ __global__ __launch_bounds__(256) void loss_reduce40_kernel(const double *partia
 extern "C" int dx_normal_act_f32(const float *head_out, const float *logstd, int B, int P,
                                  const float *normals, uint64_t seed, uint64_t counter, float *actions,
                                  float *log_prob, float *values, void *stream) {
+  DX_TRACE("dx_normal_act_f32");
   DX_REQUIRE(B >= 0 && P >= 1 && P <= 31, "dx_normal_act_f32: need 1 <= P <= 31 (P=%d)", P);
   if (B == 0) return DX_OK;
   DX_REQUIRE(head_out && logstd && actions && log_prob && values, "dx_normal_act_f32: null pointer");
@@ -510,6 +544,7 @@ extern "C" int dx_normal_loss_f32(const float *head_out, const float *logstd, co
                                   long long global_batch, float *dhead_out, float *dlogstd_out,
                                   double *partials, int partials_capacity, float *loss_out,
                                   void *stream) {
+  DX_TRACE("dx_normal_loss_f32");
   DX_REQUIRE(B >= 1 && P >= 1 && P <= 31, "dx_normal_loss_f32: need B >= 1 and 1 <= P <= 31");
   DX_REQUIRE(mode == 0 || mode == 1, "dx_normal_loss_f32: mode must be 0 (PPO) or 1 (A2C)");
   DX_REQUIRE(head_out && logstd && actions && advantages && value_targets && dhead_out && dlogstd_out &&
@@ -540,6 +575,7 @@ namespace {
 extern "C" int dx_categorical_act_f32(const float *head_out, int B, int A, const float *uniforms,
                                       uint64_t seed, uint64_t counter, int64_t *actions,
                                       float *log_prob, float *values, void *stream) {
+  DX_TRACE("dx_categorical_act_f32");
   DX_REQUIRE(B >= 0 && A >= 1 && A <= 31, "dx_categorical_act_f32: need 1 <= A <= 31 (A=%d)", A);
   if (B == 0) return DX_OK;
   DX_REQUIRE(head_out && actions && log_prob && values, "dx_categorical_act_f32: null pointer");
@@ -556,6 +592,7 @@ extern "C" int dx_categorical_loss_f32(const float *head_out, const int64_t *act
                                        float entropy_coef, long long global_batch, float *dhead_out,
                                        double *partials, int partials_capacity, float *loss_out,
                                        void *stream) {
+  DX_TRACE("dx_categorical_loss_f32");
   DX_REQUIRE(B >= 1 && A >= 1 && A <= 31, "dx_categorical_loss_f32: need B >= 1 and 1 <= A <= 31");
   DX_REQUIRE(mode == 0 || mode == 1, "dx_categorical_loss_f32: mode must be 0 (PPO) or 1 (A2C)");
   DX_REQUIRE(head_out && actions && advantages && value_targets && dhead_out && partials && loss_out,
@@ -583,8 +620,26 @@ int launch_heads_act_fused(const float *hid_slabs, int nslab, long long slab_str
                            hipStream_t stream) {
   DX_REQUIRE(B >= 1 && A >= 1 && A <= 31 && nslab >= 1, "heads_act: bad shape B=%d A=%d nslab=%d", B, A, nslab);
   DX_REQUIRE(hid_slabs && Wh && bh && actions && log_prob && values, "heads_act: null pointer");
-  hipLaunchKernelGGL(heads_act_fused_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, hid_slabs, nslab,
-                     slab_stride, Wh, bh, B, A, uniforms, seed, counter, actions, log_prob, values);
+  const HeadsActArgs p{hid_slabs, nslab, slab_stride, Wh, bh, B, A, uniforms, seed, counter, actions, log_prob, values};
+  hipLaunchKernelGGL(heads_act_fused_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, p);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+int launch_heads_act_synth(const float *hid_slabs, int nslab, long long slab_stride, const float *Wh,
+                           const float *bh, int B, int A, uint64_t seed, uint64_t counter, int64_t *actions,
+                           float *log_prob, float *values, void *frames, long long frame_bytes, float *rewards,
+                           uint8_t *resets, uint64_t env_seed, uint64_t env_counter, float p_reward,
+                           float p_reset, hipStream_t stream) {
+  DX_REQUIRE(B >= 1 && A >= 1 && A <= 31 && nslab >= 1, "heads_act_synth: bad shape B=%d A=%d nslab=%d", B, A, nslab);
+  DX_REQUIRE(hid_slabs && Wh && bh && actions && log_prob && values, "heads_act_synth: null pointer");
+  DX_REQUIRE(frames && frame_bytes > 0 && frame_bytes % 16 == 0 && aligned(frames, 16),
+             "heads_act_synth: frames must be 16-byte aligned, size a multiple of 16");
+  const HeadsActArgs p{hid_slabs, nslab, slab_stride, Wh, bh, B, A, nullptr, seed, counter, actions, log_prob, values};
+  const SynthArgs e{static_cast<uint4 *>(frames), frame_bytes / 16, rewards, resets, B, env_seed, env_counter,
+                    p_reward, p_reset};
+  const int hb = cdiv(B, 4);
+  hipLaunchKernelGGL(heads_act_synth_kernel, dim3(hb + synth_blocks(e.nvec, B)), dim3(256), 0, stream, p, e, hb);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

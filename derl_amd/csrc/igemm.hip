@@ -599,6 +599,7 @@ int launch_tn_as(const TNArgs &a_in, hipStream_t stream) {
 // barrier pairs -- small ones (rollout batches) smaller tiles so that >= 256 workgroups exist.
 //   N <= 32 : 512x32 (4 waves of 128x32)  |  256x32 (4 waves of 64x32)
 //   N >= 64 : 256x64 (4 waves of 64x64)   |  128x64 (4 waves of 64x32)  |  64x64 (4 waves of 32x32)
+#ifdef DX_EXPERIMENT_B3
 static int split_bf16() {  // DX_SPLIT_BF16=1: big NT stages on the bf16 matrix cores (3-way split)
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_SPLIT_BF16"); v = e ? atoi(e) : 0; }
@@ -609,6 +610,7 @@ static int split_min_m() {
   if (v < 0) { const char *e = getenv("DX_SPLIT_MIN_M"); v = e ? atoi(e) : 65536; }
   return v;
 }
+#endif
 static int nt_big_min_m() {  // DX_NT_BIG_MIN_M: rows from which the N=64 stages use 128x64 tiles
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_NT_BIG_MIN_M"); v = e ? atoi(e) : 65536; }
@@ -640,10 +642,12 @@ int launch_nt(const NTArgs &a_in, bool a_u8, int epi, int stage, hipStream_t str
     const int rc = launch_nt_lat(a, a_u8, epi, stage, stream);
     if (rc != DX_ENOSUP) return rc;
   }
+#ifdef DX_EXPERIMENT_B3  // build flag DERL_AMD_EXPERIMENTS=1: csrc/experiments/igemm_b3.hip (negative result)
   if (split_bf16() && !a_u8 && a.M >= split_min_m()) {
     const int rc = launch_nt_b3(a, epi, stage, stream);
     if (rc != DX_ENOSUP) return rc;
   }
+#endif
   switch (stage) {
     case ST_CONV0_FWD:
       DX_REQUIRE(epi == EPI_BIAS_RELU && a.N <= 32, "igemm_nt: conv0 forward needs bias+relu, N <= 32");

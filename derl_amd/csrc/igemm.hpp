@@ -189,4 +189,12 @@ int launch_heads_act_fused(const float *hid_slabs, int nslab, long long slab_str
                            uint64_t counter, int64_t *actions, float *log_prob, float *values,
                            hipStream_t stream);
 
+// the rollout step's last launch against the synthetic device env: heads + sampling and the
+// next observation batch / rewards / resets in ONE grid (heads.hip)
+int launch_heads_act_synth(const float *hid_slabs, int nslab, long long slab_stride, const float *Wh,
+                           const float *bh, int B, int A, uint64_t seed, uint64_t counter, int64_t *actions,
+                           float *log_prob, float *values, void *frames, long long frame_bytes, float *rewards,
+                           uint8_t *resets, uint64_t env_seed, uint64_t env_counter, float p_reward,
+                           float p_reset, hipStream_t stream);
+
 }  // namespace dx

@@ -112,6 +112,7 @@ NTArgs nt(const Gather &g, const float *Wp, const float *bias, float *out, int l
 extern "C" {
 
 int dx_mlp_init(dx_mlp_ctx *c) {
+  DX_TRACE("dx_mlp_init");
   DX_REQUIRE(c != nullptr, "dx_mlp_init: null ctx");
   DX_REQUIRE(c->struct_bytes == static_cast<int>(sizeof(dx_mlp_ctx)),
              "dx_mlp_init: struct size mismatch (caller %d, library %d)", c->struct_bytes,
@@ -166,6 +167,7 @@ static int check_mlp(const dx_mlp_ctx *c, const char *who, long long B, bool bwd
 
 // canonical parameters -> padded / transposed mirrors (after every parameter change)
 int dx_mlp_pack(const dx_mlp_ctx *c, void *stream) {
+  DX_TRACE("dx_mlp_pack");
   if (int rc = check_mlp(c, "dx_mlp_pack", 1, false)) return rc;
   if (use_fused(c)) return DX_OK;  // the fused kernels read the canonical parameters
   hipStream_t s = as_stream(stream);
@@ -187,6 +189,7 @@ int dx_mlp_pack(const dx_mlp_ctx *c, void *stream) {
 
 // obs (B, obs_dim) float32 -> ctx->head (B, 32); keeps xpad, h1, h2 of both nets for backward
 int dx_mlp_forward(const dx_mlp_ctx *c, const float *obs, int B, void *stream) {
+  DX_TRACE("dx_mlp_forward");
   if (int rc = check_mlp(c, "dx_mlp_forward", B, false)) return rc;
   DX_REQUIRE(obs != nullptr, "dx_mlp_forward: null observations");
   hipStream_t s = as_stream(stream);
@@ -215,6 +218,7 @@ int dx_mlp_forward(const dx_mlp_ctx *c, const float *obs, int B, void *stream) {
 // ctx->dhead (B, 32) -> ctx->grads (every tensor except logstd, which the Gaussian loss
 // kernel writes itself), using the activations of the matching dx_mlp_forward
 int dx_mlp_backward(const dx_mlp_ctx *c, int B, void *stream) {
+  DX_TRACE("dx_mlp_backward");
   if (int rc = check_mlp(c, "dx_mlp_backward", B, true)) return rc;
   hipStream_t s = as_stream(stream);
   const int D = c->obs_dim, P = c->policy_out, Dp = c->obs_pad;

@@ -187,6 +187,7 @@ extern "C" int dx_normalize_step_f32(const float *obs, int N, int D, const float
                                      double *ret, double *workspace, long long workspace_count,
                                      float clipobs, float cliprew, double gamma, double eps,
                                      int update_stats, float *obs_out, float *rew_out, void *stream) {
+  DX_TRACE("dx_normalize_step_f32");
   DX_REQUIRE(N >= 1 && D >= 1, "dx_normalize_step_f32: bad shape N=%d D=%d", N, D);
   DX_REQUIRE(obs && obs_out, "dx_normalize_step_f32: null observations");
   DX_REQUIRE(!rewards || (ret && rew_out), "dx_normalize_step_f32: rewards need ret and rew_out");

@@ -104,6 +104,7 @@ extern "C" int dx_reward_summary_f32(const float *rewards, const uint8_t *resets
                                      int record, double *acc, double *ep_len, uint8_t *ended,
                                      double *queue, int *qlen, int *qpos, long long *step_count,
                                      double *rows, int max_rows, int *nrows, void *stream) {
+  DX_TRACE("dx_reward_summary_f32");
   DX_REQUIRE(T >= 1 && N >= 1 && Q >= 1 && max_rows >= 0, "dx_reward_summary_f32: bad shape T=%d N=%d Q=%d", T, N, Q);
   DX_REQUIRE(rewards && resets && acc && ep_len && ended && queue && qlen && qpos && step_count && rows && nrows,
              "dx_reward_summary_f32: null pointer");

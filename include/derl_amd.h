@@ -329,19 +329,6 @@ int dx_synth_atari_step(void *frames, long long frame_bytes_total, float *reward
                         uint8_t *resets, int nenvs, uint64_t seed, uint64_t counter,
                         float p_reward, float p_reset, void *stream);
 
-/* Diagnostic: `blocks` workgroups of 4 waves, every wave issuing iters x 4 independent
- * v_mfma_f32_32x32x2_f32 with no memory traffic (blocks * 4 * iters * 4 * 4096 flop): what the
- * fp32 matrix pipe sustains on this part, timed by the caller (tools/mfma_peak.py). */
-int dx_diag_mfma_f32(int blocks, int iters, float *out, void *stream);
-/* The same flop count as one dependent accumulation chain per wave. */
-int dx_diag_mfma_f32_chain(int blocks, int iters, float *out, void *stream);
-/* The K loop of the 128x64 GEMM tile fed from LDS only (no global loads, LDS writes or barriers):
- * blocks x 4 waves x iters x 32 MFMAs; mode 0 reads fragments right before use, 1 one step ahead. */
-int dx_diag_lds_mfma_f32(int blocks, int iters, int mode, float *out, void *stream);
-/* The NT GEMM K loop rebuilt step by step on plain row-major operands (tools/gemm_loop.py). */
-int dx_diag_gemm_loop_f32(const float *A, const float *B, int tiles, int ktiles, int what, float *out,
-                          void *stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -66,3 +66,40 @@ def test_missing_library_fails_loudly(lib, monkeypatch, tmp_path):
     lib.load()
   with pytest.raises(lib.NativeError):
     lib.call("dx_abi_version")
+
+
+def test_diagnostics_live_in_their_own_header_and_library(lib):
+  """dx_diag_* microbenchmarks are not part of the product boundary: declared in
+  include/derl_amd_diag.h, exported by libderl_amd_diag.so only."""
+  import ctypes
+  from derl_amd import build
+  assert not [name for name in header_functions() if name.startswith("dx_diag")]
+  text = open(os.path.join(ROOT, "include", "derl_amd_diag.h")).read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  names = sorted(set(re.findall(r"\b(dx_diag_[a-z0-9_]+)\s*\(", text)))
+  assert len(names) >= 4
+  product = lib.load()
+  for name in names:
+    assert not hasattr(product, name), f"{name} leaked into libderl_amd.so"
+  path = build.build_diag_library()
+  diag = ctypes.CDLL(path)
+  for name in names:
+    assert hasattr(diag, name), f"{name} declared in derl_amd_diag.h but not exported"
+
+
+def test_host_layer_under_address_sanitizer():
+  """The sanitizer build of the shim: every product source compiled
+  host-only with -fsanitize=address, driven through the validation / planning layer of every
+  entry point by tools/asan_host_check.py with clang's ASan runtime preloaded."""
+  import subprocess
+  import sys
+  from derl_amd import build
+  runtime = build.asan_runtime()
+  if runtime is None or not os.path.exists(build.HIPCC):
+    pytest.skip("no hipcc / ASan runtime on this box")
+  build.build_host_asan()
+  env = dict(os.environ, LD_PRELOAD=runtime, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_host_check.py")], env=env,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0 and "asan host check OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+  assert "AddressSanitizer" not in out.stderr

@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from derl_amd import _lib  # noqa: E402
+from tools import _diag  # noqa: E402
 
 dev = torch.device("cuda:0")
 out = torch.zeros(4, device=dev)
@@ -46,11 +47,11 @@ thread = threading.Thread(target=sampler, daemon=True)
 thread.start()
 time.sleep(0.5)
 print("== idle", samples[-1][1] if samples else None, flush=True)
-phase("pure MFMA loop", lambda: _lib.call("dx_diag_mfma_f32", 1024, 20000, _lib.ptr(out), stream))
+phase("pure MFMA loop", lambda: _diag.call("dx_diag_mfma_f32", 1024, 20000, _lib.ptr(out), stream))
 tiles, ktiles = 5184, 16
 A = torch.randn(tiles * 128, 32 * ktiles, device=dev)
 B = torch.randn(64, 32 * ktiles, device=dev)
-phase("GEMM loop without global loads", lambda: _lib.call("dx_diag_gemm_loop_f32", _lib.ptr(A), _lib.ptr(B), tiles, ktiles, 1, _lib.ptr(out), stream))
-phase("GEMM loop with global loads (HBM stream)", lambda: _lib.call("dx_diag_gemm_loop_f32", _lib.ptr(A), _lib.ptr(B), tiles, ktiles, 2, _lib.ptr(out), stream))
-phase("GEMM loop, A cache-resident", lambda: _lib.call("dx_diag_gemm_loop_f32", _lib.ptr(A), _lib.ptr(B), tiles, ktiles, 4, _lib.ptr(out), stream))
+phase("GEMM loop without global loads", lambda: _diag.call("dx_diag_gemm_loop_f32", _lib.ptr(A), _lib.ptr(B), tiles, ktiles, 1, _lib.ptr(out), stream))
+phase("GEMM loop with global loads (HBM stream)", lambda: _diag.call("dx_diag_gemm_loop_f32", _lib.ptr(A), _lib.ptr(B), tiles, ktiles, 2, _lib.ptr(out), stream))
+phase("GEMM loop, A cache-resident", lambda: _diag.call("dx_diag_gemm_loop_f32", _lib.ptr(A), _lib.ptr(B), tiles, ktiles, 4, _lib.ptr(out), stream))
 stop[0] = True

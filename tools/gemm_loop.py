@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from derl_amd import _lib  # noqa: E402
+from tools import _diag  # noqa: E402
 
 dev = torch.device("cuda:0")
 out = torch.zeros(4, device=dev)
@@ -17,11 +18,11 @@ for tiles, ktiles in ((5184, 16), (1024, 98), (1024, 16)):
   B = torch.randn(64, 32 * ktiles, device=dev)
   for what in (2, 3, 7, 8):
     for _ in range(3):
-      _lib.call("dx_diag_gemm_loop_f32", _lib.ptr(A), _lib.ptr(B), tiles, ktiles, what, _lib.ptr(out), stream)
+      _diag.call("dx_diag_gemm_loop_f32", _lib.ptr(A), _lib.ptr(B), tiles, ktiles, what, _lib.ptr(out), stream)
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     for _ in range(10):
-      _lib.call("dx_diag_gemm_loop_f32", _lib.ptr(A), _lib.ptr(B), tiles, ktiles, what, _lib.ptr(out), stream)
+      _diag.call("dx_diag_gemm_loop_f32", _lib.ptr(A), _lib.ptr(B), tiles, ktiles, what, _lib.ptr(out), stream)
     end.record()
     end.synchronize()
     us = start.elapsed_time(end) * 100

@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from derl_amd import _lib  # noqa: E402
+from tools import _diag  # noqa: E402
 
 dev = torch.device("cuda:0")
 out = torch.zeros(4, device=dev)
@@ -16,11 +17,11 @@ for entry in ("dx_diag_mfma_f32", "dx_diag_mfma_f32_chain"):
   for blocks_per_cu in (1, 2, 4):
     blocks, iters = 256 * blocks_per_cu, 20000
     for _ in range(2):
-      _lib.call(entry, blocks, iters, _lib.ptr(out), stream)
+      _diag.call(entry, blocks, iters, _lib.ptr(out), stream)
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     for _ in range(5):
-      _lib.call(entry, blocks, iters, _lib.ptr(out), stream)
+      _diag.call(entry, blocks, iters, _lib.ptr(out), stream)
     end.record()
     end.synchronize()
     ms = start.elapsed_time(end) / 5
@@ -32,11 +33,11 @@ for mode, rnd in ((0, 1), (1, 1), (1, -1), (2, 1), (3, 1)):  # modes 2 / 3: eigh
   for blocks_per_cu in (1, 2, 4):
     blocks, iters = 256 * blocks_per_cu, 4000
     for _ in range(2 if rnd > 0 else 40):
-      _lib.call("dx_diag_lds_mfma_f32", blocks, rnd * iters, mode, _lib.ptr(out), stream)
+      _diag.call("dx_diag_lds_mfma_f32", blocks, rnd * iters, mode, _lib.ptr(out), stream)
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     for _ in range(5):
-      _lib.call("dx_diag_lds_mfma_f32", blocks, rnd * iters, mode, _lib.ptr(out), stream)
+      _diag.call("dx_diag_lds_mfma_f32", blocks, rnd * iters, mode, _lib.ptr(out), stream)
     end.record()
     end.synchronize()
     ms = start.elapsed_time(end) / 5
