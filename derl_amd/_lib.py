@@ -46,6 +46,7 @@ SIGNATURES = {
     "dx_mlp_pack": [P, P],
     "dx_mlp_forward": [P, P, c_int, P],
     "dx_mlp_backward": [P, c_int, P],
+    "dx_mlp_ppo_epoch": [P, P, P],
     "dx_normal_act_f32": [P, P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
     "dx_normal_loss_f32": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
                            c_longlong, P, P, P, c_int, P, P],
@@ -146,6 +147,22 @@ def stream_ptr(device=None):
     if isinstance(index, int):
       return c_void_p(_raw_stream(index))
   return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class MlpEpoch(ctypes.Structure):
+  """Mirror of ``dx_mlp_epoch`` (include/derl_amd.h); dx_mlp_ppo_epoch checks the size."""
+  _fields_ = [
+      ("struct_bytes", c_int), ("mbsize", c_int), ("samples", c_longlong),
+      ("obs", c_void_p), ("actions", c_void_p), ("action_is_f32", c_int), ("mode", c_int),
+      ("old_log_prob", c_void_p), ("advantages", c_void_p), ("old_values", c_void_p),
+      ("value_targets", c_void_p), ("normalize", c_int), ("norm_eps", c_float),
+      ("cliprange", c_float), ("value_loss_coef", c_float), ("entropy_coef", c_float),
+      ("global_batch", c_longlong), ("adv_normalized", c_void_p), ("stats", c_void_p),
+      ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("sumsq_partials", c_void_p),
+      ("npartials", c_int), ("loss_partials_capacity", c_int), ("loss_partials", c_void_p),
+      ("max_grad_norm", c_double), ("lr", c_double), ("beta1", c_double), ("beta2", c_double),
+      ("adam_eps", c_double), ("first_step", c_longlong), ("grad_norm_out", c_void_p),
+      ("loss_out", c_void_p)]
 
 
 class MlpCtx(ctypes.Structure):

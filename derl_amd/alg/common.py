@@ -101,7 +101,48 @@ class Trainer:
         grad_norm = total_norm(p.grad for p in parameters if p.grad is not None)
       summary.add_scalar(tag, grad_norm, global_step=self.step_count)
 
+  # -- native epochs ------------------------------------------------------------------------
+  native_epochs = True  # False: always one host call per update
+
+  def _epoch_fast_path(self, alg, data):
+    """(context, k) when EVERY update of this minibatch's epoch can be (or already was) enqueued
+    from one native call: MLP engine, flat Adam, single process, no summaries being recorded,
+    and the minibatch is the untouched slice of the epoch's arrays.  A caller that abandons an
+    epoch halfway still gets all of its updates applied -- set ``native_epochs = False`` then."""
+    if not self.native_epochs or summary.should_record() or distributed.world_size() > 1:
+      return None
+    state = data.get("state")
+    entry = state.get("epoch") if isinstance(state, dict) else None
+    engine = getattr(alg.model, "engine", None)
+    if (entry is None or not hasattr(self.optimizer, "native_epoch") or type(alg).loss is not Alg.loss
+        or not hasattr(engine, "ppo_epoch") or not hasattr(alg.loss_fn, "epoch_arguments")):
+      return None
+    context, k = entry
+    start = k * context.mbsize
+    for key in ("value_targets", "actions", "observations"):  # still the epoch's own slices?
+      mine, whole = data.get(key), context.shuffled.get(key)
+      if not isinstance(mine, torch.Tensor) or whole is None or mine.data_ptr() != whole[start:].data_ptr():
+        return None
+    if not context.consumed and k != 0:
+      return None  # joined mid-epoch: step by step
+    return context, k
+
+  def _step_epoch(self, alg, context, k):
+    for anneal in self.anneals:
+      anneal.step_to(alg.runner.step_count)
+    if not context.consumed:
+      self.optimizer.max_grad_norm = self.max_grad_norm
+      self.optimizer.native_epoch(alg.loss_fn, context)
+      context.consumed = True
+    alg.loss_fn.last_terms = context.losses[k]
+    alg.loss_fn.call_count += 1
+    self.step_count += 1
+    return context.losses[k, 0]
+
   def step(self, alg, data):
+    fast = self._epoch_fast_path(alg, data)
+    if fast is not None:
+      return self._step_epoch(alg, *fast)
     native = None
     if isinstance(self.optimizer, _FlatOptimizer) and type(alg).loss is Alg.loss:
       native = getattr(alg.loss_fn, "evaluate_native", None)

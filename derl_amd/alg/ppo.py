@@ -85,6 +85,11 @@ class PPOLoss(ActorCriticDeviceLoss):
     terms, _ = self._evaluate(trajectory, self.cliprange, self.value_loss_coef, self.entropy_coef)
     return terms[3]
 
+  def epoch_arguments(self):
+    """Hyper-parameters of the fused loss kernels for a native epoch (Trainer.step)."""
+    return dict(mode=0, cliprange=self.cliprange, value_loss_coef=self.value_loss_coef,
+                entropy_coef=self.entropy_coef, normalize_eps=1e-8)
+
   def evaluate_native(self, data):
     """(loss scalar on the device, closure running the model backward): what ``__call__``
     wraps into an autograd scalar; Trainer.step calls the closure directly."""

@@ -108,3 +108,63 @@ class MlpEngine:
     """Consumes self.dhead (B, 32) and fills self.grads (logstd is written by the loss)."""
     _lib.call("dx_mlp_backward", ctypes.byref(self.ctx), int(batch), _lib.stream_ptr(self.device))
     return self.grads
+
+  def ppo_epoch(self, context, loss, optimizer, first_step):
+    """Enqueues every minibatch update of ``context`` (runners.onpolicy.EpochContext): advantage
+    normalisation, forward, fused loss, backward, gradient norm, clip + Adam per minibatch, all
+    from one C call.  Returns the number of updates."""
+    arrays = context.shuffled
+    samples, mbsize = context.sample_size, context.mbsize
+    f32 = torch.float32
+
+    def need(key, dtype=f32):
+      t = arrays.get(key)
+      if t is None or not t.is_cuda or not t.is_contiguous() or t.shape[0] != samples:
+        raise _lib.NativeError(f"native epoch: '{key}' is not an epoch array of {samples} rows on the device")
+      return t if t.dtype == dtype else t.to(dtype)
+
+    obs = need("observations")
+    if obs.ndim != 2 or obs.shape[1] != self.obs_dim:
+      raise _lib.NativeError(f"native epoch: observations must be (n, {self.obs_dim})")
+    actions = need("actions", f32 if self.has_logstd else torch.int64)
+    ppo = loss["mode"] == 0
+    old_lp = need("log_prob") if ppo else None
+    old_v = need("values").reshape(-1) if ppo else None
+    adv = need("advantages").reshape(-1)
+    vt = need("value_targets").reshape(-1)
+    self.reserve(mbsize)
+    updates = context.num_minibatches
+    dev = self.device
+    context.normalized = torch.empty(samples, dtype=f32, device=dev)
+    context.norm_eps = loss["normalize_eps"]
+    context.losses = torch.empty((updates, 8), dtype=f32, device=dev)
+    if getattr(self, "_epoch_scratch", None) is None:
+      self._epoch_scratch = torch.empty(3, dtype=torch.float64, device=dev)
+    capacity = 40 * ((mbsize + 255) // 256) if self.has_logstd else 8 * ((mbsize + 7) // 8)
+    if getattr(self, "_epoch_partials", None) is None or self._epoch_partials.numel() < capacity:
+      self._epoch_partials = torch.empty(capacity, dtype=torch.float64, device=dev)
+    e = _lib.MlpEpoch()
+    e.struct_bytes = ctypes.sizeof(_lib.MlpEpoch)
+    e.mbsize, e.samples = int(mbsize), int(samples)
+    e.obs, e.actions = obs.data_ptr(), actions.data_ptr()
+    e.action_is_f32, e.mode = int(self.has_logstd), int(loss["mode"])
+    e.old_log_prob = old_lp.data_ptr() if ppo else None
+    e.old_values = old_v.data_ptr() if ppo else None
+    e.advantages, e.value_targets = adv.data_ptr(), vt.data_ptr()
+    e.normalize, e.norm_eps = 1, float(loss["normalize_eps"])
+    cliprange = loss.get("cliprange")
+    e.cliprange = float(cliprange) if cliprange is not None else -1.0
+    e.value_loss_coef, e.entropy_coef = float(loss["value_loss_coef"]), float(loss["entropy_coef"])
+    e.global_batch = 0
+    e.adv_normalized, e.stats = context.normalized.data_ptr(), self._epoch_scratch.data_ptr()
+    e.exp_avg, e.exp_avg_sq = optimizer.exp_avg.data_ptr(), optimizer.exp_avg_sq.data_ptr()
+    e.sumsq_partials, e.npartials = optimizer.partials.data_ptr(), optimizer.partials.numel()
+    e.loss_partials, e.loss_partials_capacity = self._epoch_partials.data_ptr(), int(capacity)
+    e.max_grad_norm = float(optimizer.max_grad_norm) if optimizer.max_grad_norm is not None else 0.0
+    e.lr, e.beta1, e.beta2 = optimizer.current_lr(), float(optimizer.betas[0]), float(optimizer.betas[1])
+    e.adam_eps, e.first_step = float(optimizer.eps), int(first_step)
+    e.grad_norm_out, e.loss_out = optimizer.grad_norm.data_ptr(), context.losses.data_ptr()
+    keep = (obs, actions, old_lp, old_v, adv, vt)  # alive until the call has been enqueued
+    _lib.call("dx_mlp_ppo_epoch", ctypes.byref(self.ctx), ctypes.byref(e), _lib.stream_ptr(dev))
+    del keep
+    return updates

@@ -77,6 +77,13 @@ class Adam(_FlatOptimizer):
                        self.betas[0], self.betas[1], self.eps, self.grad_norm)
     self.engine.mark_dirty()
 
+  def native_epoch(self, loss_fn, context):
+    """Every minibatch update of an epoch from one native call (MLP engines: dx_mlp_ppo_epoch);
+    fills ``context.losses`` / ``context.normalized`` and advances the step count."""
+    updates = self.engine.ppo_epoch(context, loss_fn.epoch_arguments(), self, self.step_count + 1)
+    self.step_count += updates
+    self.engine.mark_dirty()
+
   def state_dict(self):
     return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq)
 

@@ -14,6 +14,22 @@ from ..models import GatheredRows
 LAZY_ROW_BYTES = 4096
 
 
+class EpochContext:
+  """What the minibatches of one epoch share: the epoch's permuted small arrays (minibatch k is
+  rows [k * mbsize, (k + 1) * mbsize) of each) -- enough for a trainer to enqueue EVERY update of
+  the epoch from one native call when its first minibatch is stepped (Trainer.step,
+  dx_mlp_ppo_epoch), after which ``losses`` (one row of loss terms per minibatch) and
+  ``normalized`` (every minibatch's normalised advantages) are filled in."""
+  STATE_KEY = "epoch"
+
+  def __init__(self, shuffled, sample_size, mbsize):
+    self.shuffled, self.sample_size, self.mbsize = shuffled, sample_size, mbsize
+    self.num_minibatches = -(-sample_size // mbsize)
+    self.consumed = False
+    self.losses = None
+    self.normalized = None
+
+
 class TransformInteractions(RunnerWrapper):
   """Transforms interactions by applying a list of callables (onpolicy.py:11-30).  Lists
   from the generic runner are stacked (``np.asarray`` / ``torch.stack``); the
@@ -161,6 +177,7 @@ class IterateWithMinibatches(RunnerWrapper):
       for epoch, order in enumerate(orders):
         order_dev = orders_dev[epoch] if orders_dev is not None else None
         shuffled = self._gather_epoch(interactions, order_dev)
+        context = EpochContext(shuffled, sample_size, mbsize) if shuffled else None
         for start in range(0, sample_size, mbsize):
           stop = min(start + mbsize, sample_size)
           index_host = order[start:stop]
@@ -168,6 +185,9 @@ class IterateWithMinibatches(RunnerWrapper):
           minibatch = self._select_all(interactions, shuffled, start, stop, index_dev, index_host)
           if extras is not None:
             minibatch["state"] = dict(minibatch.get("state") or {}, **extras(epoch, start // mbsize))
+          if context is not None:
+            minibatch["state"] = dict(minibatch.get("state") or {},
+                                      **{EpochContext.STATE_KEY: (context, start // mbsize)})
           yield minibatch
 
 

@@ -116,6 +116,13 @@ class NormalizeAdvantages:
       advantages = to_device(advantages, torch.device("cuda"), torch.float32)
     flat = advantages.reshape(-1)
     state = trajectory.get("state")
+    epoch = state.get("epoch") if isinstance(state, dict) else None
+    if epoch is not None and epoch[0].normalized is not None and epoch[0].norm_eps == self.epsilon:
+      # the trainer enqueued this epoch's updates natively and normalised every minibatch on the way
+      context, k = epoch
+      start = k * context.mbsize
+      trajectory["advantages"] = context.normalized[start:start + flat.numel()].reshape(advantages.shape)
+      return
     ready = state.get(self.STATE_KEY) if isinstance(state, dict) else None
     if ready is not None:
       out = ops.adv_normalize(flat, self.epsilon, stats=ready, stats_ready=True)

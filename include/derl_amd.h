@@ -304,6 +304,46 @@ int dx_mlp_pack(const dx_mlp_ctx *ctx, void *stream);
 int dx_mlp_forward(const dx_mlp_ctx *ctx, const float *obs, int B, void *stream);
 int dx_mlp_backward(const dx_mlp_ctx *ctx, int B, void *stream);
 
+/* Every minibatch update of one epoch of the MLP actor-critic from ONE call -- the loop of
+ * derl/alg/common.py:66-78 (Trainer.step) over the minibatches of
+ * derl/runners/onpolicy.py:44-62, with derl/runners/trajectory_transforms.py:84-92's
+ * per-minibatch advantage normalisation.  The arrays are the EPOCH's permuted copies (what
+ * dx_gather_rows_multi produces); minibatch k is rows [k*mbsize, (k+1)*mbsize).  The launches are
+ * those of the per-step entry points in the same order (bit-identical results); loss_out gets
+ * 8 floats per minibatch (the loss kernels' terms).  Adam only (derl/factory/ppo.py:78-81);
+ * `lr` is constant over the call (the schedule follows the runner's step count, which does not
+ * move inside an epoch, derl/alg/common.py:72-75). */
+typedef struct dx_mlp_epoch {
+  int struct_bytes;
+  int mbsize;
+  long long samples;
+  const float *obs;            /* (samples, obs_dim)                                     */
+  const void *actions;         /* (samples, P) float32 (Gaussian) or (samples) int64     */
+  int action_is_f32;
+  int mode;                    /* 0 = PPO, 1 = A2C                                        */
+  const float *old_log_prob;   /* (samples) or NULL (A2C)                                 */
+  const float *advantages;     /* (samples), raw                                          */
+  const float *old_values;     /* (samples) or NULL (A2C)                                 */
+  const float *value_targets;  /* (samples)                                               */
+  int normalize;               /* 1: (a - mean) / (std + norm_eps) per minibatch          */
+  float norm_eps;
+  float cliprange, value_loss_coef, entropy_coef;
+  long long global_batch;      /* 0 = the minibatch size                                  */
+  float *adv_normalized;       /* (samples): every minibatch's normalised advantages      */
+  double *stats;               /* (3) scratch                                             */
+  float *exp_avg, *exp_avg_sq; /* Adam state (param_count)                                */
+  double *sumsq_partials;
+  int npartials;
+  int loss_partials_capacity;
+  double *loss_partials;
+  double max_grad_norm;        /* <= 0: no clipping                                       */
+  double lr, beta1, beta2, adam_eps;
+  long long first_step;        /* Adam's step number of minibatch 0 (1-based)             */
+  float *grad_norm_out;        /* (1) pre-clip norm of the LAST minibatch, or NULL        */
+  float *loss_out;             /* (ceil(samples / mbsize), 8)                             */
+} dx_mlp_epoch;
+int dx_mlp_ppo_epoch(const dx_mlp_ctx *ctx, const dx_mlp_epoch *epoch, void *stream);
+
 /* Diagonal-Gaussian head -- replaces Independent(Normal(mean, exp(logstd)), 1) of
  * derl/policies.py:40-42,66,76-77 and the PPO/A2C loss on it (derl/alg/ppo.py:24-108) with
  * its gradient w.r.t. mean, value and logstd.
