@@ -480,20 +480,17 @@ __global__ __launch_bounds__(256) void normal_loss_kernel(const NormalLossArgs a
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(64) void dlogstd_reduce_kernel(const double *partials, int nblocks, int P,
-                                                            float *dlogstd) {
-  const int d = threadIdx.x;
-  if (d >= P) return;
-  double s = 0.0;
-  for (int i = 0; i < nblocks; ++i) s += partials[i * 40 + 8 + d];
-  dlogstd[d] = static_cast<float>(s);
-}
-
 // the categorical loss_reduce_kernel with a row stride of 40 doubles
 __global__ __launch_bounds__(256) void loss_reduce40_kernel(const double *partials, int nblocks,
                                                             double count, float value_loss_coef,
-                                                            float entropy_coef, float *out) {
+                                                            float entropy_coef, float *out, int P,
+                                                            float *dlogstd) {
   __shared__ double red[4][8];
+  if (dlogstd != nullptr && static_cast<int>(threadIdx.x) < P) {  // dL/dlogstd: the block partials summed in block order
+    double t = 0.0;
+    for (int i = 0; i < nblocks; ++i) t += partials[i * 40 + 8 + threadIdx.x];
+    dlogstd[threadIdx.x] = static_cast<float>(t);
+  }
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = threadIdx.x; i < nblocks; i += blockDim.x)
 #pragma unroll
@@ -560,10 +557,9 @@ extern "C" int dx_normal_loss_f32(const float *head_out, const float *logstd, co
   hipStream_t s = dx::as_stream(stream);
   hipLaunchKernelGGL(normal_loss_kernel, dim3(blocks), dim3(256), 0, s, a);
   DX_LAUNCH_CHECK();
+  // the loss terms and dL/dlogstd from the block partials in ONE single-block launch
   hipLaunchKernelGGL(loss_reduce40_kernel, dim3(1), dim3(256), 0, s, partials, blocks, static_cast<double>(B),
-                     value_loss_coef, entropy_coef, loss_out);
-  DX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dlogstd_reduce_kernel, dim3(1), dim3(64), 0, s, partials, blocks, P, dlogstd_out);
+                     value_loss_coef, entropy_coef, loss_out, P, dlogstd_out);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
