@@ -60,6 +60,13 @@ int wgrad_direct_min_batch() {
   return v;
 }
 
+// DX_NT_DMA=0: linear-layer forward / dgrad on the implicit-GEMM kernel instead of nt_dma.hip
+bool nt_dma_on() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_NT_DMA"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 constexpr int kBiasChunks = 256;  // row chunks of the linear layer's bias-gradient launch (512 workgroups)
 
 int roundup(long long v, int m) { return static_cast<int>((v + m - 1) / m * m); }
@@ -458,6 +465,10 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a.Wb = planes(c, c->pb_fcf); a.wb_plane = static_cast<long long>(kHid) * flat;
       a.ksplit = ks;
       a.slab_stride = static_cast<long long>(B) * kHid;
+      if (ks == 1 && nt_dma_on() && nt_dma_supported(B, kHid, flat)) {
+        const NtDmaArgs d{c->y2, pk + c->pk_fcf, w + c->off_b[3], nullptr, c->hid, B, kHid, flat, flat, kHid};
+        return launch_nt_dma(d, EPI_BIAS, s);
+      }
       if (int rc = launch_nt(a, false, EPI_BIAS, stage, s)) return rc;
       if (ks == 1) return DX_OK;
       PermuteJob jr{c->hid_slabs, c->hid, static_cast<long long>(B) * kHid, 1, 1, 1, 1, 0, 0, 0, 0, ks,
@@ -480,6 +491,10 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       }
       return tn(L_FC, rows_gather(c->y2, flat), c->dhid, kHid, B, kHid, flat, false);
     case ST_FC_DGRAD:
+      if (nt_dma_on() && nt_dma_supported(B, flat, kHid)) {
+        const NtDmaArgs d{c->dhid, pk + c->pk_fcd, nullptr, c->y2, c->dy2, B, flat, kHid, kHid, flat};
+        return launch_nt_dma(d, EPI_MASK, s);
+      }
       a = nt_args(rows_gather(c->dhid, kHid), pk + c->pk_fcd, nullptr, c->dy2, flat, B, flat, kHid);
       a.Wb = planes(c, c->pb_fcd); a.wb_plane = static_cast<long long>(kHid) * flat;
       a.mask_src = c->y2;

@@ -109,6 +109,17 @@ int launch_nt_pix(const NTArgs &a, int nimg, int epi, int stage, hipStream_t str
 int launch_nt_lat(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t stream);
 // 3xbf16-split variant of the big NT stages (igemm_b3.hip); DX_ENOSUP = not covered
 int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream);
+// plain row-major NT GEMM fed by LDS-DMA (nt_dma.hip): the linear layer's forward and dgrad
+struct NtDmaArgs {
+  const float *A;  // [M][lda]
+  const float *W;  // [N][K]
+  const float *bias;      // EPI_BIAS
+  const float *mask_src;  // EPI_MASK, [M][ldc]
+  float *out;      // [M][ldc]
+  int M, N, K, lda, ldc;
+};
+bool nt_dma_supported(int M, int N, int K);
+int launch_nt_dma(const NtDmaArgs &a, int epi, hipStream_t stream);
 constexpr int kMaxSplitJobs = 8;
 int launch_split_planes(const float *const *src, uint16_t *const *dst, const long long *count, int njobs,
                         hipStream_t stream);

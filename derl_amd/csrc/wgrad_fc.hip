@@ -92,7 +92,9 @@ __global__ __launch_bounds__(512, 2) void fc_wgrad_kernel(const FcWgradArgs a) {
     // the barrier it has for everyone, and nobody reads slot (s + 2) % 3 = (s - 1) % 3 any more
     if (s + 1 < send) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(a.diag & 2)) __syncthreads();
+    // not __syncthreads(): its fence makes the compiler wait vmcnt(0), i.e. for the stage in flight
+    if (!(a.diag & 2)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if (s + 2 < send && !(a.diag & 1)) {
       const int nslot = slot >= 1 ? slot - 1 : slot + 2;
       DX_FC_ISSUE(s + 2, nslot)
