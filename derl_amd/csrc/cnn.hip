@@ -60,6 +60,38 @@ int wgrad_direct_min_batch() {
   return v;
 }
 
+// DX_ROLLOUT_LANES=1: the native rollout on the caller's stream only (default 2: see
+// dx_cnn_rollout_synth)
+int rollout_lanes() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_ROLLOUT_LANES"); v = e ? atoi(e) : 2; }
+  return v;
+}
+
+// The one piece of state the library owns: a side stream and two events per device for the
+// two-lane rollout, created on first use and kept for the life of the process.
+constexpr int kMaxLanes = 4;
+struct SideStream { hipStream_t stream[kMaxLanes - 1]; hipEvent_t fork, join[kMaxLanes - 1]; };
+SideStream *side_stream() {
+  static SideStream table[16];
+  static bool made[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { fail(DX_EHIP, "side_stream: no current device"); return nullptr; }
+  if (!made[dev]) {
+    SideStream &t = table[dev];
+    bool ok = hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < kMaxLanes - 1; ++i)
+      ok = hipStreamCreateWithFlags(&t.stream[i], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&t.join[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      fail(DX_EHIP, "side_stream: cannot create the rollout's side streams");
+      return nullptr;
+    }
+    made[dev] = true;
+  }
+  return &table[dev];
+}
+
 // DX_NT_DMA=0: linear-layer forward / dgrad on the implicit-GEMM kernel instead of nt_dma.hip
 bool nt_dma_on() {
   static int v = -1;
@@ -658,16 +690,54 @@ int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_
   const long long frame = static_cast<long long>(c->in_h) * c->in_w * c->in_c * N;
   DX_REQUIRE(frame % 16 == 0, "dx_cnn_rollout_synth: frame batch must be a multiple of 16 bytes");
   hipStream_t s = as_stream(stream);
+  // Lanes: the envs are cut into equal parts whose steps are independent chains (part A's step
+  // t + 1 needs only part A's step t), enqueued on the caller's stream and on side streams, so
+  // that one part's launch tails and ramps overlap the others' compute.  Frames, rewards and resets
+  // are bit-identical to the one-lane rollout and the samples come from the same stream positions
+  // (both are indexed by the env's position in the whole batch); log-probs and values agree to
+  // float32 rounding (a half batch may take a different tile shape).  DX_ROLLOUT_LANES=1: off.
+  int lanes = rollout_lanes() < kMaxLanes ? rollout_lanes() : kMaxLanes;
+  while (lanes > 1 && !(N / lanes >= 64 && N % (4 * lanes) == 0 && (frame / lanes) % 16 == 0 &&
+                        static_cast<long long>(lanes) * fc_ksplit(N / lanes, c->flat) * (N / lanes) * kHid <= c->hid_slab_count))
+    --lanes;
+  SideStream *side = lanes > 1 ? side_stream() : nullptr;
+  if (lanes > 1 && side == nullptr) return DX_EHIP;
+  const int part = N / lanes;
+  const long long pframe = frame / lanes;
+  dx_cnn_ctx lane_ctx[kMaxLanes];
+  for (int l = 0; l < lanes; ++l) {
+    dx_cnn_ctx &b = lane_ctx[l];
+    b = *c;
+    const long long first = static_cast<long long>(l) * part;
+    b.y0 += first * c->h0 * c->w0 * kC0;
+    b.y1 += first * c->h1 * c->w1 * kC1;
+    b.y2 += first * c->flat;
+    b.hid_slabs += fc_ksplit(part, c->flat) * first * kHid;
+    b.hid_slab_count -= fc_ksplit(part, c->flat) * first * kHid;
+  }
+  if (lanes > 1) {
+    DX_HIP(hipEventRecord(side->fork, s));
+    for (int l = 1; l < lanes; ++l) DX_HIP(hipStreamWaitEvent(side->stream[l - 1], side->fork, 0));
+  }
   for (int t = 0; t < T; ++t) {
-    NTArgs a;
-    if (int rc = act_trunk(c, obs + t * frame, 1, N, &a, s)) return rc;
-    const long long row = static_cast<long long>(t) * N;
-    if (int rc = launch_heads_act_synth(c->hid_slabs, a.ksplit, a.slab_stride, c->packed + c->pk_hdf,
-                                        c->packed + c->pk_hdb, N, c->num_actions, policy_seed,
-                                        policy_counter + t, actions + row, log_prob + row, values + row,
-                                        obs + (t + 1) * frame, frame, rewards + row, resets + row, env_seed,
-                                        env_counter + t, p_reward, p_reset, s))
-      return rc;
+    for (int l = 0; l < lanes; ++l) {
+      hipStream_t ls = l == 0 ? s : side->stream[l - 1];
+      const dx_cnn_ctx *lc = &lane_ctx[l];
+      NTArgs a;
+      if (int rc = act_trunk(lc, obs + t * frame + l * pframe, 1, part, &a, ls)) return rc;
+      const long long row = static_cast<long long>(t) * N + l * part;
+      if (int rc = launch_heads_act_synth(lc->hid_slabs, a.ksplit, a.slab_stride, c->packed + c->pk_hdf,
+                                          c->packed + c->pk_hdb, part, c->num_actions, policy_seed,
+                                          policy_counter + t, actions + row, log_prob + row, values + row,
+                                          obs + (t + 1) * frame + l * pframe, pframe, rewards + row,
+                                          resets + row, env_seed, env_counter + t, p_reward, p_reset, l * part,
+                                          l * (pframe / 16), ls))
+        return rc;
+    }
+  }
+  for (int l = 1; l < lanes; ++l) {
+    DX_HIP(hipEventRecord(side->join[l - 1], side->stream[l - 1]));
+    DX_HIP(hipStreamWaitEvent(s, side->join[l - 1], 0));
   }
   return DX_OK;
 }

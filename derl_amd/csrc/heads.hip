@@ -122,6 +122,7 @@ struct HeadsActArgs {
   uint64_t seed, counter;
   int64_t *actions;
   float *log_prob, *values;
+  int b0;  // index of row 0 in the whole batch (sampling stream position of a batch slice)
 };
 
 __device__ __forceinline__ void heads_act_fused_block(const HeadsActArgs &p, int block) {
@@ -196,7 +197,7 @@ __device__ __forceinline__ void heads_act_fused_block(const HeadsActArgs &p, int
     acc += lane_value(e, k);
     if (k == col) cdf = acc;
   }
-  const float u = uniforms ? u_given : uniform01(seed, counter, b);
+  const float u = uniforms ? u_given : uniform01(seed, counter, b + p.b0);
   const float thresh = u * acc;
   const unsigned long long below = __ballot(is_logit && cdf <= thresh);
   int a = __popcll(below & 0xffffffffull);
@@ -616,7 +617,7 @@ int launch_heads_act_fused(const float *hid_slabs, int nslab, long long slab_str
                            hipStream_t stream) {
   DX_REQUIRE(B >= 1 && A >= 1 && A <= 31 && nslab >= 1, "heads_act: bad shape B=%d A=%d nslab=%d", B, A, nslab);
   DX_REQUIRE(hid_slabs && Wh && bh && actions && log_prob && values, "heads_act: null pointer");
-  const HeadsActArgs p{hid_slabs, nslab, slab_stride, Wh, bh, B, A, uniforms, seed, counter, actions, log_prob, values};
+  const HeadsActArgs p{hid_slabs, nslab, slab_stride, Wh, bh, B, A, uniforms, seed, counter, actions, log_prob, values, 0};
   hipLaunchKernelGGL(heads_act_fused_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, p);
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -626,14 +627,14 @@ int launch_heads_act_synth(const float *hid_slabs, int nslab, long long slab_str
                            const float *bh, int B, int A, uint64_t seed, uint64_t counter, int64_t *actions,
                            float *log_prob, float *values, void *frames, long long frame_bytes, float *rewards,
                            uint8_t *resets, uint64_t env_seed, uint64_t env_counter, float p_reward,
-                           float p_reset, hipStream_t stream) {
+                           float p_reset, int env0, long long vec0, hipStream_t stream) {
   DX_REQUIRE(B >= 1 && A >= 1 && A <= 31 && nslab >= 1, "heads_act_synth: bad shape B=%d A=%d nslab=%d", B, A, nslab);
   DX_REQUIRE(hid_slabs && Wh && bh && actions && log_prob && values, "heads_act_synth: null pointer");
   DX_REQUIRE(frames && frame_bytes > 0 && frame_bytes % 16 == 0 && aligned(frames, 16),
              "heads_act_synth: frames must be 16-byte aligned, size a multiple of 16");
-  const HeadsActArgs p{hid_slabs, nslab, slab_stride, Wh, bh, B, A, nullptr, seed, counter, actions, log_prob, values};
+  const HeadsActArgs p{hid_slabs, nslab, slab_stride, Wh, bh, B, A, nullptr, seed, counter, actions, log_prob, values, env0};
   const SynthArgs e{static_cast<uint4 *>(frames), frame_bytes / 16, rewards, resets, B, env_seed, env_counter,
-                    p_reward, p_reset};
+                    p_reward, p_reset, vec0, env0};
   const int hb = cdiv(B, 4);
   hipLaunchKernelGGL(heads_act_synth_kernel, dim3(hb + synth_blocks(e.nvec, B)), dim3(256), 0, stream, p, e, hb);
   DX_LAUNCH_CHECK();

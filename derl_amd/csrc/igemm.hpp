@@ -206,6 +206,8 @@ int launch_heads_act_synth(const float *hid_slabs, int nslab, long long slab_str
                            const float *bh, int B, int A, uint64_t seed, uint64_t counter, int64_t *actions,
                            float *log_prob, float *values, void *frames, long long frame_bytes, float *rewards,
                            uint8_t *resets, uint64_t env_seed, uint64_t env_counter, float p_reward,
-                           float p_reset, hipStream_t stream);
+                           float p_reset, int env0, long long vec0, hipStream_t stream);
+// (env0, vec0): position of this launch's first env / first 16-byte frame vector in the whole
+// batch, so that a slice of the envs draws exactly what the whole-batch launch draws for it
 
 }  // namespace dx

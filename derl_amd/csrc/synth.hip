@@ -20,7 +20,7 @@ extern "C" int dx_synth_atari_step(void *frames, long long frame_bytes_total, fl
              "dx_synth_atari_step: frames must be 16-byte aligned, size a multiple of 16");
   DX_REQUIRE(nenvs >= 0, "dx_synth_atari_step: nenvs < 0");
   const long long nvec = frame_bytes_total / 16;
-  const dx::SynthArgs a{static_cast<uint4 *>(frames), nvec, rewards, resets, nenvs, seed, counter, p_reward, p_reset};
+  const dx::SynthArgs a{static_cast<uint4 *>(frames), nvec, rewards, resets, nenvs, seed, counter, p_reward, p_reset, 0, 0};
   hipLaunchKernelGGL(synth_atari_kernel, dim3(dx::synth_blocks(nvec, nenvs)), dim3(256), 0,
                      dx::as_stream(stream), a);
   DX_LAUNCH_CHECK();

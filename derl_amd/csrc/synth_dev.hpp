@@ -16,6 +16,8 @@ struct SynthArgs {
   int nenvs;
   uint64_t seed, counter;
   float p_reward, p_reset;
+  long long vec0;     // position of frames[0] / rewards[0] in the whole batch: a launch that covers
+  int env0;           // a slice of the envs draws the values the whole-batch launch would
 };
 
 __device__ __forceinline__ uint64_t synth_mix64(uint64_t z) {
@@ -29,13 +31,14 @@ __device__ __forceinline__ void synth_atari_block(const SynthArgs &a, int block,
   const long long stride = static_cast<long long>(nblocks) * 256;
   const long long gid = static_cast<long long>(block) * 256 + threadIdx.x;
   for (long long i = gid; i < a.nvec; i += stride) {
-    const uint64_t x = synth_mix64(key + 2 * static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull);
-    const uint64_t y = synth_mix64(key + (2 * static_cast<uint64_t>(i) + 1) * 0x9E3779B97F4A7C15ull);
+    const uint64_t p = static_cast<uint64_t>(i + a.vec0);
+    const uint64_t x = synth_mix64(key + 2 * p * 0x9E3779B97F4A7C15ull);
+    const uint64_t y = synth_mix64(key + (2 * p + 1) * 0x9E3779B97F4A7C15ull);
     a.frames[i] = make_uint4(static_cast<uint32_t>(x), static_cast<uint32_t>(x >> 32),
                              static_cast<uint32_t>(y), static_cast<uint32_t>(y >> 32));
   }
   for (long long e = gid; e < a.nenvs; e += stride) {
-    const uint64_t r = synth_mix64(~key + static_cast<uint64_t>(e) * 0xD1B54A32D192ED03ull);
+    const uint64_t r = synth_mix64(~key + static_cast<uint64_t>(e + a.env0) * 0xD1B54A32D192ED03ull);
     const float u0 = static_cast<float>(r & 0xffffff) * (1.0f / 16777216.0f);
     const float u1 = static_cast<float>((r >> 24) & 0xffffff) * (1.0f / 16777216.0f);
     if (a.rewards) a.rewards[e] = u0 < a.p_reward ? ((r >> 63) ? -1.f : 1.f) : 0.f;

@@ -466,3 +466,36 @@ def test_inplace_writes_through_parameters_refresh_packed_weights(kind):
   with torch.no_grad():
     next(iter(model.parameters())).mul_(0.5)
   check("in-place op on one parameter")
+
+
+def test_two_lane_native_rollout_matches_per_step_loop():
+  """From 128 envs on, dx_cnn_rollout_synth runs the two halves of the envs as two chains on two
+  streams.  Against the Python per-step loop (whole batch per launch): observations, rewards and
+  resets bit-identical, samples from the same stream positions (a logit that differs in the last
+  bit may flip a sample on a CDF boundary), log-probs and values to float32 rounding."""
+  import derl_amd as derl
+  from derl_amd.policies import ActorCriticPolicy
+
+  def rollout(use_fused):
+    torch.manual_seed(0)
+    model = derl.NatureCNNModel([4, 1], max_batch=256)
+    policy = ActorCriticPolicy(model, seed=5)
+    if not use_fused:
+      policy.rollout_into = lambda *a, **k: False
+    env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=256, seed=2)
+    runner = derl.EnvRunner(env, policy, horizon=5, nsteps=256 * 5 * 2)
+    outs = []
+    for inter in runner.run():
+      outs.append({k: v.clone() for k, v in inter.items() if isinstance(v, torch.Tensor)})
+    return outs
+
+  a, b = rollout(True), rollout(False)
+  assert len(a) == len(b) == 2
+  for x, y in zip(a, b):
+    for k in ("observations", "rewards", "resets"):
+      assert torch.equal(x[k], y[k]), k
+    same = x["actions"] == y["actions"]
+    assert (~same).float().mean().item() <= 2e-3
+    for k in ("log_prob", "values"):
+      if k in x:
+        nt.assert_allclose(x[k][same].cpu().numpy(), y[k][same].cpu().numpy(), rtol=1e-4, atol=2e-5)
