@@ -571,6 +571,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a.om.OHW = OHp * OWp; a.om.OW = OWp;
       a.om.div_img = make_fastdiv(a.om.OHW); a.om.div_row = make_fastdiv(OWp);
       a.om.OUT_H = c->h0; a.om.OUT_W = c->w0; a.om.osy = a.om.osx = 2; a.om.chan = kC0;
+      if (const int rc = launch_ntp_pix(a, B, 2, 2, s); rc != DX_ENOSUP) return rc;
       if (const int rc = launch_nt_pix(a, B, EPI_MASK, stage, s); rc != DX_ENOSUP) return rc;
       return launch_nt(a, false, EPI_MASK, stage, s);
     }

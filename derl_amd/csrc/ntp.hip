@@ -25,13 +25,41 @@
 #include "igemm_dev.hpp"
 
 namespace dx {
+namespace ntp {
+constexpr int kBK = 32;  // K elements per stage
+
+// Tile shape of one instantiation.  BM x BN tile, consumer waves of 64 x (32 TN), NLOAD loader waves,
+// RING stages of (BM + BN) rows x 128 bytes, WGS workgroups per CU.
+template <int BM_, int BN_, int TN_, int RING_, int NLOAD_, int WGS_>
+struct Shape {
+  static constexpr int BM = BM_, BN = BN_, TN = TN_, RING = RING_, NLOAD = NLOAD_, WGS = WGS_;
+  static constexpr int WN = BN / (32 * TN), NCONS = (BM / 64) * WN, THREADS = 64 * (NCONS + NLOAD);
+  static constexpr int STAGE_FLOATS = (BM + BN) * kBK;
+  static constexpr int APIECES = BM / 8 / NLOAD, WPIECES = BN / 8 / NLOAD;  // per loader wave and stage
+  static constexpr int LDS_BYTES = RING * STAGE_FLOATS * 4;
+  static_assert(BM % 64 == 0 && BN % (32 * TN) == 0 && (BM / 8) % NLOAD == 0 && (BN / 8) % NLOAD == 0, "tile shape");
+};
+using ShapeS = Shape<128, 64, 1, 3, 4, 2>;   // 64-column stages: 4 + 4 waves, two workgroups per CU
+using ShapeL = Shape<256, 128, 2, 2, 4, 1>;  // 128-column stages: 8 + 4 waves, one workgroup per CU
+
+}  // namespace ntp
 namespace {
+using ntp::ShapeS;
+using ntp::ShapeL;
+using ntp::kBK;
 
 using f4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kBM = 128, kBN = 64, kBK = 32, kRing = 3;
-constexpr int kStageFloats = (kBM + kBN) * kBK;  // 6144 floats = 24 KiB
-constexpr int kDma = 6;                          // LDS-DMA instructions per wave per stage
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane addresses to 1 KiB of LDS at `dst` (uniform).
+// A plain function, not the builtin spelled inside the kernel template: with template-dependent
+// arguments hipcc's host pass silently drops the whole kernel instantiation (no stub is emitted).
+__device__ __forceinline__ void dma_piece(const char *base, uint32_t lane_offset, float *dst) {
+  // `base` uniform, `lane_offset` a 32-bit register: selects the SGPR-base form (no address VALU).
+  // The empty asm keeps the compiler from widening the offset to 64 bits ahead of the loop, after
+  // which it adds the base with v_lshl_add_u64 per piece.
+  asm volatile("" : "+v"(lane_offset));
+  __builtin_amdgcn_global_load_lds(base + lane_offset, dst, 16, 0, 0);
+}
 
 struct NtpArgs {
   NTArgs nt;
@@ -58,7 +86,7 @@ struct Cursor {
   int ta_hi, tb_lo, tb_hi;
 };
 
-template <int MODE>
+template <int MODE, int BM>
 __device__ __forceinline__ void open_tile(Cursor &c, const NtpArgs &p) {
   const Gather &g = p.nt.g;
   if (MODE == 0) {
@@ -83,7 +111,7 @@ __device__ __forceinline__ void open_tile(Cursor &c, const NtpArgs &p) {
 }
 
 // -> true when the step just left was the last of its tile
-template <int MODE>
+template <int MODE, int BM>
 __device__ __forceinline__ bool advance(Cursor &c, const NtpArgs &p) {
   c.q += kBK;
   if (c.q < p.nt.g.seglen) return false;
@@ -92,73 +120,88 @@ __device__ __forceinline__ bool advance(Cursor &c, const NtpArgs &p) {
   c.tb = c.tb_lo;
   if (++c.ta <= c.ta_hi) return false;
   ++c.i;
-  open_tile<MODE>(c, p);
+  open_tile<MODE, BM>(c, p);
   return true;
 }
 
-template <int MODE, int EPI>
-__global__ __launch_bounds__(512, 2) void ntp_kernel(const NtpArgs p, unsigned long long *stamps) {
+// (the shape is spelled out as integers: with a class parameter in __launch_bounds__ hipcc emits no
+// host stub for the instantiations)
+template <int MODE, int EPI, int BM, int BN, int TN, int RING, int NLOAD, int WGS>
+__global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD), WGS) void ntp_kernel(const NtpArgs p,
+                                                                                                unsigned long long *stamps) {
+  using S = ntp::Shape<BM, BN, TN, RING, NLOAD, WGS>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const unsigned long long t_entry = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   const NTArgs &a = p.nt;
   const Gather &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = wave8 & 3;  // index inside its role
   Cursor first;
   first.i = 0;
-  open_tile<MODE>(first, p);
+  open_tile<MODE, BM>(first, p);
   if (!first.valid) return;  // uniform: this workgroup has no tile
 
-  if (wave8 >= 4) {
+  if (wave8 >= S::NCONS) {
     // ================= loader waves: fills only =================
-    // wave w fills A pieces 4w .. 4w+3 (rows 32w .. 32w+31) and W pieces 2w, 2w+1 of every stage
+    // loader l fills A pieces l, l + NLOAD, ... (8 rows each) and W pieces l, l + NLOAD, ... of every stage
+    const int wave = wave8 - S::NCONS;
     const int lrow = lane >> 3;
-    const float *wp[2];
+    // Addresses are a UNIFORM 64-bit base (tensor + the step's offset: scalar adds) plus a per-lane
+    // 32-bit byte offset that changes only with the tile: the fill then issues no vector ALU
+    // instruction at all (global_load_lds with an SGPR base).  A loader shares its SIMD with
+    // consumers that keep the matrix pipe full; every VALU instruction it issued waited for a gap
+    // there (measured: ~800 cycles per fill instruction with 64-bit per-lane address adds).
+    uint32_t wv[S::WPIECES];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = (2 * wave + j) * 8 + lrow;
-      wp[j] = a.Wp + static_cast<long long>(n) * a.K + 4 * ((lane & 7) ^ ((n >> 1) & 7));
+    for (int j = 0; j < S::WPIECES; ++j) {
+      const int n = (wave + S::NLOAD * j) * 8 + lrow;
+      wv[j] = (static_cast<uint32_t>(n) * a.K + 4 * ((lane & 7) ^ ((n >> 1) & 7))) * 4u;
     }
-    const float *ap[4];
+    uint32_t av[S::APIECES];
     Cursor ld = first;  // where the NEXT fill goes
 #define DX_NTP_ROWS()                                                                            \
-  _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                             \
-    const int R = 32 * wave + 8 * q_ + lrow;                                                     \
+  _Pragma("unroll") for (int q_ = 0; q_ < S::APIECES; ++q_) {                                    \
+    const int R = (wave + S::NLOAD * q_) * 8 + lrow;                                             \
     const int chunk = (lane & 7) ^ ((R >> 1) & 7);                                               \
-    long long base;                                                                              \
+    uint32_t base;                                                                               \
     if (MODE == 0) {                                                                             \
-      const uint32_t m = ld.tile * kBM + R;                                                      \
+      const uint32_t m = ld.tile * BM + R;                                                       \
       const uint32_t img = fdiv(m, g.div_img), rem = m - img * g.OHW;                            \
       const uint32_t oy = fdiv(rem, g.div_row), ox = rem - oy * g.OW;                            \
-      base = static_cast<long long>(img) * g.img_stride + (oy * g.sy * g.W + ox * g.sx) * g.C;   \
+      base = img * static_cast<uint32_t>(g.img_stride) + (oy * g.sy * g.W + ox * g.sx) * g.C;    \
     } else {                                                                                     \
-      base = static_cast<long long>(ld.tile * kBM + R) * g.img_stride;                           \
+      base = static_cast<uint32_t>(ld.tile * BM + R) * static_cast<uint32_t>(g.img_stride);      \
     }                                                                                            \
-    ap[q_] = static_cast<const float *>(g.src) + base + 4 * chunk;                               \
+    av[q_] = (base + 4 * chunk) * 4u;                                                            \
   }
 #define DX_NTP_FILL(SLOT)                                                                        \
   {                                                                                              \
-    float *dst_ = smem + (SLOT) * kStageFloats;                                                  \
-    const int ao_ = ld.pixoff + ld.ta * p.PA + ld.tb * p.PB + ld.q;                              \
-    const int ko_ = (ld.ta * p.TB + ld.tb) * g.seglen + ld.q;                                    \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                             \
-        __builtin_amdgcn_global_load_lds(ap[q_] + ao_, dst_ + (4 * wave + q_) * 256, 16, 0, 0); \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                             \
-        __builtin_amdgcn_global_load_lds(wp[j_] + ko_, dst_ + (16 + 2 * wave + j_) * 256, 16, 0, 0); \
+    float *dst_ = smem + (SLOT) * S::STAGE_FLOATS;                                               \
+    const char *abase_ = static_cast<const char *>(g.src) +                                      \
+                         4LL * (ld.pixoff + ld.ta * p.PA + ld.tb * p.PB + ld.q);                 \
+    const char *wbase_ = reinterpret_cast<const char *>(a.Wp) +                                  \
+                         4LL * ((ld.ta * p.TB + ld.tb) * g.seglen + ld.q);                       \
+    _Pragma("unroll") for (int q_ = 0; q_ < S::APIECES; ++q_)                                    \
+        dma_piece(abase_, av[q_], dst_ + (wave + S::NLOAD * q_) * 256);                         \
+    _Pragma("unroll") for (int j_ = 0; j_ < S::WPIECES; ++j_)                                    \
+        dma_piece(wbase_, wv[j_], dst_ + (BM / 8 + wave + S::NLOAD * j_) * 256);                \
     const int before_ = ld.tile;                                                                 \
-    if (advance<MODE>(ld, p) && ld.valid && (MODE == 0 || ld.tile != before_)) { DX_NTP_ROWS() } \
+    if (advance<MODE, BM>(ld, p) && ld.valid && (MODE == 0 || ld.tile != before_)) { DX_NTP_ROWS() } \
     ++issued;                                                                                    \
   }
     DX_NTP_ROWS()
-    int issued = 0, slot = 2;  // slot of the next fill
-    DX_NTP_FILL(0)
-    if (ld.valid) DX_NTP_FILL(1)
+    int issued = 0, slot = 0;  // slot of the next fill
+    for (int r = 0; r < S::RING - 1; ++r)
+      if (r == 0 || ld.valid) {
+        DX_NTP_FILL(slot)
+        ++slot;
+      }
+    slot = S::RING - 1;
     unsigned long long l_vm = 0, l_bar = 0, l_all = stamps ? __builtin_amdgcn_s_memtime() : 0;
     for (int gstep = 0; gstep < issued; ++gstep) {
-      // hand step gstep over: its fill is the oldest in flight, at most one younger fill behind it
+      // hand step gstep over: its fill is the oldest in flight, at most RING - 2 younger fills behind it
       const unsigned long long l0 = (stamps && (p.diag & 2)) ? __builtin_amdgcn_s_memtime() : 0;
-      if (issued - gstep >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
+      if (S::RING == 3 && issued - gstep >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::APIECES + S::WPIECES) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned long long l1 = (stamps && (p.diag & 2)) ? __builtin_amdgcn_s_memtime() : 0;
       __builtin_amdgcn_s_barrier();  // consumers are done with step gstep - 1: its slot is free
@@ -166,24 +209,26 @@ __global__ __launch_bounds__(512, 2) void ntp_kernel(const NtpArgs p, unsigned l
       if (stamps && (p.diag & 2)) { l_vm += l1 - l0; l_bar += __builtin_amdgcn_s_memtime() - l1; }
       if (ld.valid && !(p.diag & 4)) {
         DX_NTP_FILL(slot)
-        slot = slot == kRing - 1 ? 0 : slot + 1;
+        slot = slot == S::RING - 1 ? 0 : slot + 1;
       } else if (ld.valid) {  // diagnostic: walk the cursor without filling
-        advance<MODE>(ld, p);
+        advance<MODE, BM>(ld, p);
         ++issued;
       }
     }
 #undef DX_NTP_FILL
 #undef DX_NTP_ROWS
     if (stamps && lane == 0) {  // loader stamps behind the consumers': total, vmcnt wait, barrier wait
-      unsigned long long *o = stamps + static_cast<long long>(gridDim.x) * 4 * 7 + (static_cast<long long>(blockIdx.x) * 4 + wave) * 3;
+      unsigned long long *o = stamps + static_cast<long long>(gridDim.x) * S::NCONS * 7 +
+                              (static_cast<long long>(blockIdx.x) * S::NLOAD + wave) * 3;
       o[0] = __builtin_amdgcn_s_memtime() - l_all; o[1] = l_vm; o[2] = l_bar;
     }
     return;
   }
 
   // ================= consumer waves: fragment reads, MFMAs, epilogues =================
+  const int wave = wave8;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves of 64 x 32
+  const int wm = wave / S::WN, wn = wave % S::WN;  // waves of 64 x (32 TN)
   const char *lds = reinterpret_cast<const char *>(smem);
   const unsigned x = (l31 >> 1) & 7;
   unsigned aoff[4], boff[4];
@@ -191,20 +236,25 @@ __global__ __launch_bounds__(512, 2) void ntp_kernel(const NtpArgs p, unsigned l
   for (int q = 0; q < 4; ++q) {
     const unsigned slot = ((2 * q + hi) ^ x) * 16;
     aoff[q] = (wm * 64 + l31) * 128 + slot;
-    boff[q] = (kBM + wn * 32 + l31) * 128 + slot;
+    boff[q] = (BM + wn * 32 * TN + l31) * 128 + slot;
   }
-  f32x16 acc[2];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
   Cursor cs = first;  // the step being multiplied
   int slot = 0;
-  const int n = wn * 32 + l31;
-  const float bias = (EPI == EPI_BIAS_RELU) ? a.bias[n] : 0.f;
-  // a use of the bias in front of the loop: otherwise the compiler waits for this load at its
-  // first use, inside the epilogue
-  asm volatile("" ::"v"(bias));
+  float bias[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bias[j] = (EPI == EPI_BIAS_RELU) ? a.bias[wn * 32 * TN + 32 * j + l31] : 0.f;
+    // a use of the bias in front of the loop: otherwise the compiler waits for this load at its
+    // first use, inside the epilogue
+    asm volatile("" ::"v"(bias[j]));
+  }
 
   const unsigned long long t_loop = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   const unsigned long long c_loop = stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -217,72 +267,101 @@ __global__ __launch_bounds__(512, 2) void ntp_kernel(const NtpArgs p, unsigned l
     if (stamps && (p.diag & 2)) c_wait += __builtin_amdgcn_s_memtime() - c_w0;
     ++nsteps;
     if (p.diag & 64) {  // diagnostic: loaders alone (no fragment reads, no MFMAs)
-      slot = slot == kRing - 1 ? 0 : slot + 1;
-      advance<MODE>(cs, p);
+      slot = slot == S::RING - 1 ? 0 : slot + 1;
+      advance<MODE, BM>(cs, p);
       continue;
     }
-    const char *base = lds + slot * kStageFloats * 4;
-    f4 af[2][2], bf[2];
+    const char *base = lds + slot * S::STAGE_FLOATS * 4;
+    f4 af[2][2], bf[2][TN];
     af[0][0] = *reinterpret_cast<const f4 *>(base + aoff[0]);
     af[0][1] = *reinterpret_cast<const f4 *>(base + aoff[0] + 32 * 128);
-    bf[0] = *reinterpret_cast<const f4 *>(base + boff[0]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f4 *>(base + boff[0] + j * 32 * 128);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = q & 1, nx = c ^ 1;
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0][0], bf[c][0], acc[0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0][0], bf[c][0][0], acc[0][0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (q + 1 < 4) {  // the next group's fragments, requested in the first MFMA's shadow
         af[nx][0] = *reinterpret_cast<const f4 *>(base + aoff[q + 1]);
         af[nx][1] = *reinterpret_cast<const f4 *>(base + aoff[q + 1] + 32 * 128);
-        bf[nx] = *reinterpret_cast<const f4 *>(base + boff[q + 1]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[nx][j] = *reinterpret_cast<const f4 *>(base + boff[q + 1] + j * 32 * 128);
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][1][0], bf[c][0], acc[1], 0, 0, 0);
 #pragma unroll
-      for (int e = 1; e < 4; ++e) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0][e], bf[c][e], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][1][e], bf[c][e], acc[1], 0, 0, 0);
-      }
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if (e + t + j > 0)
+              acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][t][e], bf[c][j][e], acc[t][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    slot = slot == kRing - 1 ? 0 : slot + 1;
+    slot = slot == S::RING - 1 ? 0 : slot + 1;
 
     const int tile = cs.tile, pix = cs.pix;
-    if (!advance<MODE>(cs, p)) continue;
+    if (!advance<MODE, BM>(cs, p)) continue;
     // ---- epilogue of (tile, pix): C/D layout column = l31, row = (r & 3) + 8 (r >> 2) + 4 hi.
-    // Tiles are never ragged (the launchers require whole tiles).
-    const int row0 = tile * kBM + wm * 64 + 4 * hi;  // GEMM row (MODE 0) or image (MODE 1)
+    // Tiles are never ragged (the launchers require whole tiles): a guarded store or load here is
+    // a branch, and the compiler then drains vmcnt at the loop header.
+    const int row0 = tile * BM + wm * 64 + 4 * hi;  // GEMM row (MODE 0) or image (MODE 1)
     if (p.diag & 16) {  // diagnostic: no epilogue traffic
     } else if (MODE == 0) {
-      float *o = a.out + static_cast<long long>(row0) * a.ldc + n;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int j = 0; j < TN; ++j) {
+        float *o = a.out + static_cast<long long>(row0) * a.ldc + wn * 32 * TN + 32 * j + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          o[static_cast<long long>(32 * t + (r & 3) + 8 * (r >> 2)) * a.ldc] = fmaxf(acc[t][r] + bias, 0.f);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            o[static_cast<long long>(32 * t + (r & 3) + 8 * (r >> 2)) * a.ldc] = fmaxf(acc[t][j][r] + bias[j], 0.f);
+      }
     } else {
-      const long long imgo = static_cast<long long>(g.OHW) * a.ldc;
-      const long long o0 = static_cast<long long>(row0) * imgo + static_cast<long long>(pix) * a.ldc + n;
-      float mk[2][16];
+      const OutMap &om = a.om;
+      const int oy = fdiv(pix, g.div_row), ox = pix - oy * g.OW;
+      long long imgo, o0[TN];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int j = 0; j < TN; ++j) {
+        const int nb = wn * 32 * TN + 32 * j;  // uniform: first column of this 32-wide block
+        if (om.enabled) {  // column block -> (py, px) of the osy x osx output pixels of this row
+          const int gq = nb / om.chan;
+          const int py = gq / om.osx, px = gq - py * om.osx;
+          imgo = static_cast<long long>(om.OUT_H) * om.OUT_W * a.ldc;
+          o0[j] = static_cast<long long>((oy * om.osy + py) * om.OUT_W + ox * om.osx + px) * a.ldc + (nb - gq * om.chan) + l31;
+        } else {
+          imgo = static_cast<long long>(g.OHW) * a.ldc;
+          o0[j] = static_cast<long long>(pix) * a.ldc + nb + l31;
+        }
+        o0[j] += static_cast<long long>(row0) * imgo;
+      }
+      float mk[TN][2][16];  // every mask load ahead of the first store
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mk[t][r] = a.mask_src[o0 + (32 * t + (r & 3) + 8 * (r >> 2)) * imgo];
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          a.out[o0 + (32 * t + (r & 3) + 8 * (r >> 2)) * imgo] = mk[t][r] > 0.f ? acc[t][r] : 0.f;
+          for (int r = 0; r < 16; ++r) mk[j][t][r] = a.mask_src[o0[j] + (32 * t + (r & 3) + 8 * (r >> 2)) * imgo];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            a.out[o0[j] + (32 * t + (r & 3) + 8 * (r >> 2)) * imgo] = mk[j][t][r] > 0.f ? acc[t][j][r] : 0.f;
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
     ++ntiles;
   }
   if (stamps && lane == 0) {  // DX_NTP_DIAG: 100 MHz ticks (entry, loop start, exit), loop cycles, wait cycles, steps, tiles
-    unsigned long long *o = stamps + (static_cast<long long>(blockIdx.x) * 4 + wave) * 7;
+    unsigned long long *o = stamps + (static_cast<long long>(blockIdx.x) * S::NCONS + wave) * 7;
     o[0] = t_entry; o[1] = t_loop; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = __builtin_amdgcn_s_memtime() - c_loop;
     o[4] = c_wait; o[5] = nsteps; o[6] = ntiles;
   }
@@ -294,25 +373,25 @@ bool ntp_on() {  // DX_NTP=0: these stages on the per-tile kernels
   return v != 0;
 }
 
-int ntp_workgroups() {  // DX_NTP_NWG: resident workgroups (default 512 = two per CU)
+int ntp_workgroups(int per_cu) {  // DX_NTP_NWG: resident workgroups (default: every CU full)
   static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NTP_NWG"); v = e ? atoi(e) : 512; }
-  return v < 8 ? 8 : v / 8 * 8;
+  if (v < 0) { const char *e = getenv("DX_NTP_NWG"); v = e ? atoi(e) : 0; }
+  const int n = v > 0 ? v : 256 * per_cu;
+  return n < 8 ? 8 : n / 8 * 8;
 }
 
-template <int MODE, int EPI>
+template <int MODE, int EPI, class S>
 int launch_as(const NtpArgs &p, hipStream_t stream) {
-  constexpr int lds = kRing * kStageFloats * 4;
   static bool configured = false;
   if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntp_kernel<MODE, EPI>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntp_kernel<MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES));
     configured = true;
   }
   static const int diag = getenv("DX_NTP_DIAG") ? atoi(getenv("DX_NTP_DIAG")) : 0;
-  const int grid = ntp_workgroups();
+  const int grid = ntp_workgroups(S::WGS);
   if (!diag) {
-    hipLaunchKernelGGL((ntp_kernel<MODE, EPI>), dim3(grid), dim3(512), lds, stream, p, nullptr);
+    hipLaunchKernelGGL((ntp_kernel<MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, p, nullptr);
     DX_LAUNCH_CHECK();
     return DX_OK;
   }
@@ -320,10 +399,10 @@ int launch_as(const NtpArgs &p, hipStream_t stream) {
   NtpArgs pd = p;
   pd.diag = diag;
   unsigned long long *dev = nullptr;
-  const size_t count = static_cast<size_t>(grid) * 4 * 7, lcount = static_cast<size_t>(grid) * 4 * 3;
+  const size_t count = static_cast<size_t>(grid) * S::NCONS * 7, lcount = static_cast<size_t>(grid) * S::NLOAD * 3;
   DX_HIP(hipMalloc(&dev, (count + lcount) * 8));
   DX_HIP(hipMemsetAsync(dev, 0, (count + lcount) * 8, stream));
-  hipLaunchKernelGGL((ntp_kernel<MODE, EPI>), dim3(grid), dim3(512), lds, stream, pd, dev);
+  hipLaunchKernelGGL((ntp_kernel<MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, pd, dev);
   DX_LAUNCH_CHECK();
   DX_HIP(hipStreamSynchronize(stream));
   std::vector<unsigned long long> h(count + lcount);
@@ -345,44 +424,64 @@ int launch_as(const NtpArgs &p, hipStream_t stream) {
   }
   auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
   auto mx = [](const std::vector<double> &v) { return *std::max_element(v.begin(), v.end()); };
-  fprintf(stderr, "[ntp mode %d M=%d K=%d grid=%d] span %.1f us | per wave: prologue %.2f us, loop median %.1f max %.1f us, "
-          "steps median %.0f max %.0f, %.0f cycles/step (ideal 4096), wait+barrier %.1f %% of the loop\n", MODE, p.nt.M, p.nt.K,
-          grid, (last - first) * 0.01, med(pro), med(loop), mx(loop), med(steps), mx(steps), med(cps), 100 * med(wfrac));
+  const int ideal = 2 * S::TN * 16 * 64 * (S::NCONS * S::WGS / 4);  // MFMA cycles of a step on a SIMD shared by NCONS WGS / 4 waves
+  fprintf(stderr, "[ntp mode %d %dx%d M=%d K=%d grid=%d] span %.1f us | per wave: prologue %.2f us, loop median %.1f max %.1f us, "
+          "steps median %.0f max %.0f, %.0f cycles/step (ideal %d), wait+barrier %.1f %% of the loop\n", MODE, S::BM, S::BN,
+          p.nt.M, p.nt.K, grid, (last - first) * 0.01, med(pro), med(loop), mx(loop), med(steps), mx(steps), med(cps), ideal,
+          100 * med(wfrac));
   if (!lvm.empty())
     fprintf(stderr, "        loaders: %.1f %% of their time waiting for a fill to land, %.1f %% at the barrier\n", 100 * med(lvm), 100 * med(lbar));
   return DX_OK;
 }
 
+// `rows`: GEMM rows (forward) or images (dgrad) in whole tiles, `tiles`: enough of them to fill the chip
+template <class S>
+bool shape_fits(const NTArgs &a, long long rows, long long tiles) {
+  const Gather &g = a.g;
+  return a.N == S::BN && !g.idx && a.ksplit == 1 && g.seglen % kBK == 0 && g.nseg <= kMaxSeg &&
+         a.K == g.nseg * g.seglen && rows % S::BM == 0 && tiles >= 256LL * S::WGS;
+}
+
 }  // namespace
 
-// Forward conv stage (bias + ReLU).  DX_ENOSUP = not covered: the caller keeps its own kernel.
+// Forward conv stage (bias + ReLU), 64 output channels.  DX_ENOSUP = not covered: the caller keeps
+// its own kernel.
 int launch_ntp_fwd(const NTArgs &a, hipStream_t stream) {
   const Gather &g = a.g;
-  if (!ntp_on() || a.N != kBN || g.idx || g.check || a.om.enabled || a.ksplit != 1 || g.seglen % kBK ||
-      g.nseg > kMaxSeg || a.K != g.nseg * g.seglen || a.M < kBM * 512 || a.M % kBM || a.ldc != kBN)
-    return DX_ENOSUP;
+  if (!ntp_on() || !shape_fits<ShapeS>(a, a.M, a.M / ShapeS::BM) || g.check || a.om.enabled || a.ldc != ShapeS::BN) return DX_ENOSUP;
   DX_REQUIRE(aligned(g.src, 16) && aligned(a.Wp, 16) && g.C % 4 == 0, "ntp: operands must be 16-byte aligned");
   NtpArgs p;
   p.nt = a;
-  p.ntiles = cdiv(a.M, kBM);
+  p.ntiles = a.M / ShapeS::BM;
   p.nimg = p.ngroups = p.tiles_per_xcd = p.diag = 0;
   p.TA = g.nseg; p.TB = 1; p.PA = g.nseg > 1 ? g.seg_off[1] : 0; p.PB = 0;
   for (int s2 = 0; s2 < g.nseg; ++s2)
     if (g.seg_off[s2] != s2 * p.PA) return DX_ENOSUP;
-  return launch_as<0, EPI_BIAS_RELU>(p, stream);
+  return launch_as<0, EPI_BIAS_RELU, ShapeS>(p, stream);
 }
 
-// dgrad stage tiled as one pixel x 128 images (ReLU mask from the kept activation)
+// dgrad stage tiled as one pixel x BM images (ReLU mask from the kept activation): 64 columns on
+// 128-image tiles, 128 columns (the stride-2 layer's four parity classes) on 256-image tiles
 int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream) {
   const Gather &g = a.g;
-  if (TA * TB != g.nseg || TB < 2 || g.sy != 1 || g.sx != 1 || !g.check) return DX_ENOSUP;
+  const OutMap &om = a.om;
+  if (!ntp_on() || TA * TB != g.nseg || TB < 2 || g.sy != 1 || g.sx != 1 || !g.check || !a.mask_src ||
+      static_cast<long long>(nimg) * g.OHW != a.M)
+    return DX_ENOSUP;
   for (int s2 = 0; s2 < g.nseg; ++s2)  // tap (ta, tb) reads pixel (y - ta, x - tb)
     if (g.seg_dy[s2] != -(s2 / TB) || g.seg_dx[s2] != -(s2 % TB) ||
         g.seg_off[s2] != (s2 / TB) * g.seg_off[TB] + (s2 % TB) * g.seg_off[1])
       return DX_ENOSUP;
-  if (!ntp_on() || a.N != kBN || g.idx || a.om.enabled || a.ksplit != 1 || g.seglen % kBK || g.nseg > kMaxSeg ||
-      a.K != g.nseg * g.seglen || nimg < kBM * 8 || nimg % kBM || static_cast<long long>(nimg) * g.OHW != a.M ||
-      !a.mask_src || a.ldc != kBN)
+  if (om.enabled) {  // every output pixel of every row exists, columns in whole 32-wide channel blocks
+    if (om.OHW != g.OHW || om.OW != g.OW || om.chan % 32 || a.ldc != om.chan || a.N != om.osy * om.osx * om.chan ||
+        om.OUT_H != (g.OHW / g.OW) * om.osy || om.OUT_W != g.OW * om.osx)
+      return DX_ENOSUP;
+  } else if (a.ldc != a.N) {
+    return DX_ENOSUP;
+  }
+  const bool large = a.N == ShapeL::BN;
+  if (!(large ? shape_fits<ShapeL>(a, nimg, 1LL * nimg / ShapeL::BM * g.OHW)
+              : shape_fits<ShapeS>(a, nimg, 1LL * nimg / ShapeS::BM * g.OHW)))
     return DX_ENOSUP;
   DX_REQUIRE(aligned(g.src, 16) && aligned(a.Wp, 16) && g.C % 4 == 0, "ntp: operands must be 16-byte aligned");
   NtpArgs p;
@@ -390,9 +489,9 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
   p.ntiles = p.diag = 0;
   p.TA = TA; p.TB = TB; p.PA = g.seg_off[TB]; p.PB = g.seg_off[1];
   p.nimg = nimg;
-  p.ngroups = cdiv(nimg, kBM);
+  p.ngroups = nimg / (large ? ShapeL::BM : ShapeS::BM);
   p.tiles_per_xcd = cdiv(p.ngroups, 8) * g.OHW;
-  return launch_as<1, EPI_MASK>(p, stream);
+  return large ? launch_as<1, EPI_MASK, ShapeL>(p, stream) : launch_as<1, EPI_MASK, ShapeS>(p, stream);
 }
 
 }  // namespace dx
