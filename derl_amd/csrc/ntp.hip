@@ -40,7 +40,7 @@ struct Shape {
   static_assert(BM % 64 == 0 && BN % (32 * TN) == 0 && (BM / 8) % NLOAD == 0 && (BN / 8) % NLOAD == 0, "tile shape");
 };
 using ShapeS = Shape<128, 64, 1, 3, 4, 2>;   // 64-column stages: 4 + 4 waves, two workgroups per CU
-using ShapeL = Shape<256, 128, 2, 2, 4, 1>;  // 128-column stages: 8 + 4 waves, one workgroup per CU
+using ShapeL = Shape<128, 128, 2, 2, 4, 2>;  // 128-column stages: 4 + 4 waves of 64 x 64, two workgroups per CU
 
 }  // namespace ntp
 namespace {
@@ -70,6 +70,18 @@ struct NtpArgs {
   int diag;           // DX_NTP_DIAG bits: 1 = stamps, 2 = cycles at the wait + barrier; WRONG RESULTS: 4 = no fills
                       // after the first two, 8 = no barrier, 16 = no epilogue loads / stores, 32 = every tile reads the rows of the first
 };
+
+// Epilogue accesses in the SGPR-base form too: a uniform 64-bit base (tensor + the row's offset, scalar
+// adds) plus ONE per-lane 32-bit byte offset per column block, instead of a 64-bit per-lane
+// address per element (two VALU instructions and two registers each).
+__device__ __forceinline__ float load_at(const float *tensor, long long uniform_bytes, uint32_t lane_bytes) {
+  asm volatile("" : "+v"(lane_bytes));
+  return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(tensor) + uniform_bytes + lane_bytes);
+}
+__device__ __forceinline__ void store_at(float *tensor, long long uniform_bytes, uint32_t lane_bytes, float v) {
+  asm volatile("" : "+v"(lane_bytes));
+  *reinterpret_cast<float *>(reinterpret_cast<char *>(tensor) + uniform_bytes + lane_bytes) = v;
+}
 
 // Position in the stream of K steps: tile `i` of this workgroup, tap (ta, tb), offset q inside the
 // tap's run.  The runs of a row form a TA x TB grid (forward: TA = kernel rows, TB = 1; dgrad: one
@@ -127,8 +139,9 @@ __device__ __forceinline__ bool advance(Cursor &c, const NtpArgs &p) {
 // (the shape is spelled out as integers: with a class parameter in __launch_bounds__ hipcc emits no
 // host stub for the instantiations)
 template <int MODE, int EPI, int BM, int BN, int TN, int RING, int NLOAD, int WGS>
-__global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD), WGS) void ntp_kernel(const NtpArgs p,
-                                                                                                unsigned long long *stamps) {
+__global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // second argument: waves per SIMD
+                             ((BM / 64) * (BN / (32 * TN)) + NLOAD) * WGS / 4) void ntp_kernel(const NtpArgs p,
+                                                                                               unsigned long long *stamps) {
   using S = ntp::Shape<BM, BN, TN, RING, NLOAD, WGS>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const unsigned long long t_entry = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -307,50 +320,63 @@ __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD), WGS) v
     // ---- epilogue of (tile, pix): C/D layout column = l31, row = (r & 3) + 8 (r >> 2) + 4 hi.
     // Tiles are never ragged (the launchers require whole tiles): a guarded store or load here is
     // a branch, and the compiler then drains vmcnt at the loop header.
-    const int row0 = tile * BM + wm * 64 + 4 * hi;  // GEMM row (MODE 0) or image (MODE 1)
+    // element (t, r) of column block j: uniform part (tile, wave, t, r) + lane part (hi, l31)
+    const long long rowbytes = 4LL * (MODE == 0 ? a.ldc : (a.om.enabled ? a.om.OUT_H * a.om.OUT_W : g.OHW) * a.ldc);
+    const long long tile0 = static_cast<long long>(tile * BM + wm * 64) * rowbytes;  // uniform
     if (p.diag & 16) {  // diagnostic: no epilogue traffic
     } else if (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        float *o = a.out + static_cast<long long>(row0) * a.ldc + wn * 32 * TN + 32 * j + l31;
+        const uint32_t lane_off = static_cast<uint32_t>(4 * hi) * static_cast<uint32_t>(rowbytes) +
+                                  4u * (wn * 32 * TN + 32 * j + l31);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            o[static_cast<long long>(32 * t + (r & 3) + 8 * (r >> 2)) * a.ldc] = fmaxf(acc[t][j][r] + bias[j], 0.f);
+            store_at(a.out, tile0 + (32 * t + (r & 3) + 8 * (r >> 2)) * rowbytes, lane_off, fmaxf(acc[t][j][r] + bias[j], 0.f));
       }
     } else {
       const OutMap &om = a.om;
       const int oy = fdiv(pix, g.div_row), ox = pix - oy * g.OW;
-      long long imgo, o0[TN];
+      long long pix0[TN];  // uniform: byte offset of this row's output pixel and column block inside an image
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int nb = wn * 32 * TN + 32 * j;  // uniform: first column of this 32-wide block
+        const int nb = wn * 32 * TN + 32 * j;  // first column of this 32-wide block
         if (om.enabled) {  // column block -> (py, px) of the osy x osx output pixels of this row
           const int gq = nb / om.chan;
           const int py = gq / om.osx, px = gq - py * om.osx;
-          imgo = static_cast<long long>(om.OUT_H) * om.OUT_W * a.ldc;
-          o0[j] = static_cast<long long>((oy * om.osy + py) * om.OUT_W + ox * om.osx + px) * a.ldc + (nb - gq * om.chan) + l31;
+          pix0[j] = 4LL * (((oy * om.osy + py) * om.OUT_W + ox * om.osx + px) * a.ldc + (nb - gq * om.chan));
         } else {
-          imgo = static_cast<long long>(g.OHW) * a.ldc;
-          o0[j] = static_cast<long long>(pix) * a.ldc + nb + l31;
+          pix0[j] = 4LL * (pix * a.ldc + nb);
         }
-        o0[j] += static_cast<long long>(row0) * imgo;
       }
-      float mk[TN][2][16];  // every mask load ahead of the first store
+      const uint32_t lane_off = static_cast<uint32_t>(4 * hi) * static_cast<uint32_t>(rowbytes) + 4u * l31;
+      // every mask load ahead of the first store (a load behind a store waits for it).  With two
+      // column blocks the first block's masks are packed into bits before the second block's loads
+      // go out: 32 registers instead of 64 keep the kernel at two workgroups per CU.
+      uint32_t keep[TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j) {
+        float mk[2][16];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mk[j][t][r] = a.mask_src[o0[j] + (32 * t + (r & 3) + 8 * (r >> 2)) * imgo];
+          for (int r = 0; r < 16; ++r)
+            mk[t][r] = load_at(a.mask_src, tile0 + pix0[j] + (32 * t + (r & 3) + 8 * (r >> 2)) * rowbytes, lane_off);
+        keep[j] = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) keep[j] |= (mk[t][r] > 0.f ? 1u : 0u) << (16 * t + r);
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            a.out[o0[j] + (32 * t + (r & 3) + 8 * (r >> 2)) * imgo] = mk[j][t][r] > 0.f ? acc[t][j][r] : 0.f;
+            store_at(a.out, tile0 + pix0[j] + (32 * t + (r & 3) + 8 * (r >> 2)) * rowbytes, lane_off,
+                     ((keep[j] >> (16 * t + r)) & 1u) ? acc[t][j][r] : 0.f);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
