@@ -525,6 +525,8 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       }
       return tn(L_FC, rows_gather(c->y2, flat), c->dhid, kHid, B, kHid, flat, false);
     case ST_FC_DGRAD:
+      if (const int rc = launch_ntp_rows(c->dhid, kHid, pk + c->pk_fcd, c->y2, c->dy2, B, flat, kHid, s); rc != DX_ENOSUP)
+        return rc;
       if (nt_dma_on() && nt_dma_supported(B, flat, kHid)) {
         const NtDmaArgs d{c->dhid, pk + c->pk_fcd, nullptr, c->y2, c->dy2, B, flat, kHid, kHid, flat};
         return launch_nt_dma(d, EPI_MASK, s);

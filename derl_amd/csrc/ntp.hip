@@ -20,6 +20,7 @@
 //     the workgroups of an XCD walk the pixels of the same image groups (shared taps from L2).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "igemm_dev.hpp"
@@ -91,8 +92,8 @@ __device__ __forceinline__ void store_at(float *tensor, long long uniform_bytes,
 struct Cursor {
   int i;        // tile counter of this workgroup
   int valid;    // tile exists
-  int tile;     // MODE 0: row tile; MODE 1: image group
-  int pix;      // MODE 1: pixel
+  int tile;     // MODE 0: row tile; MODE 1: image group; MODE 2: row block
+  int pix;      // MODE 1: pixel; MODE 2: column tile
   int pixoff;   // MODE 1: element offset of the pixel inside an image
   int ta, tb, q;
   int ta_hi, tb_lo, tb_hi;
@@ -113,10 +114,14 @@ __device__ __forceinline__ void open_tile(Cursor &c, const NtpArgs &p) {
     c.pix = u - gl * g.OHW;
     c.tile = gl * 8 + xcd;
     c.valid = u < static_cast<uint32_t>(p.tiles_per_xcd) && c.tile < p.ngroups;
-    const int y = fdiv(c.pix, g.div_row), x = c.pix - y * g.OW;  // unit stride (checked on the host)
-    c.ta = max(0, y - g.H + 1); c.ta_hi = min(p.TA - 1, y);
-    c.tb_lo = max(0, x - g.W + 1); c.tb_hi = min(p.TB - 1, x);
-    c.pixoff = (y * g.W + x) * g.C;
+    if (MODE == 2) {  // plain rows: the "pixel" is the column tile, one run of K elements
+      c.ta = 0; c.ta_hi = 0; c.tb_lo = 0; c.tb_hi = 0; c.pixoff = 0;
+    } else {
+      const int y = fdiv(c.pix, g.div_row), x = c.pix - y * g.OW;  // unit stride (checked on the host)
+      c.ta = max(0, y - g.H + 1); c.ta_hi = min(p.TA - 1, y);
+      c.tb_lo = max(0, x - g.W + 1); c.tb_hi = min(p.TB - 1, x);
+      c.pixoff = (y * g.W + x) * g.C;
+    }
   }
   c.tb = c.tb_lo;
   c.q = 0;
@@ -193,7 +198,8 @@ __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // se
     const char *abase_ = static_cast<const char *>(g.src) +                                      \
                          4LL * (ld.pixoff + ld.ta * p.PA + ld.tb * p.PB + ld.q);                 \
     const char *wbase_ = reinterpret_cast<const char *>(a.Wp) +                                  \
-                         4LL * ((ld.ta * p.TB + ld.tb) * g.seglen + ld.q);                       \
+                         4LL * ((ld.ta * p.TB + ld.tb) * g.seglen + ld.q) +                      \
+                         (MODE == 2 ? 4LL * ld.pix * S::BN * a.K : 0LL);                         \
     _Pragma("unroll") for (int q_ = 0; q_ < S::APIECES; ++q_)                                    \
         dma_piece(abase_, av[q_], dst_ + (wave + S::NLOAD * q_) * 256);                         \
     _Pragma("unroll") for (int j_ = 0; j_ < S::WPIECES; ++j_)                                    \
@@ -518,6 +524,31 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
   p.ngroups = nimg / (large ? ShapeL::BM : ShapeS::BM);
   p.tiles_per_xcd = cdiv(p.ngroups, 8) * g.OHW;
   return large ? launch_as<1, EPI_MASK, ShapeL>(p, stream) : launch_as<1, EPI_MASK, ShapeS>(p, stream);
+}
+
+// Plain masked dgrad of a linear layer: out[m][n] = mask[m][n] > 0 ? sum_k A[m][k] W[n][k] : 0, N in
+// whole 64-column tiles (the linear layer of the conv stack: N = 49 pixels x 64 channels).  The
+// tile walk is the dgrad one with the column tile in the pixel's place (MODE 2).
+int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, float *out, int M, int N, int K,
+                    hipStream_t stream) {
+  if (!ntp_on() || N % ShapeS::BN || K % kBK || lda < K || lda % 4 || M % ShapeS::BM ||
+      1LL * (M / ShapeS::BM) * (N / ShapeS::BN) < 256LL * ShapeS::WGS || 4LL * M * N >= (1LL << 32))
+    return DX_ENOSUP;
+  DX_REQUIRE(A && W && mask && out && aligned(A, 16) && aligned(W, 16), "ntp_rows: bad operands");
+  NtpArgs p;
+  std::memset(&p, 0, sizeof(p));
+  const int gn = N / ShapeS::BN;
+  Gather &g = p.nt.g;
+  g.src = A; g.img_stride = lda; g.H = g.W = 1; g.C = K;
+  g.OHW = gn; g.OW = gn; g.div_img = make_fastdiv(gn); g.div_row = make_fastdiv(gn);
+  g.sy = g.sx = 1; g.nseg = 1; g.seglen = K;
+  p.nt.Wp = W; p.nt.mask_src = mask; p.nt.out = out; p.nt.ldc = ShapeS::BN;
+  p.nt.M = M; p.nt.N = ShapeS::BN; p.nt.K = K; p.nt.ksplit = 1;
+  p.TA = p.TB = 1;
+  p.nimg = M;
+  p.ngroups = M / ShapeS::BM;
+  p.tiles_per_xcd = cdiv(p.ngroups, 8) * gn;
+  return launch_as<2, EPI_MASK, ShapeS>(p, stream);
 }
 
 }  // namespace dx
