@@ -42,6 +42,22 @@ __device__ __forceinline__ float4 masked(float4 v, bool ok) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
+// One LDS-DMA piece: 64 lanes x 16 bytes to 1 KiB of LDS at `dst` (uniform), from `base` (UNIFORM)
+// plus a per-lane 32-bit byte offset: the SGPR-base form of global_load_lds, which needs no vector
+// ALU instruction for the address.  A 64-bit per-lane address costs a v_lshl_add_u64 per piece, and
+// a VALU instruction issued beside waves that keep the matrix pipe full waits for a gap there.
+// The empty asm keeps the compiler from widening the offset ahead of the loop (it then adds the
+// base per piece with VALU after all).  Also: the builtin must not be spelled inside a kernel
+// TEMPLATE with template-dependent arguments -- hipcc's host pass then silently emits no stub.
+__device__ __forceinline__ void dma_piece(const void *base, uint32_t lane_bytes, float *dst) {
+  // both operands opaque: the compiler otherwise folds several pieces' bases into one plus per-piece
+  // constants and adds those to a widened lane offset with v_lshl_add_u64.  `base` MUST be uniform
+  // (the "s" constraint would take lane 0's value otherwise).
+  asm volatile("" : "+s"(base));
+  asm volatile("" : "+v"(lane_bytes));
+  __builtin_amdgcn_global_load_lds(static_cast<const char *>(base) + lane_bytes, dst, 16, 0, 0);
+}
+
 struct RowPos {
   long long base;   // element offset of the row's origin pixel (channel 0)
   uint32_t okmask;  // bit s: run s of this row lies inside the image (all runs if !check)

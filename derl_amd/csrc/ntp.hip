@@ -51,17 +51,6 @@ using ntp::kBK;
 
 using f4 = __attribute__((ext_vector_type(4))) float;
 
-// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane addresses to 1 KiB of LDS at `dst` (uniform).
-// A plain function, not the builtin spelled inside the kernel template: with template-dependent
-// arguments hipcc's host pass silently drops the whole kernel instantiation (no stub is emitted).
-__device__ __forceinline__ void dma_piece(const char *base, uint32_t lane_offset, float *dst) {
-  // `base` uniform, `lane_offset` a 32-bit register: selects the SGPR-base form (no address VALU).
-  // The empty asm keeps the compiler from widening the offset to 64 bits ahead of the loop, after
-  // which it adds the base with v_lshl_add_u64 per piece.
-  asm volatile("" : "+v"(lane_offset));
-  __builtin_amdgcn_global_load_lds(base + lane_offset, dst, 16, 0, 0);
-}
-
 struct NtpArgs {
   NTArgs nt;
   int ntiles;         // MODE 0: row tiles

@@ -70,6 +70,7 @@ __device__ __forceinline__ void conv_wgrad_direct_body(const WgradDirectArgs &a,
   constexpr int OHW = L::OHW, XN = L::XN, GN = L::GN, NP = L::NP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int och = wave % OCT;
   const int hi = lane >> 5, l31 = lane & 31;
   const char *lds = reinterpret_cast<const char *>(smem);
@@ -148,15 +149,23 @@ __device__ __forceinline__ void conv_wgrad_direct_body(const WgradDirectArgs &a,
   }
   // wave w copies pieces w, w + NW, ... of an image: lane l of piece p brings 16-byte unit
   // 64p + l of the flat image [input | gradient]; the lanes past the end of the last piece stay
-  // inactive (nothing is written behind the image)
+  // inactive (nothing is written behind the image).  Every fill is a uniform base plus the lane's
+  // constant offset (dma_piece: no address VALU between the MFMAs)
 #define DX_WD_COPY(IMG, DST)                                                                     \
   {                                                                                              \
     const f4 *xs_ = reinterpret_cast<const f4 *>(a.x + static_cast<long long>(IMG) * XN);        \
     const f4 *gs_ = reinterpret_cast<const f4 *>(a.g + static_cast<long long>(IMG) * GN);        \
-    for (int p = wave; p < L::PIECES; p += NW) {                                                 \
-      const int i_ = p * 64 + lane;                                                              \
-      if (i_ < L::TOTAL)                                                                         \
-        __builtin_amdgcn_global_load_lds(i_ < L::XV ? xs_ + i_ : gs_ + (i_ - L::XV), (DST) + p * 256, 16, 0, 0); \
+    for (int p = wave_u; p < L::PIECES; p += NW) {                                               \
+      const int u0_ = p * 64; /* uniform: first 16-byte unit of the piece */                      \
+      float *d_ = (DST) + p * 256;                                                               \
+      if (u0_ + 64 <= L::XV) {                                                                   \
+        dma_piece(xs_ + u0_, lane * 16u, d_);                                                    \
+      } else if (u0_ >= L::XV) {                                                                 \
+        if (u0_ + 64 <= L::TOTAL || lane < L::TOTAL - u0_) dma_piece(gs_ + (u0_ - L::XV), lane * 16u, d_); \
+      } else { /* the piece that straddles [input | gradient]: two masked fills of the same KiB */ \
+        if (lane < L::XV - u0_) dma_piece(xs_ + u0_, lane * 16u, d_);                            \
+        else if (lane < L::TOTAL - u0_) dma_piece(gs_ - (L::XV - u0_), lane * 16u, d_);          \
+      }                                                                                          \
     }                                                                                            \
   }
 

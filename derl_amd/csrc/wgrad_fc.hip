@@ -51,18 +51,18 @@ __global__ __launch_bounds__(512, 2) void fc_wgrad_kernel(const FcWgradArgs a) {
 
   // this wave's pieces of a stage: G pieces 4w .. 4w+3 (piece p = row p / 2, columns 256 (p % 2)
   // + 4 lane), A piece w (rows 2w + hi, columns 4 l31; lanes past K stay inactive)
-  const float *gsrc = a.G + static_cast<long long>(2 * wave) * kN + lane * 4;
+  // uniform base + constant 32-bit lane offset: the SGPR-base form, no address VALU (igemm_dev.hpp)
+  const uint32_t glane = lane * 16u;
   const int acol = k0 + 4 * l31;
   const bool avalid = acol < a.K;
-  const float *asrc = a.A + static_cast<long long>(2 * wave + hi) * a.K + (avalid ? acol : 0);
+  const uint32_t alane = (static_cast<uint32_t>(hi) * a.K + (avalid ? 4 * l31 : 0)) * 4u;
 #define DX_FC_ISSUE(S, SLOT)                                                                     \
   {                                                                                              \
     float *dst_ = smem + (SLOT) * kStageFloats;                                                  \
-    const long long row_ = static_cast<long long>(S) * kRows;                                    \
+    const long long row_ = static_cast<long long>(S) * kRows + 2 * wave;                         \
     _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                \
-        __builtin_amdgcn_global_load_lds(gsrc + (row_ + (p >> 1)) * kN + (p & 1) * 256,          \
-                                         dst_ + (4 * wave + p) * 256, 16, 0, 0);                 \
-    if (avalid) __builtin_amdgcn_global_load_lds(asrc + row_ * a.K, dst_ + kGFloats + wave * 256, 16, 0, 0); \
+        dma_piece(a.G + (row_ + (p >> 1)) * kN + (p & 1) * 256, glane, dst_ + (4 * wave + p) * 256); \
+    if (avalid) dma_piece(a.A + row_ * a.K + k0, alane, dst_ + kGFloats + wave * 256);           \
   }
 
   const int wn = wave & 3, wk = wave >> 2;
