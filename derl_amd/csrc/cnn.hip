@@ -482,13 +482,13 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a = nt_args(conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), pk + c->pk_c1f,
                   w + c->off_b[1], c->y1, kC1, M1, kC1, 16 * kC0);
       a.Wb = planes(c, c->pb_c1f); a.wb_plane = kC1 * 16LL * kC0;
-      if (const int rc = launch_ntp_fwd(a, s); rc != DX_ENOSUP) return rc;
+      if (const int rc = launch_ntp_fwd(a, stage, s); rc != DX_ENOSUP) return rc;
       return launch_nt(a, false, EPI_BIAS_RELU, stage, s);
     case ST_CONV2_FWD:
       a = nt_args(conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), pk + c->pk_c2f,
                   w + c->off_b[2], c->y2, kC2, M2, kC2, 9 * kC1);
       a.Wb = planes(c, c->pb_c2f); a.wb_plane = kC2 * 9LL * kC1;
-      if (const int rc = launch_ntp_fwd(a, s); rc != DX_ENOSUP) return rc;
+      if (const int rc = launch_ntp_fwd(a, stage, s); rc != DX_ENOSUP) return rc;
       return launch_nt(a, false, EPI_BIAS_RELU, stage, s);
     case ST_FC_FWD: {
       // small minibatches (multi-GPU shards): 49 sequential 64-deep K steps on 128 workgroups are

@@ -110,7 +110,7 @@ int launch_nt_lat(const NTArgs &a, bool a_u8, int epi, int stage, hipStream_t st
 // 3xbf16-split variant of the big NT stages (igemm_b3.hip); DX_ENOSUP = not covered
 int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream);
 // persistent LDS-DMA ring kernels for the 64-column conv stages (ntp.hip); DX_ENOSUP = not covered
-int launch_ntp_fwd(const NTArgs &a, hipStream_t stream);
+int launch_ntp_fwd(const NTArgs &a, int stage, hipStream_t stream);
 int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream);
 int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, float *out, int M, int N, int K,
                     hipStream_t stream);

@@ -57,6 +57,13 @@ struct NtpArgs {
   int nimg, ngroups;  // MODE 1: images, groups of 128 images
   int tiles_per_xcd;  // MODE 1: ceil(ngroups / 8) * pixels
   int TA, TB, PA, PB;  // run grid and the element pitch of a step in ta / tb (see Cursor)
+  // MODE 0: the K steps of a tile in the order they are walked (element offsets into the input
+  // window and into a row of Wp).  The order is free (any permutation of the K axis); the
+  // stride-2 layer walks its taps grouped by (kh % 2, kw % 2): the four taps that read the same
+  // input pixel for neighbouring output pixels follow each other, so the pixel is still in L2
+  // when it is wanted again (kernel-row-major order: 0.72 GB of fetches for 0.42 GB of input).
+  int nstep;
+  int step_ao[24], step_ko[24];
   int diag;           // DX_NTP_DIAG bits: 1 = stamps, 2 = cycles at the wait + barrier; WRONG RESULTS: 4 = no fills
                       // after the first two, 8 = no barrier, 16 = no epilogue loads / stores, 32 = every tile reads the rows of the first
 };
@@ -119,12 +126,16 @@ __device__ __forceinline__ void open_tile(Cursor &c, const NtpArgs &p) {
 // -> true when the step just left was the last of its tile
 template <int MODE, int BM>
 __device__ __forceinline__ bool advance(Cursor &c, const NtpArgs &p) {
-  c.q += kBK;
-  if (c.q < p.nt.g.seglen) return false;
-  c.q = 0;
-  if (++c.tb <= c.tb_hi) return false;
-  c.tb = c.tb_lo;
-  if (++c.ta <= c.ta_hi) return false;
+  if (MODE == 0) {  // q counts the steps of the table
+    if (++c.q < p.nstep) return false;
+  } else {
+    c.q += kBK;
+    if (c.q < p.nt.g.seglen) return false;
+    c.q = 0;
+    if (++c.tb <= c.tb_hi) return false;
+    c.tb = c.tb_lo;
+    if (++c.ta <= c.ta_hi) return false;
+  }
   ++c.i;
   open_tile<MODE, BM>(c, p);
   return true;
@@ -132,7 +143,8 @@ __device__ __forceinline__ bool advance(Cursor &c, const NtpArgs &p) {
 
 // (the shape is spelled out as integers: with a class parameter in __launch_bounds__ hipcc emits no
 // host stub for the instantiations)
-template <int MODE, int EPI, int BM, int BN, int TN, int RING, int NLOAD, int WGS>
+// TAG = the network stage: one instantiation (= one profiler row) per stage
+template <int TAG, int MODE, int EPI, int BM, int BN, int TN, int RING, int NLOAD, int WGS>
 __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // second argument: waves per SIMD
                              ((BM / 64) * (BN / (32 * TN)) + NLOAD) * WGS / 4) void ntp_kernel(const NtpArgs p,
                                                                                                unsigned long long *stamps) {
@@ -185,10 +197,10 @@ __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // se
   {                                                                                              \
     float *dst_ = smem + (SLOT) * S::STAGE_FLOATS;                                               \
     const char *abase_ = static_cast<const char *>(g.src) +                                      \
-                         4LL * (ld.pixoff + ld.ta * p.PA + ld.tb * p.PB + ld.q);                 \
+        4LL * (MODE == 0 ? p.step_ao[ld.q] : ld.pixoff + ld.ta * p.PA + ld.tb * p.PB + ld.q);    \
     const char *wbase_ = reinterpret_cast<const char *>(a.Wp) +                                  \
-                         4LL * ((ld.ta * p.TB + ld.tb) * g.seglen + ld.q) +                      \
-                         (MODE == 2 ? 4LL * ld.pix * S::BN * a.K : 0LL);                         \
+        4LL * (MODE == 0 ? p.step_ko[ld.q] : (ld.ta * p.TB + ld.tb) * g.seglen + ld.q) +         \
+        (MODE == 2 ? 4LL * ld.pix * S::BN * a.K : 0LL);                                          \
     _Pragma("unroll") for (int q_ = 0; q_ < S::APIECES; ++q_)                                    \
         dma_piece(abase_, av[q_], dst_ + (wave + S::NLOAD * q_) * 256);                         \
     _Pragma("unroll") for (int j_ = 0; j_ < S::WPIECES; ++j_)                                    \
@@ -401,18 +413,18 @@ int ntp_workgroups(int per_cu) {  // DX_NTP_NWG: resident workgroups (default: e
   return n < 8 ? 8 : n / 8 * 8;
 }
 
-template <int MODE, int EPI, class S>
+template <int TAG, int MODE, int EPI, class S>
 int launch_as(const NtpArgs &p, hipStream_t stream) {
   static bool configured = false;
   if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntp_kernel<MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>),
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES));
     configured = true;
   }
   static const int diag = getenv("DX_NTP_DIAG") ? atoi(getenv("DX_NTP_DIAG")) : 0;
   const int grid = ntp_workgroups(S::WGS);
   if (!diag) {
-    hipLaunchKernelGGL((ntp_kernel<MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, p, nullptr);
+    hipLaunchKernelGGL((ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, p, nullptr);
     DX_LAUNCH_CHECK();
     return DX_OK;
   }
@@ -423,7 +435,7 @@ int launch_as(const NtpArgs &p, hipStream_t stream) {
   const size_t count = static_cast<size_t>(grid) * S::NCONS * 7, lcount = static_cast<size_t>(grid) * S::NLOAD * 3;
   DX_HIP(hipMalloc(&dev, (count + lcount) * 8));
   DX_HIP(hipMemsetAsync(dev, 0, (count + lcount) * 8, stream));
-  hipLaunchKernelGGL((ntp_kernel<MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, pd, dev);
+  hipLaunchKernelGGL((ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, pd, dev);
   DX_LAUNCH_CHECK();
   DX_HIP(hipStreamSynchronize(stream));
   std::vector<unsigned long long> h(count + lcount);
@@ -467,7 +479,7 @@ bool shape_fits(const NTArgs &a, long long rows, long long tiles) {
 
 // Forward conv stage (bias + ReLU), 64 output channels.  DX_ENOSUP = not covered: the caller keeps
 // its own kernel.
-int launch_ntp_fwd(const NTArgs &a, hipStream_t stream) {
+int launch_ntp_fwd(const NTArgs &a, int stage, hipStream_t stream) {
   const Gather &g = a.g;
   if (!ntp_on() || !shape_fits<ShapeS>(a, a.M, a.M / ShapeS::BM) || g.check || a.om.enabled || a.ldc != ShapeS::BN) return DX_ENOSUP;
   DX_REQUIRE(aligned(g.src, 16) && aligned(a.Wp, 16) && g.C % 4 == 0, "ntp: operands must be 16-byte aligned");
@@ -476,9 +488,25 @@ int launch_ntp_fwd(const NTArgs &a, hipStream_t stream) {
   p.ntiles = a.M / ShapeS::BM;
   p.nimg = p.ngroups = p.tiles_per_xcd = p.diag = 0;
   p.TA = g.nseg; p.TB = 1; p.PA = g.nseg > 1 ? g.seg_off[1] : 0; p.PB = 0;
-  for (int s2 = 0; s2 < g.nseg; ++s2)
-    if (g.seg_off[s2] != s2 * p.PA) return DX_ENOSUP;
-  return launch_as<0, EPI_BIAS_RELU, ShapeS>(p, stream);
+  const int per_run = g.seglen / kBK, taps_per_run = g.seglen / g.C, steps_per_tap = g.C / kBK;
+  p.nstep = g.nseg * per_run;
+  if (p.nstep > 24 || g.C % kBK || g.seglen % g.C) return DX_ENOSUP;
+  int n = 0;
+  // stride 2: taps grouped by parity class (see NtpArgs); otherwise kernel-row-major
+  const bool by_parity = g.sy == 2 && g.sx == 2 && g.nseg % 2 == 0 && taps_per_run % 2 == 0;
+  for (int cls = 0; cls < (by_parity ? 4 : 1); ++cls)
+    for (int kh = 0; kh < g.nseg; ++kh)
+      for (int kw = 0; kw < taps_per_run; ++kw) {
+        if (by_parity && (kh % 2 != cls / 2 || kw % 2 != cls % 2)) continue;
+        for (int h = 0; h < steps_per_tap; ++h, ++n) {
+          p.step_ao[n] = g.seg_off[kh] + kw * g.C + h * kBK;
+          p.step_ko[n] = kh * g.seglen + kw * g.C + h * kBK;
+        }
+      }
+  if (n != p.nstep) return fail(DX_EINVAL, "ntp: step table has %d of %d steps", n, p.nstep);
+  if (stage == ST_CONV1_FWD) return launch_as<ST_CONV1_FWD, 0, EPI_BIAS_RELU, ShapeS>(p, stream);
+  if (stage == ST_CONV2_FWD) return launch_as<ST_CONV2_FWD, 0, EPI_BIAS_RELU, ShapeS>(p, stream);
+  return DX_ENOSUP;
 }
 
 // dgrad stage tiled as one pixel x BM images (ReLU mask from the kept activation): 64 columns on
@@ -512,7 +540,7 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
   p.nimg = nimg;
   p.ngroups = nimg / (large ? ShapeL::BM : ShapeS::BM);
   p.tiles_per_xcd = cdiv(p.ngroups, 8) * g.OHW;
-  return large ? launch_as<1, EPI_MASK, ShapeL>(p, stream) : launch_as<1, EPI_MASK, ShapeS>(p, stream);
+  return large ? launch_as<ST_CONV1_DGRAD, 1, EPI_MASK, ShapeL>(p, stream) : launch_as<ST_CONV2_DGRAD, 1, EPI_MASK, ShapeS>(p, stream);
 }
 
 // Plain masked dgrad of a linear layer: out[m][n] = mask[m][n] > 0 ? sum_k A[m][k] W[n][k] : 0, N in
@@ -537,7 +565,7 @@ int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, 
   p.nimg = M;
   p.ngroups = M / ShapeS::BM;
   p.tiles_per_xcd = cdiv(p.ngroups, 8) * gn;
-  return launch_as<2, EPI_MASK, ShapeS>(p, stream);
+  return launch_as<ST_FC_DGRAD, 2, EPI_MASK, ShapeS>(p, stream);
 }
 
 }  // namespace dx
