@@ -406,6 +406,14 @@ bool ntp_on() {  // DX_NTP=0: these stages on the per-tile kernels
   return v != 0;
 }
 
+// DX_NTP_MIN_TILES: fewest tiles a stage must have to take these kernels (below it a workgroup per
+// CU is not reached and the per-tile kernels' finer tiles win)
+int ntp_min_tiles() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_NTP_MIN_TILES"); v = e ? atoi(e) : 256; }
+  return v;
+}
+
 int ntp_workgroups(int per_cu) {  // DX_NTP_NWG: resident workgroups (default: every CU full)
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_NTP_NWG"); v = e ? atoi(e) : 0; }
@@ -472,7 +480,7 @@ template <class S>
 bool shape_fits(const NTArgs &a, long long rows, long long tiles) {
   const Gather &g = a.g;
   return a.N == S::BN && !g.idx && a.ksplit == 1 && g.seglen % kBK == 0 && g.nseg <= kMaxSeg &&
-         a.K == g.nseg * g.seglen && rows % S::BM == 0 && tiles >= 256LL * S::WGS;
+         a.K == g.nseg * g.seglen && rows % S::BM == 0 && tiles >= ntp_min_tiles();
 }
 
 }  // namespace
@@ -529,6 +537,7 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
     return DX_ENOSUP;
   }
   const bool large = a.N == ShapeL::BN;
+  if (nimg / (large ? ShapeL::BM : ShapeS::BM) < 8) return DX_ENOSUP;  // an image group per XCD at least
   if (!(large ? shape_fits<ShapeL>(a, nimg, 1LL * nimg / ShapeL::BM * g.OHW)
               : shape_fits<ShapeS>(a, nimg, 1LL * nimg / ShapeS::BM * g.OHW)))
     return DX_ENOSUP;
@@ -548,8 +557,8 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
 // tile walk is the dgrad one with the column tile in the pixel's place (MODE 2).
 int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, float *out, int M, int N, int K,
                     hipStream_t stream) {
-  if (!ntp_on() || N % ShapeS::BN || K % kBK || lda < K || lda % 4 || M % ShapeS::BM ||
-      1LL * (M / ShapeS::BM) * (N / ShapeS::BN) < 256LL * ShapeS::WGS || 4LL * M * N >= (1LL << 32))
+  if (!ntp_on() || N % ShapeS::BN || K % kBK || lda < K || lda % 4 || M % ShapeS::BM || M / ShapeS::BM < 8 ||
+      1LL * (M / ShapeS::BM) * (N / ShapeS::BN) < ntp_min_tiles() || 4LL * M * N >= (1LL << 32))
     return DX_ENOSUP;
   DX_REQUIRE(A && W && mask && out && aligned(A, 16) && aligned(W, 16), "ntp_rows: bad operands");
   NtpArgs p;
