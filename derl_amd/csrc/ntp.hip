@@ -29,24 +29,29 @@ namespace dx {
 namespace ntp {
 constexpr int kBK = 32;  // K elements per stage
 
-// Tile shape of one instantiation.  BM x BN tile, consumer waves of 64 x (32 TN), NLOAD loader waves,
+// Tile shape of one instantiation.  BM x BN tile, consumer waves of (32 TM) x (32 TN), NLOAD loader waves,
 // RING stages of (BM + BN) rows x 128 bytes, WGS workgroups per CU.
-template <int BM_, int BN_, int TN_, int RING_, int NLOAD_, int WGS_>
+template <int BM_, int BN_, int TM_, int TN_, int RING_, int NLOAD_, int WGS_>
 struct Shape {
-  static constexpr int BM = BM_, BN = BN_, TN = TN_, RING = RING_, NLOAD = NLOAD_, WGS = WGS_;
-  static constexpr int WN = BN / (32 * TN), NCONS = (BM / 64) * WN, THREADS = 64 * (NCONS + NLOAD);
+  static constexpr int BM = BM_, BN = BN_, TM = TM_, TN = TN_, RING = RING_, NLOAD = NLOAD_, WGS = WGS_;
+  static constexpr int WN = BN / (32 * TN), NCONS = (BM / (32 * TM)) * WN, THREADS = 64 * (NCONS + NLOAD);
   static constexpr int STAGE_FLOATS = (BM + BN) * kBK;
   static constexpr int APIECES = BM / 8 / NLOAD, WPIECES = BN / 8 / NLOAD;  // per loader wave and stage
   static constexpr int LDS_BYTES = RING * STAGE_FLOATS * 4;
-  static_assert(BM % 64 == 0 && BN % (32 * TN) == 0 && (BM / 8) % NLOAD == 0 && (BN / 8) % NLOAD == 0, "tile shape");
+  static_assert(BM % (32 * TM) == 0 && BN % (32 * TN) == 0 && (BM / 8) % NLOAD == 0 && (BN / 8) % NLOAD == 0, "tile shape");
 };
-using ShapeS = Shape<128, 64, 1, 3, 4, 2>;   // 64-column stages: 4 + 4 waves, two workgroups per CU
-using ShapeL = Shape<128, 128, 2, 2, 4, 2>;  // 128-column stages: 4 + 4 waves of 64 x 64, two workgroups per CU
+using ShapeS = Shape<128, 64, 2, 1, 3, 4, 2>;   // 64-column stages: 4 + 4 waves, two workgroups per CU
+using ShapeL = Shape<128, 128, 2, 2, 2, 4, 2>;  // 128-column stages: 4 + 4 waves of 64 x 64, two workgroups per CU
 
+// between rollout and training sizes (256..511 tiles of 64 rows): 64 x 64 tiles on four consumer waves
+// of 32 x 32 and eight loaders (a wave gets one fill instruction through per ~900 cycles): 5-10 %
+// ahead of the latency kernels there, behind them below 256 tiles
+using ShapeX = Shape<64, 64, 1, 1, 3, 8, 2>;
 }  // namespace ntp
 namespace {
 using ntp::ShapeS;
 using ntp::ShapeL;
+using ntp::ShapeX;
 using ntp::kBK;
 
 using f4 = __attribute__((ext_vector_type(4))) float;
@@ -144,11 +149,11 @@ __device__ __forceinline__ bool advance(Cursor &c, const NtpArgs &p) {
 // (the shape is spelled out as integers: with a class parameter in __launch_bounds__ hipcc emits no
 // host stub for the instantiations)
 // TAG = the network stage: one instantiation (= one profiler row) per stage
-template <int TAG, int MODE, int EPI, int BM, int BN, int TN, int RING, int NLOAD, int WGS>
-__global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // second argument: waves per SIMD
-                             ((BM / 64) * (BN / (32 * TN)) + NLOAD) * WGS / 4) void ntp_kernel(const NtpArgs p,
+template <int TAG, int MODE, int EPI, int BM, int BN, int TM, int TN, int RING, int NLOAD, int WGS>
+__global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),  // second argument: waves per SIMD
+                             ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD) * WGS / 4) void ntp_kernel(const NtpArgs p,
                                                                                                unsigned long long *stamps) {
-  using S = ntp::Shape<BM, BN, TN, RING, NLOAD, WGS>;
+  using S = ntp::Shape<BM, BN, TM, TN, RING, NLOAD, WGS>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const unsigned long long t_entry = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   const NTArgs &a = p.nt;
@@ -248,19 +253,19 @@ __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // se
   // ================= consumer waves: fragment reads, MFMAs, epilogues =================
   const int wave = wave8;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int wm = wave / S::WN, wn = wave % S::WN;  // waves of 64 x (32 TN)
+  const int wm = wave / S::WN, wn = wave % S::WN;  // waves of (32 TM) x (32 TN)
   const char *lds = reinterpret_cast<const char *>(smem);
   const unsigned x = (l31 >> 1) & 7;
   unsigned aoff[4], boff[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const unsigned slot = ((2 * q + hi) ^ x) * 16;
-    aoff[q] = (wm * 64 + l31) * 128 + slot;
+    aoff[q] = (wm * 32 * TM + l31) * 128 + slot;
     boff[q] = (BM + wn * 32 * TN + l31) * 128 + slot;
   }
-  f32x16 acc[2][TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < TM; ++t)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -292,9 +297,9 @@ __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // se
       continue;
     }
     const char *base = lds + slot * S::STAGE_FLOATS * 4;
-    f4 af[2][2], bf[2][TN];
-    af[0][0] = *reinterpret_cast<const f4 *>(base + aoff[0]);
-    af[0][1] = *reinterpret_cast<const f4 *>(base + aoff[0] + 32 * 128);
+    f4 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) af[0][t] = *reinterpret_cast<const f4 *>(base + aoff[0] + t * 32 * 128);
 #pragma unroll
     for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f4 *>(base + boff[0] + j * 32 * 128);
     __builtin_amdgcn_sched_barrier(0);
@@ -304,8 +309,8 @@ __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // se
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0][0], bf[c][0][0], acc[0][0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (q + 1 < 4) {  // the next group's fragments, requested in the first MFMA's shadow
-        af[nx][0] = *reinterpret_cast<const f4 *>(base + aoff[q + 1]);
-        af[nx][1] = *reinterpret_cast<const f4 *>(base + aoff[q + 1] + 32 * 128);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[nx][t] = *reinterpret_cast<const f4 *>(base + aoff[q + 1] + t * 32 * 128);
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[nx][j] = *reinterpret_cast<const f4 *>(base + boff[q + 1] + j * 32 * 128);
       }
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // se
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             if (e + t + j > 0)
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // se
     // a branch, and the compiler then drains vmcnt at the loop header.
     // element (t, r) of column block j: uniform part (tile, wave, t, r) + lane part (hi, l31)
     const long long rowbytes = 4LL * (MODE == 0 ? a.ldc : (a.om.enabled ? a.om.OUT_H * a.om.OUT_W : g.OHW) * a.ldc);
-    const long long tile0 = static_cast<long long>(tile * BM + wm * 64) * rowbytes;  // uniform
+    const long long tile0 = static_cast<long long>(tile * BM + wm * 32 * TM) * rowbytes;  // uniform
     if (p.diag & 16) {  // diagnostic: no epilogue traffic
     } else if (MODE == 0) {
 #pragma unroll
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // se
         const uint32_t lane_off = static_cast<uint32_t>(4 * hi) * static_cast<uint32_t>(rowbytes) +
                                   4u * (wn * 32 * TN + 32 * j + l31);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             store_at(a.out, tile0 + (32 * t + (r & 3) + 8 * (r >> 2)) * rowbytes, lane_off, fmaxf(acc[t][j][r] + bias[j], 0.f));
@@ -364,29 +369,29 @@ __global__ __launch_bounds__(64 * ((BM / 64) * (BN / (32 * TN)) + NLOAD),  // se
       uint32_t keep[TN];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        float mk[2][16];
+        float mk[TM][16];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             mk[t][r] = load_at(a.mask_src, tile0 + pix0[j] + (32 * t + (r & 3) + 8 * (r >> 2)) * rowbytes, lane_off);
         keep[j] = 0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) keep[j] |= (mk[t][r] > 0.f ? 1u : 0u) << (16 * t + r);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             store_at(a.out, tile0 + pix0[j] + (32 * t + (r & 3) + 8 * (r >> 2)) * rowbytes, lane_off,
                      ((keep[j] >> (16 * t + r)) & 1u) ? acc[t][j][r] : 0.f);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TM; ++t)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -414,6 +419,12 @@ int ntp_min_tiles() {
   return v;
 }
 
+bool ntp_small_on() {  // DX_NTP_SMALL=0: rollout-sized forward stages on the latency kernels
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_NTP_SMALL"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 int ntp_workgroups(int per_cu) {  // DX_NTP_NWG: resident workgroups (default: every CU full)
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_NTP_NWG"); v = e ? atoi(e) : 0; }
@@ -425,14 +436,14 @@ template <int TAG, int MODE, int EPI, class S>
 int launch_as(const NtpArgs &p, hipStream_t stream) {
   static bool configured = false;
   if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>),
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TM, S::TN, S::RING, S::NLOAD, S::WGS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES));
     configured = true;
   }
   static const int diag = getenv("DX_NTP_DIAG") ? atoi(getenv("DX_NTP_DIAG")) : 0;
   const int grid = ntp_workgroups(S::WGS);
   if (!diag) {
-    hipLaunchKernelGGL((ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, p, nullptr);
+    hipLaunchKernelGGL((ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TM, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, p, nullptr);
     DX_LAUNCH_CHECK();
     return DX_OK;
   }
@@ -443,7 +454,7 @@ int launch_as(const NtpArgs &p, hipStream_t stream) {
   const size_t count = static_cast<size_t>(grid) * S::NCONS * 7, lcount = static_cast<size_t>(grid) * S::NLOAD * 3;
   DX_HIP(hipMalloc(&dev, (count + lcount) * 8));
   DX_HIP(hipMemsetAsync(dev, 0, (count + lcount) * 8, stream));
-  hipLaunchKernelGGL((ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, pd, dev);
+  hipLaunchKernelGGL((ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TM, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, pd, dev);
   DX_LAUNCH_CHECK();
   DX_HIP(hipStreamSynchronize(stream));
   std::vector<unsigned long long> h(count + lcount);
@@ -465,7 +476,7 @@ int launch_as(const NtpArgs &p, hipStream_t stream) {
   }
   auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
   auto mx = [](const std::vector<double> &v) { return *std::max_element(v.begin(), v.end()); };
-  const int ideal = 2 * S::TN * 16 * 64 * (S::NCONS * S::WGS / 4);  // MFMA cycles of a step on a SIMD shared by NCONS WGS / 4 waves
+  const int ideal = S::TM * S::TN * 16 * 64 * (S::NCONS * S::WGS / 4);  // MFMA cycles of a step on a SIMD shared by NCONS WGS / 4 waves
   fprintf(stderr, "[ntp mode %d %dx%d M=%d K=%d grid=%d] span %.1f us | per wave: prologue %.2f us, loop median %.1f max %.1f us, "
           "steps median %.0f max %.0f, %.0f cycles/step (ideal %d), wait+barrier %.1f %% of the loop\n", MODE, S::BM, S::BN,
           p.nt.M, p.nt.K, grid, (last - first) * 0.01, med(pro), med(loop), mx(loop), med(steps), mx(steps), med(cps), ideal,
@@ -477,28 +488,40 @@ int launch_as(const NtpArgs &p, hipStream_t stream) {
 
 // `rows`: GEMM rows (forward) or images (dgrad) in whole tiles, `tiles`: enough of them to fill the chip
 template <class S>
-bool shape_fits(const NTArgs &a, long long rows, long long tiles) {
+bool shape_fits(const NTArgs &a, long long rows, long long tiles, long long min_tiles = -1) {
   const Gather &g = a.g;
   return a.N == S::BN && !g.idx && a.ksplit == 1 && g.seglen % kBK == 0 && g.nseg <= kMaxSeg &&
-         a.K == g.nseg * g.seglen && rows % S::BM == 0 && tiles >= ntp_min_tiles();
+         a.K == g.nseg * g.seglen && rows % S::BM == 0 && tiles >= (min_tiles < 0 ? ntp_min_tiles() : min_tiles);
 }
 
 }  // namespace
 
 // Forward conv stage (bias + ReLU), 64 output channels.  DX_ENOSUP = not covered: the caller keeps
 // its own kernel.
+template <class S>
+int launch_fwd_as(const NTArgs &a, NtpArgs &p, int stage, hipStream_t stream) {
+  p.ntiles = a.M / S::BM;
+  if (stage == ST_CONV1_FWD) return launch_as<ST_CONV1_FWD, 0, EPI_BIAS_RELU, S>(p, stream);
+  if (stage == ST_CONV2_FWD) return launch_as<ST_CONV2_FWD, 0, EPI_BIAS_RELU, S>(p, stream);
+  return DX_ENOSUP;
+}
+
 int launch_ntp_fwd(const NTArgs &a, int stage, hipStream_t stream) {
   const Gather &g = a.g;
-  if (!ntp_on() || !shape_fits<ShapeS>(a, a.M, a.M / ShapeS::BM) || g.check || a.om.enabled || a.ldc != ShapeS::BN) return DX_ENOSUP;
+  if (!ntp_on() || g.check || a.om.enabled || a.ldc != ShapeS::BN) return DX_ENOSUP;
+  // 128-row tiles when they fill the chip, 64-row tiles for rollout-sized batches
+  const bool big = shape_fits<ShapeS>(a, a.M, a.M / ShapeS::BM);
+  if (!big && !(ntp_small_on() && shape_fits<ShapeX>(a, a.M, a.M / ShapeX::BM))) return DX_ENOSUP;
   DX_REQUIRE(aligned(g.src, 16) && aligned(a.Wp, 16) && g.C % 4 == 0, "ntp: operands must be 16-byte aligned");
   NtpArgs p;
   p.nt = a;
-  p.ntiles = a.M / ShapeS::BM;
   p.nimg = p.ngroups = p.tiles_per_xcd = p.diag = 0;
   p.TA = g.nseg; p.TB = 1; p.PA = g.nseg > 1 ? g.seg_off[1] : 0; p.PB = 0;
   const int per_run = g.seglen / kBK, taps_per_run = g.seglen / g.C, steps_per_tap = g.C / kBK;
   p.nstep = g.nseg * per_run;
   if (p.nstep > 24 || g.C % kBK || g.seglen % g.C) return DX_ENOSUP;
+  for (int s2 = 0; s2 < g.nseg; ++s2)
+    if (g.seg_off[s2] != s2 * p.PA) return DX_ENOSUP;
   int n = 0;
   // stride 2: taps grouped by parity class (see NtpArgs); otherwise kernel-row-major
   const bool by_parity = g.sy == 2 && g.sx == 2 && g.nseg % 2 == 0 && taps_per_run % 2 == 0;
@@ -512,9 +535,7 @@ int launch_ntp_fwd(const NTArgs &a, int stage, hipStream_t stream) {
         }
       }
   if (n != p.nstep) return fail(DX_EINVAL, "ntp: step table has %d of %d steps", n, p.nstep);
-  if (stage == ST_CONV1_FWD) return launch_as<ST_CONV1_FWD, 0, EPI_BIAS_RELU, ShapeS>(p, stream);
-  if (stage == ST_CONV2_FWD) return launch_as<ST_CONV2_FWD, 0, EPI_BIAS_RELU, ShapeS>(p, stream);
-  return DX_ENOSUP;
+  return big ? launch_fwd_as<ShapeS>(a, p, stage, stream) : launch_fwd_as<ShapeX>(a, p, stage, stream);
 }
 
 // dgrad stage tiled as one pixel x BM images (ReLU mask from the kept activation): 64 columns on
