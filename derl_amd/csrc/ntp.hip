@@ -41,6 +41,7 @@ struct Shape {
   static_assert(BM % (32 * TM) == 0 && BN % (32 * TN) == 0 && (BM / 8) % NLOAD == 0 && (BN / 8) % NLOAD == 0, "tile shape");
 };
 using ShapeS = Shape<128, 64, 2, 1, 3, 4, 2>;   // 64-column stages: 4 + 4 waves, two workgroups per CU
+using ShapeF = Shape<128, 64, 2, 1, 3, 8, 2>;   // forward: the same tile with eight loaders (66 registers: 6 waves per SIMD fit; -2 %)
 using ShapeL = Shape<128, 128, 2, 2, 2, 4, 2>;  // 128-column stages: 4 + 4 waves of 64 x 64, two workgroups per CU
 
 // between rollout and training sizes (256..511 tiles of 64 rows): 64 x 64 tiles on four consumer waves
@@ -51,6 +52,7 @@ using ShapeX = Shape<64, 64, 1, 1, 3, 8, 2>;
 namespace {
 using ntp::ShapeS;
 using ntp::ShapeL;
+using ntp::ShapeF;
 using ntp::ShapeX;
 using ntp::kBK;
 
@@ -535,7 +537,7 @@ int launch_ntp_fwd(const NTArgs &a, int stage, hipStream_t stream) {
         }
       }
   if (n != p.nstep) return fail(DX_EINVAL, "ntp: step table has %d of %d steps", n, p.nstep);
-  return big ? launch_fwd_as<ShapeS>(a, p, stage, stream) : launch_fwd_as<ShapeX>(a, p, stage, stream);
+  return big ? launch_fwd_as<ShapeF>(a, p, stage, stream) : launch_fwd_as<ShapeX>(a, p, stage, stream);
 }
 
 // dgrad stage tiled as one pixel x BM images (ReLU mask from the kept activation): 64 columns on
