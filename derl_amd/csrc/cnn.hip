@@ -92,6 +92,12 @@ SideStream *side_stream() {
   return &table[dev];
 }
 
+bool ntp_fc_fwd() {  // DX_NTP_FC_FWD=0: the linear layer's forward on nt_dma.hip's 128x128 tiles
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_NTP_FC_FWD"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 // DX_NT_DMA=0: linear-layer forward / dgrad on the implicit-GEMM kernel instead of nt_dma.hip
 bool nt_dma_on() {
   static int v = -1;
@@ -499,6 +505,11 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a.Wb = planes(c, c->pb_fcf); a.wb_plane = static_cast<long long>(kHid) * flat;
       a.ksplit = ks;
       a.slab_stride = static_cast<long long>(B) * kHid;
+      if (ks == 1 && ntp_fc_fwd()) {
+        if (const int rc = launch_ntp_rows(c->y2, flat, pk + c->pk_fcf, nullptr, w + c->off_b[3], c->hid, B, kHid, flat, s);
+            rc != DX_ENOSUP)
+          return rc;
+      }
       if (ks == 1 && nt_dma_on() && nt_dma_supported(B, kHid, flat)) {
         const NtDmaArgs d{c->y2, pk + c->pk_fcf, w + c->off_b[3], nullptr, c->hid, B, kHid, flat, flat, kHid};
         return launch_nt_dma(d, EPI_BIAS, s);
@@ -525,7 +536,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       }
       return tn(L_FC, rows_gather(c->y2, flat), c->dhid, kHid, B, kHid, flat, false);
     case ST_FC_DGRAD:
-      if (const int rc = launch_ntp_rows(c->dhid, kHid, pk + c->pk_fcd, c->y2, c->dy2, B, flat, kHid, s); rc != DX_ENOSUP)
+      if (const int rc = launch_ntp_rows(c->dhid, kHid, pk + c->pk_fcd, c->y2, nullptr, c->dy2, B, flat, kHid, s); rc != DX_ENOSUP)
         return rc;
       if (nt_dma_on() && nt_dma_supported(B, flat, kHid)) {
         const NtDmaArgs d{c->dhid, pk + c->pk_fcd, nullptr, c->y2, c->dy2, B, flat, kHid, kHid, flat};

@@ -365,6 +365,17 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
         }
       }
       const uint32_t lane_off = static_cast<uint32_t>(4 * hi) * static_cast<uint32_t>(rowbytes) + 4u * l31;
+      if (EPI == EPI_BIAS) {  // plain rows forward: the bias of this column tile, no mask
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float bj = a.bias[pix * S::BN + wn * 32 * TN + 32 * j + l31];
+#pragma unroll
+          for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              store_at(a.out, tile0 + pix0[j] + (32 * t + (r & 3) + 8 * (r >> 2)) * rowbytes, lane_off, acc[t][j][r] + bj);
+        }
+      } else {
       // every mask load ahead of the first store (a load behind a store waits for it).  With two
       // column blocks the first block's masks are packed into bits before the second block's loads
       // go out: 32 registers instead of 64 keep the kernel at two workgroups per CU.
@@ -391,6 +402,7 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
           for (int r = 0; r < 16; ++r)
             store_at(a.out, tile0 + pix0[j] + (32 * t + (r & 3) + 8 * (r >> 2)) * rowbytes, lane_off,
                      ((keep[j] >> (16 * t + r)) & 1u) ? acc[t][j][r] : 0.f);
+      }
     }
 #pragma unroll
     for (int t = 0; t < TM; ++t)
@@ -575,15 +587,16 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
   return large ? launch_as<ST_CONV1_DGRAD, 1, EPI_MASK, ShapeL>(p, stream) : launch_as<ST_CONV2_DGRAD, 1, EPI_MASK, ShapeS>(p, stream);
 }
 
-// Plain masked dgrad of a linear layer: out[m][n] = mask[m][n] > 0 ? sum_k A[m][k] W[n][k] : 0, N in
-// whole 64-column tiles (the linear layer of the conv stack: N = 49 pixels x 64 channels).  The
-// tile walk is the dgrad one with the column tile in the pixel's place (MODE 2).
-int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, float *out, int M, int N, int K,
-                    hipStream_t stream) {
+// Plain rows (a linear layer), N in whole 64-column tiles: the masked dgrad out[m][n] = mask[m][n] > 0 ?
+// sum_k A[m][k] W[n][k] : 0 (mask given; N = 49 pixels x 64 channels of the conv stack) or the
+// forward out[m][n] = bias[n] + sum_k A[m][k] W[n][k] (bias given).  The tile walk is the dgrad one
+// with the column tile in the pixel's place (MODE 2).
+int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, const float *bias, float *out, int M,
+                    int N, int K, hipStream_t stream) {
   if (!ntp_on() || N % ShapeS::BN || K % kBK || lda < K || lda % 4 || M % ShapeS::BM || M / ShapeS::BM < 8 ||
-      1LL * (M / ShapeS::BM) * (N / ShapeS::BN) < ntp_min_tiles() || 4LL * M * N >= (1LL << 32))
+      1LL * (M / ShapeS::BM) * (N / ShapeS::BN) < ntp_min_tiles() || 4LL * M * N >= (1LL << 32) || (mask != nullptr) == (bias != nullptr))
     return DX_ENOSUP;
-  DX_REQUIRE(A && W && mask && out && aligned(A, 16) && aligned(W, 16), "ntp_rows: bad operands");
+  DX_REQUIRE(A && W && out && aligned(A, 16) && aligned(W, 16), "ntp_rows: bad operands");
   NtpArgs p;
   std::memset(&p, 0, sizeof(p));
   const int gn = N / ShapeS::BN;
@@ -591,13 +604,13 @@ int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, 
   g.src = A; g.img_stride = lda; g.H = g.W = 1; g.C = K;
   g.OHW = gn; g.OW = gn; g.div_img = make_fastdiv(gn); g.div_row = make_fastdiv(gn);
   g.sy = g.sx = 1; g.nseg = 1; g.seglen = K;
-  p.nt.Wp = W; p.nt.mask_src = mask; p.nt.out = out; p.nt.ldc = ShapeS::BN;
+  p.nt.Wp = W; p.nt.mask_src = mask; p.nt.bias = bias; p.nt.out = out; p.nt.ldc = ShapeS::BN;
   p.nt.M = M; p.nt.N = ShapeS::BN; p.nt.K = K; p.nt.ksplit = 1;
   p.TA = p.TB = 1;
   p.nimg = M;
   p.ngroups = M / ShapeS::BM;
   p.tiles_per_xcd = cdiv(p.ngroups, 8) * gn;
-  return launch_as<ST_FC_DGRAD, 2, EPI_MASK, ShapeS>(p, stream);
+  return mask ? launch_as<ST_FC_DGRAD, 2, EPI_MASK, ShapeS>(p, stream) : launch_as<ST_FC_FWD, 2, EPI_BIAS, ShapeS>(p, stream);
 }
 
 }  // namespace dx

@@ -14,7 +14,7 @@ import sys
 
 STAGE_OF = [  # substring of the kernel name -> stage
     ("conv0_fwd_b16", "conv0_fwd"), ("igemm_nt_kernel<1,", "conv1_fwd"), ("igemm_nt_kernel<2,", "conv2_fwd"),
-    ("ntp_kernel<1,", "conv1_fwd"), ("ntp_kernel<2,", "conv2_fwd"), ("ntp_kernel<8,", "fc_dgrad"),
+    ("ntp_kernel<1,", "conv1_fwd"), ("ntp_kernel<2,", "conv2_fwd"), ("ntp_kernel<3,", "fc_fwd"), ("ntp_kernel<8,", "fc_dgrad"),
     ("ntp_kernel<10,", "conv2_dgrad"), ("ntp_kernel<12,", "conv1_dgrad"), ("nt_dma_kernel<1,", "fc_fwd"),
     ("nt_dma_kernel<3,", "fc_dgrad"), ("igemm_nt_small_kernel<3,", "fc_fwd"), ("fc_wgrad_kernel", "fc_wgrad"), ("colsum_kernel", "fc_wgrad_bias"),
     ("igemm_tn_kernel<7,", "fc_wgrad"), ("igemm_nt_small_kernel<8,", "fc_dgrad"),
