@@ -203,8 +203,9 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
       }
     }
     if (layer_direct_supported(c, l)) {
-      const int nwg = wgrad_direct_workgroups(l == L_C1 ? ST_CONV1_WGRAD : ST_CONV2_WGRAD);
-      if (ms_cap < nwg) ms_cap = nwg;
+      const int st = l == L_C1 ? ST_CONV1_WGRAD : ST_CONV2_WGRAD;
+      const int nwg = wgrad_direct_workgroups(st, B), cap = wgrad_direct_workgroups(st, c->max_batch);
+      if (ms_cap < cap) ms_cap = cap;
       if (B >= wgrad_direct_min_batch()) {
         p.s[l].direct = 1;
         p.s[l].msplit = static_cast<int>(B < nwg ? B : nwg);

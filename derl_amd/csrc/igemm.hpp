@@ -163,7 +163,7 @@ struct WgradDirectArgs {
 };
 bool wgrad_direct_supported(int IH, int IW, int IC, int OH, int OW, int OC, int KH, int KW, int S);
 int launch_wgrad_direct(const WgradDirectArgs &a, int stage, int nwg, hipStream_t stream);
-int wgrad_direct_workgroups(int stage);  // persistent workgroups that fill the chip for this layer
+int wgrad_direct_workgroups(int stage, long long batch);  // persistent workgroups that fill the chip for this layer
 
 // weight gradient of the 512-wide linear layer (wgrad_fc.hip): slab[slice][512][K] partial sums
 // over `msplit` row slices; the bias gradient partials come from launch_colsum

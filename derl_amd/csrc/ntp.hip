@@ -500,12 +500,15 @@ int launch_as(const NtpArgs &p, hipStream_t stream) {
   return DX_OK;
 }
 
-// `rows`: GEMM rows (forward) or images (dgrad) in whole tiles, `tiles`: enough of them to fill the chip
+// `rows`: GEMM rows (forward) or images (dgrad) in whole tiles, `tiles`: enough of them to fill the
+// chip, `images`: images of the gathered tensor (the loaders address it with 32-bit lane offsets:
+// it has to stay below 4 GiB)
 template <class S>
-bool shape_fits(const NTArgs &a, long long rows, long long tiles, long long min_tiles = -1) {
+bool shape_fits(const NTArgs &a, long long rows, long long tiles, long long images) {
   const Gather &g = a.g;
+  if (4LL * images * g.img_stride >= (1LL << 32)) return false;
   return a.N == S::BN && !g.idx && a.ksplit == 1 && g.seglen % kBK == 0 && g.nseg <= kMaxSeg &&
-         a.K == g.nseg * g.seglen && rows % S::BM == 0 && tiles >= (min_tiles < 0 ? ntp_min_tiles() : min_tiles);
+         a.K == g.nseg * g.seglen && rows % S::BM == 0 && tiles >= ntp_min_tiles();
 }
 
 }  // namespace
@@ -524,8 +527,9 @@ int launch_ntp_fwd(const NTArgs &a, int stage, hipStream_t stream) {
   const Gather &g = a.g;
   if (!ntp_on() || g.check || a.om.enabled || a.ldc != ShapeS::BN) return DX_ENOSUP;
   // 128-row tiles when they fill the chip, 64-row tiles for rollout-sized batches
-  const bool big = shape_fits<ShapeS>(a, a.M, a.M / ShapeS::BM);
-  if (!big && !(ntp_small_on() && shape_fits<ShapeX>(a, a.M, a.M / ShapeX::BM))) return DX_ENOSUP;
+  const long long images = (a.M + g.OHW - 1) / g.OHW;
+  const bool big = shape_fits<ShapeS>(a, a.M, a.M / ShapeS::BM, images);
+  if (!big && !(ntp_small_on() && shape_fits<ShapeX>(a, a.M, a.M / ShapeX::BM, images))) return DX_ENOSUP;
   DX_REQUIRE(aligned(g.src, 16) && aligned(a.Wp, 16) && g.C % 4 == 0, "ntp: operands must be 16-byte aligned");
   NtpArgs p;
   p.nt = a;
@@ -573,8 +577,8 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
   }
   const bool large = a.N == ShapeL::BN;
   if (nimg / (large ? ShapeL::BM : ShapeS::BM) < 8) return DX_ENOSUP;  // an image group per XCD at least
-  if (!(large ? shape_fits<ShapeL>(a, nimg, 1LL * nimg / ShapeL::BM * g.OHW)
-              : shape_fits<ShapeS>(a, nimg, 1LL * nimg / ShapeS::BM * g.OHW)))
+  if (!(large ? shape_fits<ShapeL>(a, nimg, 1LL * nimg / ShapeL::BM * g.OHW, nimg)
+              : shape_fits<ShapeS>(a, nimg, 1LL * nimg / ShapeS::BM * g.OHW, nimg)))
     return DX_ENOSUP;
   DX_REQUIRE(aligned(g.src, 16) && aligned(a.Wp, 16) && g.C % 4 == 0, "ntp: operands must be 16-byte aligned");
   NtpArgs p;

@@ -280,11 +280,13 @@ bool wgrad_direct_supported(int IH, int IW, int IC, int OH, int OW, int OC, int 
   return c1 || c2;
 }
 
-int wgrad_direct_workgroups(int stage) {
+// Workgroups (= slabs) of a launch.  conv2: two 4-wave workgroups per CU; below 2,048 images one per
+// CU (four images each at 1,024): the same kernel time and half the slabs for the finalize pass.
+int wgrad_direct_workgroups(int stage, long long batch) {
   static int forced = -1;  // DX_WD_NWG: timing experiments
   if (forced < 0) { const char *e = getenv("DX_WD_NWG"); forced = e ? atoi(e) : 0; }
   if (forced > 0 && stage == ST_CONV2_WGRAD) return forced;
-  return stage == ST_CONV1_WGRAD ? 256 : 512;
+  return stage == ST_CONV1_WGRAD || batch < 2048 ? 256 : 512;
 }
 
 int launch_wgrad_direct(const WgradDirectArgs &a_in, int stage, int nwg, hipStream_t stream) {

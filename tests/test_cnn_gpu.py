@@ -56,11 +56,11 @@ def oracle_activations(weights, obs):
   return acts
 
 
-@pytest.mark.parametrize("batch", [1, 3, 33, 129, 256])
+@pytest.mark.parametrize("batch", [1, 3, 33, 129, 256, 320, 512])  # 256..512: the 64x64 ring shape
 def test_forward_layers_and_ragged_batches(batch):
   weights = gi.nature_cnn_weights(4, 7)
   obs = gi.frames(batch, 5 + batch)
-  eng = make_engine(4, weights, max_batch=256)
+  eng = make_engine(4, weights, max_batch=max(batch, 256))
   head = eng.forward(torch.from_numpy(obs).to(DEV))
   torch.cuda.synchronize()
   ref = oracle_activations(weights, obs)
@@ -155,7 +155,8 @@ def test_loss_and_gradients_match_reference_golden(name):
 
 # 1024 / 2100: the training-size code paths (128x64 forward tiles from 65536 rows, wgrad with the
 # XCD-aware block numbering from 64 reduction slices, pixel-group dgrads with a ragged last group)
-@pytest.mark.parametrize("batch", [1, 5, 37, 130, 1024, 2100, 8192])  # 8192 = BASELINE minibatch
+# 2048: the persistent ring kernels with few tiles per workgroup + nt_dma for the linear layer
+@pytest.mark.parametrize("batch", [1, 5, 37, 130, 1024, 2048, 2100, 8192])  # 8192 = BASELINE minibatch
 def test_backward_ragged_batches_with_gather(batch):
   rs = np.random.RandomState(batch)
   A = 6

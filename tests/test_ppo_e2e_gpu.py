@@ -415,13 +415,17 @@ def test_bench_line_contract():
 
 def test_a2c_cnn_learns_image_bandit():
   """The A2C route (GAE with lambda 1, fused A2C loss, RMSprop with the annealed rate) as a learner
-  on the same image bandit: 300 rollouts of 64 envs x 5 steps at lr 1e-4 annealed to zero (the
-  preset's 7e-4 takes RMSprop's first normalised steps too far on this toy task and parks the
-  policy at 0.5; the run is deterministic, so the curve is the same on every box)."""
+  on the same image bandit: 300 rollouts of 64 envs x 5 steps at lr 5e-5 annealed to zero.  The
+  task has a trap -- a policy that never tries one of the four actions scores 0.75 and stays there
+  -- and RMSprop's first normalised steps decide whether a run falls into it: at the preset's 7e-4
+  every run does, at 1e-4 it depends on float32 summation order (tools/a2c_probe.py: 2 of 5 seeds
+  on one kernel route, 0 of 5 on another), at 5e-5 all five seeds reach 1.0 on every route.  Two
+  seeds here."""
   from tools.quadrant_learns import run
-  curve, _ = run(iterations=300, nenvs=64, horizon=5, seed=0, lr=1e-4, algorithm="a2c")
-  assert np.mean(curve[:5]) < 0.6, curve[:5]
-  assert np.mean(curve[-20:]) > 0.9, curve[-20:]
+  for seed in (0, 1):
+    curve, _ = run(iterations=300, nenvs=64, horizon=5, seed=seed, lr=5e-5, algorithm="a2c")
+    assert np.mean(curve[:5]) < 0.6, curve[:5]
+    assert np.mean(curve[-20:]) > 0.9, (seed, curve[-20:])
 
 
 @pytest.mark.parametrize("kind", ["cnn", "mlp"])
