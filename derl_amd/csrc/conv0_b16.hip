@@ -14,6 +14,8 @@
 //   wgrad   : dW[oc][k] = sum_m dY[m][oc] * x[m][k]; A = dY^T as three bf16 planes [oc][m] built once
 //             per 256-pixel tile, B = the bytes of 8 pixels at this lane's k (8 ds_read_u8).
 // Tiling, patch staging and the persistent tile loop are those of conv0.hip.
+#include <type_traits>
+
 #include "conv0_tile.hpp"
 
 namespace dx {
@@ -82,14 +84,25 @@ __global__ __launch_bounds__(256) void conv0_fwd_b16_kernel(const Conv0Args a) {
   const int lrow = lane & 31, h = lane >> 5;
   const float bias = a.bias[lrow];
   u32x4 pre[kPatchRegs];
-  if (blockIdx.x < a.ntiles) patch_load(a, tile_segments(a, blockIdx.x * kTile), pre);
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  Seg nxt = tile_segments(a, min(static_cast<int>(blockIdx.x), a.ntiles - 1) * kTile);  // the tile whose patch is in `pre`
+  if (blockIdx.x < a.ntiles) patch_load(a, nxt, pre);
+  // Whole tiles in the loop, the (at most one) ragged last tile after it: with the guarded stores of
+  // a ragged tile inside the loop the number of stores per pass is not static, hipcc then waits
+  // vmcnt(0) for the prefetched patch at the top of the next pass -- i.e. for every store of this
+  // one.  (Worth 2-3 % here; neither this, a two-tile-deep prefetch, software-pipelined fragment reads
+  // nor dropping the byte -> bf16 conversions moves the kernel off 175-180 us for 0.68 GB of traffic
+  // and 70 us of MFMA work.)
+  auto one_tile = [&](int tile, auto ragged) {
+    constexpr bool RAGGED = decltype(ragged)::value;
     const int m0 = tile * kTile;
-    const Seg s = tile_segments(a, m0);
+    const Seg s = nxt;
     __syncthreads();  // every wave finished reading the previous patch (and the planes are written)
     patch_store(s, pre, patch);
     __syncthreads();
-    if (tile + gridDim.x < a.ntiles) patch_load(a, tile_segments(a, (tile + gridDim.x) * kTile), pre);
+    if (tile + gridDim.x < a.ntiles) {
+      nxt = tile_segments(a, (tile + gridDim.x) * kTile);
+      patch_load(a, nxt, pre);
+    }
     int rb[2];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) rb[t2] = pixel_base(a, s, wave * 64 + t2 * 32 + lrow) + 8 * h;
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_b16_kernel(const Conv0Args a) {
     // Full tiles (all but the last) store through one per-lane base pointer with immediate
     // offsets; a guarded store per element compiles to 32 exec-mask branches.
     float *obase = a.out + (static_cast<long long>(m0) + wave * 64 + 4 * h) * 32 + lrow;
-    if (m0 + kTile <= a.M) {
+    if (!RAGGED) {
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -142,7 +155,11 @@ __global__ __launch_bounds__(256) void conv0_fwd_b16_kernel(const Conv0Args a) {
           }
         }
     }
-  }
+  };
+  const int nfull = a.M / kTile;
+  int tile = blockIdx.x;
+  for (; tile < nfull; tile += gridDim.x) one_tile(tile, std::false_type{});
+  if (tile < a.ntiles) one_tile(tile, std::true_type{});
 }
 
 constexpr int kGRowB = 528;            // bytes per row of a dY^T plane: 256 bf16 (m) + 16 pad

@@ -35,13 +35,25 @@ __device__ __forceinline__ Seg tile_segments(const Conv0Args &a, int m0) {
   s.cnt_b = left - s.cnt_a;
   s.oya0 = s.pa / a.w0;
   const int oya1 = (s.pa + s.cnt_a - 1) / a.w0;
-  const long long ia = a.idx ? a.idx[img_a] : img_a;
+  // The image gather is read with SCALAR loads (the table is never written by these kernels).  As a
+  // vector load the compiler waits for it with vmcnt(0), which also waits for every store the
+  // workgroup still has in flight (the previous tile's output): one full drain per tile.
+  long long ia = img_a, ib = img_a + 1;
+  if (a.idx) {
+    const int32_t *pa = a.idx + __builtin_amdgcn_readfirstlane(img_a);
+    const int32_t *pb = s.cnt_b > 0 ? pa + 1 : pa;  // (the entry behind the last image is not touched)
+    int va, vb;
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(va), "=&s"(vb)
+                 : "s"(pa), "s"(pb)
+                 : "memory");
+    ia = va; ib = vb;
+  }
   s.src_a = ia * imgB + static_cast<long long>(4 * s.oya0) * rowB;
   s.bytes_a = (4 * (oya1 - s.oya0) + 8) * rowB;
   s.src_b = 0;
   s.bytes_b = 0;
   if (s.cnt_b > 0) {
-    const long long ib = a.idx ? a.idx[img_a + 1] : img_a + 1;
     s.src_b = ib * imgB;
     s.bytes_b = (4 * ((s.cnt_b - 1) / a.w0) + 8) * rowB;
   }
