@@ -333,8 +333,7 @@ int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
   j[n - 1].scatter = 1;
   add(w + c->off_w[5], pk + c->pk_hdd + A, kHid, kHid, 1, 1, 1, kHeadLd, 0, 0, 0);
   j[n - 1].scatter = 1;
-  if (int rc = launch_permute_reduce(j, n, s)) return rc;
-  if (int rc = launch_fc_pack(w + c->off_w[3], pk + c->pk_fcf, pk + c->pk_fcd, kHid, P, kC2, s)) return rc;
+  if (int rc = launch_pack_fused(j, n, w + c->off_w[3], pk + c->pk_fcf, pk + c->pk_fcd, kHid, P, kC2, s)) return rc;
   // bf16 planes (second launch: reads the mirrors packed above): conv0 for the rollout kernel,
   // the other NT mirrors only for the opt-in bf16-split GEMMs
   const long long wsz0 = kC0 * 64LL * IC0, wsz1 = kC1 * 16LL * kC0, wsz2 = kC2 * 9LL * kC1,
@@ -432,9 +431,9 @@ static int finalize_grads(const dx_cnn_ctx *c, const Plan &plan, int which, hipS
     addb(L_FC, c->off_b[3], kHid, 0, kHid);
     addb(L_HD, c->off_b[4], A, 0, kHeadLd);
     addb(L_HD, c->off_b[5], 1, A, kHeadLd);
-    if (int rc = launch_fc_grad_finalize(c->slabs + plan.s[L_FC].w_off, plan.s[L_FC].msplit,
-                                         static_cast<long long>(kHid) * flat, g + c->off_w[3], kHid, P, kC2, s))
-      return rc;
+    // one launch for the permute jobs and the linear layer's [p][c] -> [c][p] reduction
+    return launch_finalize_fused(j, n, c->slabs + plan.s[L_FC].w_off, plan.s[L_FC].msplit,
+                                 static_cast<long long>(kHid) * flat, g + c->off_w[3], kHid, P, kC2, s);
   }
   return launch_permute_reduce(j, n, s);
 }

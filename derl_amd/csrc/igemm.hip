@@ -522,10 +522,8 @@ struct JobTable {
 // slabs (wave g sums slabs z = g, g+4, ...) with the 64 lanes on consecutive elements, so every
 // slab read is one coalesced 256-B row when the source is contiguous along the fastest output
 // dimension (all finalize jobs); the waves combine through LDS.  Loads are issued 8 deep.
-__global__ __launch_bounds__(256) void permute_reduce_kernel(const JobTable t) {
-  __shared__ float red[4][64];
+__device__ __forceinline__ void permute_reduce_block(const JobTable &t, int b, float (*red)[64]) {
   int job = 0;
-  const int b = blockIdx.x;
   while (job + 1 < t.njobs && b >= t.chunk_begin[job + 1]) ++job;  // uniform, <= kMaxJobs steps
   const PermuteJob &j = t.jobs[job];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -551,6 +549,11 @@ __global__ __launch_bounds__(256) void permute_reduce_kernel(const JobTable t) {
   __syncthreads();
   if (g == 0 && active)
     j.dst[j.scatter ? strided : i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+__global__ __launch_bounds__(256) void permute_reduce_kernel(const JobTable t) {
+  __shared__ float red[4][64];
+  permute_reduce_block(t, blockIdx.x, red);
 }
 
 template <int TAG, int BM, int BN, int WM, int WN, bool AU8, int EPI, int BK = 32>
@@ -700,12 +703,11 @@ namespace {
 // Packing of the 3136-wide linear layer (95 % of the parameters) with coalesced traffic on both
 // sides.  fcf[n][p*C + c] = W[n][c*P + p] (the reference flattens NCHW, activations here are
 // NHWC): one workgroup per row n stages the row in LDS and writes it permuted.
-__global__ __launch_bounds__(256) void fc_row_permute_kernel(const float *__restrict__ W, float *__restrict__ out,
-                                                            int P, int C) {
-  extern __shared__ float row[];
+__device__ __forceinline__ void fc_row_permute_block(const float *__restrict__ W, float *__restrict__ out, int P,
+                                                     int C, int n, float *row) {
   const int K = P * C;
-  const float *src = W + static_cast<long long>(blockIdx.x) * K;
-  float *dst = out + static_cast<long long>(blockIdx.x) * K;
+  const float *src = W + static_cast<long long>(n) * K;
+  float *dst = out + static_cast<long long>(n) * K;
   for (int i = threadIdx.x; i < K; i += 256) row[i] = src[i];
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += 256) {
@@ -714,19 +716,24 @@ __global__ __launch_bounds__(256) void fc_row_permute_kernel(const float *__rest
   }
 }
 
+__global__ __launch_bounds__(256) void fc_row_permute_kernel(const float *__restrict__ W, float *__restrict__ out,
+                                                            int P, int C) {
+  extern __shared__ float row[];
+  fc_row_permute_block(W, out, P, C, blockIdx.x, row);
+}
+
 // The inverse for the weight gradient: canonical dW[n][c*P + p] = sum_z slab[z][n][p*C + c].  A
 // workgroup takes one row n and one half of the channels: it sums the slabs with 16-byte loads
 // (two slabs in flight per thread), permutes through LDS (row stride C/2 + 1: the transposed read
 // walks p, which with a power-of-two stride would hit one bank 49 times) and writes its
 // contiguous [c][p] range.  Was one scalar-load workgroup per row: 27-35 us for 38 MB.
-__global__ __launch_bounds__(256) void fc_row_unpermute_reduce_kernel(const float *__restrict__ slab, int nslab,
-                                                                     long long slab_stride,
-                                                                     float *__restrict__ out, int P, int C) {
+__device__ __forceinline__ void fc_row_unpermute_block(const float *__restrict__ slab, int nslab,
+                                                       long long slab_stride, float *__restrict__ out, int P,
+                                                       int C, int bx, int by, float *row) {  // row: [P][C/2 + 1]
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  extern __shared__ float row[];  // [P][CH + 1]
   const int CH = C / 2, C4 = CH / 4, LD = CH + 1;
   const long long K = static_cast<long long>(P) * C;
-  const float *src = slab + blockIdx.x * K + blockIdx.y * CH;
+  const float *src = slab + bx * K + by * CH;
   for (int q = threadIdx.x; q < P * C4; q += 256) {
     const int p = q / C4, c4 = q - p * C4;
     const float *s = src + p * C + 4 * c4;
@@ -742,10 +749,39 @@ __global__ __launch_bounds__(256) void fc_row_unpermute_reduce_kernel(const floa
     d[0] = v0[0]; d[1] = v0[1]; d[2] = v0[2]; d[3] = v0[3];
   }
   __syncthreads();
-  float *dst = out + blockIdx.x * K + static_cast<long long>(blockIdx.y) * CH * P;
+  float *dst = out + bx * K + static_cast<long long>(by) * CH * P;
   for (int i = threadIdx.x; i < CH * P; i += 256) {
     const int c = i / P, p = i - c * P;
     dst[i] = row[p * LD + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void fc_row_unpermute_reduce_kernel(const float *__restrict__ slab, int nslab,
+                                                                     long long slab_stride,
+                                                                     float *__restrict__ out, int P, int C) {
+  extern __shared__ float row[];
+  fc_row_unpermute_block(slab, nslab, slab_stride, out, P, C, blockIdx.x, blockIdx.y, row);
+}
+
+// Gradient finalisation in ONE launch: the strided slab reductions of permute_reduce_kernel in
+// workgroups [0, chunks), the linear layer's [p][c] -> [c][p] reduction in the rest -- the two are
+// independent, and as separate launches on one stream the second waited for the first (28 + 14 us).
+struct FcFinalize {
+  const float *slab;
+  int nslab;
+  long long slab_stride;
+  float *out;
+  int N, P, C;
+};
+__global__ __launch_bounds__(256) void finalize_fused_kernel(const JobTable t, const FcFinalize f, int chunks) {
+  __shared__ float red[4][64];
+  extern __shared__ float row[];
+  const int b = blockIdx.x;
+  if (b < chunks) {
+    permute_reduce_block(t, b, red);
+  } else {
+    const int r = b - chunks;
+    fc_row_unpermute_block(f.slab, f.nslab, f.slab_stride, f.out, f.P, f.C, r >> 1, r & 1, row);
   }
 }
 
@@ -785,6 +821,71 @@ int launch_fc_grad_finalize(const float *slab, int nslab, long long slab_stride,
 int launch_fc_pack(const float *W, float *fcf, float *fcd, int N, int P, int C, hipStream_t stream) {
   DX_REQUIRE(W && fcf && fcd && N > 0 && P > 0 && C > 0 && P * C * 4 <= 64 * 1024, "fc_pack: bad arguments");
   hipLaunchKernelGGL(fc_row_permute_kernel, dim3(N), dim3(256), sizeof(float) * P * C, stream, W, fcf, P, C);
+  DX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(P * C, 64), cdiv(N, 64)), dim3(256), 0, stream, fcf, fcd, N,
+                     P * C);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+// Weight packing: the strided mirrors (permute jobs) in workgroups [0, chunks), the linear layer's
+// row permutation in the rest (independent; one launch less per optimizer step)
+__global__ __launch_bounds__(256) void pack_fused_kernel(const JobTable t, const float *__restrict__ W,
+                                                        float *__restrict__ fcf, int P, int C, int chunks) {
+  __shared__ float red[4][64];
+  extern __shared__ float row[];
+  const int b = blockIdx.x;
+  if (b < chunks) permute_reduce_block(t, b, red);
+  else fc_row_permute_block(W, fcf, P, C, b - chunks, row);
+}
+
+// permute jobs + the linear layer's gradient (see finalize_fused_kernel)
+int launch_finalize_fused(const PermuteJob *jobs, int njobs, const float *slab, int nslab, long long slab_stride,
+                          float *grad, int N, int P, int C, hipStream_t stream) {
+  DX_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "finalize_fused: %d jobs (max %d)", njobs, kMaxJobs);
+  DX_REQUIRE(slab && grad && nslab >= 1 && N > 0 && P * C * 4 <= 64 * 1024 && C % 8 == 0 && slab_stride % 4 == 0 &&
+                 aligned(slab, 16),
+             "finalize_fused: bad arguments");
+  JobTable t;
+  long long chunks = 0;
+  for (int i = 0; i < njobs; ++i) {
+    DX_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].nslab >= 1 && jobs[i].D1 > 0 && jobs[i].D2 > 0 &&
+                   jobs[i].D3 > 0 && jobs[i].total > 0,
+               "finalize_fused: bad job %d", i);
+    t.jobs[i] = jobs[i];
+    t.chunk_begin[i] = static_cast<int>(chunks);
+    chunks += (jobs[i].total + 63) / 64;
+    DX_REQUIRE(chunks < (1LL << 30), "finalize_fused: too many elements");
+  }
+  t.chunk_begin[njobs] = static_cast<int>(chunks);
+  t.njobs = njobs;
+  const FcFinalize f{slab, nslab, slab_stride, grad, N, P, C};
+  hipLaunchKernelGGL(finalize_fused_kernel, dim3(static_cast<unsigned>(chunks) + 2 * N), dim3(256),
+                     sizeof(float) * P * (C / 2 + 1), stream, t, f, static_cast<int>(chunks));
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+// permute jobs + fcf [N][P*C] (k = p*C + c) from the canonical W [N][C*P] in one launch, then its
+// transpose fcd [P*C][N]
+int launch_pack_fused(const PermuteJob *jobs, int njobs, const float *W, float *fcf, float *fcd, int N, int P, int C,
+                      hipStream_t stream) {
+  DX_REQUIRE(njobs >= 1 && njobs <= kMaxJobs && W && fcf && fcd && N > 0 && P > 0 && C > 0 && P * C * 4 <= 64 * 1024,
+             "pack_fused: bad arguments");
+  JobTable t;
+  long long chunks = 0;
+  for (int i = 0; i < njobs; ++i) {
+    DX_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].nslab >= 1 && jobs[i].D1 > 0 && jobs[i].D2 > 0 &&
+                   jobs[i].D3 > 0 && jobs[i].total > 0,
+               "pack_fused: bad job %d", i);
+    t.jobs[i] = jobs[i];
+    t.chunk_begin[i] = static_cast<int>(chunks);
+    chunks += (jobs[i].total + 63) / 64;
+  }
+  t.chunk_begin[njobs] = static_cast<int>(chunks);
+  t.njobs = njobs;
+  hipLaunchKernelGGL(pack_fused_kernel, dim3(static_cast<unsigned>(chunks) + N), dim3(256), sizeof(float) * P * C,
+                     stream, t, W, fcf, P, C, static_cast<int>(chunks));
   DX_LAUNCH_CHECK();
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(P * C, 64), cdiv(N, 64)), dim3(256), 0, stream, fcf, fcd, N,
                      P * C);

@@ -146,6 +146,10 @@ struct PermuteJob {
 constexpr int kMaxJobs = 24;
 int launch_permute_reduce(const PermuteJob *jobs, int njobs, hipStream_t stream);
 // the linear layer's two mirrors with coalesced reads and writes (row permute, then tiled transpose)
+int launch_finalize_fused(const PermuteJob *jobs, int njobs, const float *slab, int nslab, long long slab_stride,
+                          float *grad, int N, int P, int C, hipStream_t stream);
+int launch_pack_fused(const PermuteJob *jobs, int njobs, const float *W, float *fcf, float *fcd, int N, int P, int C,
+                      hipStream_t stream);
 int launch_fc_pack(const float *W, float *fcf, float *fcd, int N, int P, int C, hipStream_t stream);
 // canonical dW[n][c*P + p] = sum over slabs of slab[z][n][p*C + c] (coalesced on both sides)
 int launch_fc_grad_finalize(const float *slab, int nslab, long long slab_stride, float *grad, int N, int P,
