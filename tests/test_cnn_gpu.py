@@ -156,7 +156,8 @@ def test_loss_and_gradients_match_reference_golden(name):
 # 1024 / 2100: the training-size code paths (128x64 forward tiles from 65536 rows, wgrad with the
 # XCD-aware block numbering from 64 reduction slices, pixel-group dgrads with a ragged last group)
 # 2048: the persistent ring kernels with few tiles per workgroup + nt_dma for the linear layer
-@pytest.mark.parametrize("batch", [1, 5, 37, 130, 1024, 2048, 2100, 8192])  # 8192 = BASELINE minibatch
+# 1152 = 9 groups of 128 images: the ring kernels with one XCD holding two image groups, the others one
+@pytest.mark.parametrize("batch", [1, 5, 37, 130, 1024, 1152, 2048, 2100, 8192])  # 8192 = BASELINE minibatch
 def test_backward_ragged_batches_with_gather(batch):
   rs = np.random.RandomState(batch)
   A = 6

@@ -21,7 +21,7 @@ STAGE_OF = [  # substring of the kernel name -> stage
     ("conv_wgrad_direct_kernel<9,", "conv2_wgrad"), ("igemm_tn_kernel<9,", "conv2_wgrad"),
     ("igemm_nt_pix_kernel<10,", "conv2_dgrad"), ("conv_wgrad_direct_kernel<11,", "conv1_wgrad"),
     ("igemm_tn_kernel<11,", "conv1_wgrad"), ("igemm_nt_pix_kernel<12,", "conv1_dgrad"),
-    ("conv0_wgrad_b16", "conv0_wgrad"), ("permute_reduce_kernel", "finalize"),
+    ("conv0_wgrad_b16", "conv0_wgrad"), ("finalize_fused_kernel", "finalize"), ("permute_reduce_kernel", "finalize"),
     ("fc_row_unpermute_reduce", "finalize_fc"),
 ]
 
