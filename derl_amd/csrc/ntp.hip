@@ -614,7 +614,7 @@ int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, 
   p.nimg = M;
   p.ngroups = M / ShapeS::BM;
   p.tiles_per_xcd = cdiv(p.ngroups, 8) * gn;
-  return mask ? launch_as<ST_FC_DGRAD, 2, EPI_MASK, ShapeS>(p, stream) : launch_as<ST_FC_FWD, 2, EPI_BIAS, ShapeS>(p, stream);
+  return mask ? launch_as<ST_FC_DGRAD, 2, EPI_MASK, ShapeS>(p, stream) : launch_as<ST_FC_FWD, 2, EPI_BIAS, ShapeF>(p, stream);
 }
 
 }  // namespace dx
