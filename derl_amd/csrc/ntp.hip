@@ -1,23 +1,31 @@
-// Persistent NT GEMM for the 64-column conv stages (conv1 / conv2 forward, conv2 dgrad):
-// C[m][n] = epi(sum_k A(m,k) * Wp[n][k]) with the implicit A matrix of igemm.hpp.
+// Persistent NT GEMM with loader and consumer waves: conv1 / conv2 forward, conv2 / conv1 dgrad and
+// the linear layer's forward and dgrad at training batches (derl/models.py:94-124 and its autograd
+// backward).  C[m][n] = epi(sum_k A(m,k) * Wp[n][k]) with the implicit A matrix of igemm.hpp.
 //
 // The LDS-tiled kernels of igemm.hip / igemm_pix.hip start a workgroup per output tile: with K =
 // 512 / 576 (and 64..576 for a dgrad pixel, whose invalid taps are skipped) a tile is 2..18 K steps,
 // and every tile pays its own memory round trip before the first MFMA and its own epilogue after
 // the last.  Here 512 workgroups (two per CU) stay resident and walk their tiles as ONE stream of
-// K steps:
-//   * operands arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB pieces of 8 rows x 128 bytes) in a
-//     ring of three stages; the fills for step g + 2 are issued behind the barrier of step g, so
-//     the ring keeps running across tile boundaries: the next tile's first operands are in
+// K steps through a ring of LDS stages:
+//   * LOADER waves issue nothing but LDS-DMA fills (global_load_lds_dwordx4, 1 KiB pieces of 8 rows
+//     x 128 bytes) in the SGPR-base form: a uniform 64-bit base (tensor + the step's offset, scalar
+//     adds) plus one per-lane 32-bit offset that changes only with the tile -- no vector ALU
+//     instruction per fill (beside busy matrix pipes every VALU instruction waits for a gap);
+//   * CONSUMER waves do the fragment reads, the MFMAs and the epilogues; ONE s_barrier per K step is
+//     the whole hand-off: the loaders arrive once the step's fill has landed (their own counted
+//     vmcnt), the consumers once they are done with the previous step, whose slot the loaders then
+//     refill.  The ring keeps running across tile boundaries, so the next tile's operands are in
 //     flight while this tile's last MFMAs and its epilogue run;
-//   * ONE barrier per K step behind a counted vmcnt (loads, stores and LDS-DMA complete in issue
-//     order: the two steps after an epilogue count its 32 stores);
-//   * a 128 x 64 tile on 4 waves of 64 x 32: a lane reads 4 consecutive k of its row with one
-//     ds_read_b128 (3 reads feed 8 MFMAs); the DMA writes LDS linearly, so the bank swizzle is
-//     applied to the SOURCE address (16-byte chunk c of row R sits in slot c ^ ((R >> 1) & 7));
-//   * MODE 0 (forward): a tile is 128 consecutive output pixels; MODE 1 (dgrad): a tile is one
-//     input pixel of 128 images, so the set of valid taps is uniform and the others are skipped;
-//     the workgroups of an XCD walk the pixels of the same image groups (shared taps from L2).
+//   * the DMA writes LDS linearly, so the bank swizzle of the 128-byte rows is applied to the
+//     SOURCE address (16-byte chunk c of row R sits in slot c ^ ((R >> 1) & 7)): a lane reads 4
+//     consecutive k of its row with one conflict-free ds_read_b128 (3 reads feed 8 MFMAs);
+//   * MODE 0 (forward): a tile is BM consecutive output pixels, the K steps come from a host-built
+//     table (the stride-2 layer walks its taps grouped by parity: L2 reuse of the input);
+//     MODE 1 (dgrad): a tile is one input pixel of BM images, so the set of valid taps is uniform
+//     (a rectangle computed arithmetically) and the others are skipped; the workgroups of an XCD
+//     walk the pixels of the same image groups (shared taps from L2); MODE 2 (plain rows, the
+//     linear layer): the same walk with the column tile in the pixel's place.
+// Shapes, measurements and what did NOT work: DESIGN.md section 3.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
