@@ -9,7 +9,11 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libderl_amd.so")
-ABI_VERSION = 1
+# DERL_AMD_LIBRARY=diag: the -DDX_DIAG=1 flavour (derl_amd/build.py), for tools/ only -- it carries
+# the in-kernel stamps and bisecting switches that are compiled out of the product library
+if os.environ.get("DERL_AMD_LIBRARY", "") == "diag":
+  LIB_PATH = os.path.join(_PKG, "libderl_amd_diag.so")
+ABI_VERSION = 2
 
 c_int, c_float, c_void_p, c_char_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p
 c_size_t, c_int64, c_uint64, c_double = ctypes.c_size_t, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double

@@ -107,7 +107,9 @@ class Trainer:
   def _epoch_fast_path(self, alg, data):
     """(context, k) when EVERY update of this minibatch's epoch can be (or already was) enqueued
     from one native call: MLP engine, flat Adam, single process, no summaries being recorded,
-    and the minibatch is the untouched slice of the epoch's arrays.  A caller that abandons an
+    the minibatch is the untouched slice of the epoch's arrays and its advantages are either the
+    raw slice or what NormalizeAdvantages made of it (the transform records its epsilon in the
+    context: the native epoch normalises with THAT epsilon, or not at all).  A caller that abandons an
     epoch halfway still gets all of its updates applied -- set ``native_epochs = False`` then."""
     if not self.native_epochs or summary.should_record() or distributed.world_size() > 1:
       return None
@@ -119,10 +121,29 @@ class Trainer:
       return None
     context, k = entry
     start = k * context.mbsize
-    for key in ("value_targets", "actions", "observations"):  # still the epoch's own slices?
-      mine, whole = data.get(key), context.shuffled.get(key)
-      if not isinstance(mine, torch.Tensor) or whole is None or mine.data_ptr() != whole[start:].data_ptr():
+
+    def same(mine, whole):
+      return (isinstance(mine, torch.Tensor) and isinstance(whole, torch.Tensor)
+              and mine.data_ptr() == whole[start:].data_ptr())
+
+    # still the epoch's own slices?  (a transform that replaced any of them -- or a pipeline whose
+    # advantages are neither the raw slice nor NormalizeAdvantages' output -- trains step by step)
+    keys = ["value_targets", "actions", "observations"]
+    if getattr(alg.loss_fn, "mode", 0) == 0:
+      keys += ["log_prob", "values"]
+    for key in keys:
+      if not same(data.get(key), context.shuffled.get(key)):
         return None
+    mine = data.get("advantages")
+    if context.norm_eps is None:
+      if not same(mine, context.shuffled.get("advantages")):
+        return None
+    elif context.consumed:
+      if not same(mine, context.normalized):
+        return None
+    elif not (isinstance(mine, torch.Tensor) and context.norm_first is not None
+              and mine.data_ptr() == context.norm_first.data_ptr()):
+      return None
     if not context.consumed and k != 0:
       return None  # joined mid-epoch: step by step
     return context, k

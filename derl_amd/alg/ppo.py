@@ -88,7 +88,7 @@ class PPOLoss(ActorCriticDeviceLoss):
   def epoch_arguments(self):
     """Hyper-parameters of the fused loss kernels for a native epoch (Trainer.step)."""
     return dict(mode=0, cliprange=self.cliprange, value_loss_coef=self.value_loss_coef,
-                entropy_coef=self.entropy_coef, normalize_eps=1e-8)
+                entropy_coef=self.entropy_coef)
 
   def evaluate_native(self, data):
     """(loss scalar on the device, closure running the model backward): what ``__call__``

@@ -2,8 +2,12 @@
 
 ``build_library()``       derl_amd/csrc/*.hip -> derl_amd/libderl_amd.so: the C-ABI declared in
                           include/derl_amd.h (the product).
-``build_diag_library()``  derl_amd/csrc/experiments/diag.hip -> derl_amd/libderl_amd_diag.so: the
-                          microbenchmark entry points of include/derl_amd_diag.h (tools/ only).
+``build_diag_library()``  the product sources with -DDX_DIAG=1 (in-kernel stamps and the bisecting
+                          switches DX_NTP_DIAG / DX_NT_DIAG / DX_WD_DIAG / DX_FC_DIAG / DX_NTP_NWG /
+                          DX_WD_NWG, some of which compute wrong results on purpose: compiled OUT of
+                          libderl_amd.so) + derl_amd/csrc/experiments/diag.hip (the microbenchmark
+                          entry points of include/derl_amd_diag.h) -> derl_amd/libderl_amd_diag.so.
+                          Self-contained; tools/ load it with DERL_AMD_LIBRARY=diag.
 ``build_host_asan()``     the HOST side of every product source (argument validation, planning,
                           launch set-up) compiled with -fsanitize=address into
                           derl_amd/libderl_amd_hostasan.so; device code is not built
@@ -90,16 +94,31 @@ def build_library(force=False, verbose=False, jobs=4):
   return LIB
 
 
-def build_diag_library(verbose=False):
-  """The microbenchmark library (links against libderl_amd.so for the error buffer)."""
+def _uses_diag_macro(src):
+  with open(src) as f:
+    return "DX_DIAG" in f.read()
+
+
+def build_diag_library(verbose=False, jobs=4):
+  """The diagnostic flavour: every product source that looks at DX_DIAG recompiled with
+  -DDX_DIAG=1 (the others' objects are shared with the product build) + the microbenchmarks."""
   if not os.path.exists(HIPCC):
     return DIAG_LIB if os.path.exists(DIAG_LIB) else None
   build_library(verbose=verbose)
   os.makedirs(OBJ, exist_ok=True)
-  src = os.path.join(CSRC, "experiments", "diag.hip")
-  obj = _compile(src, _headers(), verbose)
-  if _stale(DIAG_LIB, [obj, LIB]):
-    _link([obj], DIAG_LIB, verbose, ["-L" + PKG, "-lderl_amd", "-Wl,-rpath,$ORIGIN"])
+  headers = _headers()
+  sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+  def one(src):
+    if _uses_diag_macro(src):
+      return _compile(src, headers, verbose, ("-DDX_DIAG=1",), ".diag")
+    return _compile(src, headers, verbose)
+
+  with concurrent.futures.ThreadPoolExecutor(jobs) as pool:
+    objs = list(pool.map(one, sources))
+  objs.append(_compile(os.path.join(CSRC, "experiments", "diag.hip"), headers, verbose))
+  if _stale(DIAG_LIB, objs):
+    _link(objs, DIAG_LIB, verbose, ["-ldl"])
   return DIAG_LIB
 
 

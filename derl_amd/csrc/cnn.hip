@@ -9,6 +9,7 @@
 #include "igemm.hpp"
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 using namespace dx;
 
@@ -75,8 +76,10 @@ struct SideStream { hipStream_t stream[kMaxLanes - 1]; hipEvent_t fork, join[kMa
 SideStream *side_stream() {
   static SideStream table[16];
   static bool made[16];
+  static std::mutex lock;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { fail(DX_EHIP, "side_stream: no current device"); return nullptr; }
+  std::lock_guard<std::mutex> guard(lock);
   if (!made[dev]) {
     SideStream &t = table[dev];
     bool ok = hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
@@ -736,27 +739,34 @@ int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_
     DX_HIP(hipEventRecord(side->fork, s));
     for (int l = 1; l < lanes; ++l) DX_HIP(hipStreamWaitEvent(side->stream[l - 1], side->fork, 0));
   }
-  for (int t = 0; t < T; ++t) {
-    for (int l = 0; l < lanes; ++l) {
+  int rc = DX_OK;
+  for (int t = 0; t < T && rc == DX_OK; ++t) {
+    for (int l = 0; l < lanes && rc == DX_OK; ++l) {
       hipStream_t ls = l == 0 ? s : side->stream[l - 1];
       const dx_cnn_ctx *lc = &lane_ctx[l];
       NTArgs a;
-      if (int rc = act_trunk(lc, obs + t * frame + l * pframe, 1, part, &a, ls)) return rc;
+      rc = act_trunk(lc, obs + t * frame + l * pframe, 1, part, &a, ls);
+      if (rc != DX_OK) break;
       const long long row = static_cast<long long>(t) * N + l * part;
-      if (int rc = launch_heads_act_synth(lc->hid_slabs, a.ksplit, a.slab_stride, c->packed + c->pk_hdf,
-                                          c->packed + c->pk_hdb, part, c->num_actions, policy_seed,
-                                          policy_counter + t, actions + row, log_prob + row, values + row,
-                                          obs + (t + 1) * frame + l * pframe, pframe, rewards + row,
-                                          resets + row, env_seed, env_counter + t, p_reward, p_reset, l * part,
-                                          l * (pframe / 16), ls))
-        return rc;
+      rc = launch_heads_act_synth(lc->hid_slabs, a.ksplit, a.slab_stride, c->packed + c->pk_hdf,
+                                  c->packed + c->pk_hdb, part, c->num_actions, policy_seed,
+                                  policy_counter + t, actions + row, log_prob + row, values + row,
+                                  obs + (t + 1) * frame + l * pframe, pframe, rewards + row,
+                                  resets + row, env_seed, env_counter + t, p_reward, p_reset, l * part,
+                                  l * (pframe / 16), ls);
     }
   }
+  // also on failure: the caller's stream must not run ahead of (and the caller must not free
+  // buffers under) work already enqueued on the side streams
   for (int l = 1; l < lanes; ++l) {
-    DX_HIP(hipEventRecord(side->join[l - 1], side->stream[l - 1]));
-    DX_HIP(hipStreamWaitEvent(s, side->join[l - 1], 0));
+    const bool joined = hipEventRecord(side->join[l - 1], side->stream[l - 1]) == hipSuccess &&
+                        hipStreamWaitEvent(s, side->join[l - 1], 0) == hipSuccess;
+    if (!joined) {
+      (void)hipStreamSynchronize(side->stream[l - 1]);
+      if (rc == DX_OK) rc = fail(DX_EHIP, "dx_cnn_rollout_synth: cannot join the side streams");
+    }
   }
-  return DX_OK;
+  return rc;
 }
 
 // A single stage, for per-kernel timing (bench.py roofline) and layer-level tests.

@@ -6,7 +6,17 @@
 #include <cstdio>
 #include "../../include/derl_amd.h"
 
+// -DDX_DIAG=1 (libderl_amd_diag.so only, derl_amd/build.py): in-kernel stamps and the bisecting
+// switches of the ring / weight-gradient kernels (DX_NTP_DIAG, DX_NT_DIAG, DX_WD_DIAG, DX_FC_DIAG,
+// DX_NTP_NWG, DX_WD_NWG -- some of them compute WRONG results on purpose).  The product library is
+// built without it: the branches are compiled out of its kernels and the variables are never read.
+#ifndef DX_DIAG
+#define DX_DIAG 0
+#endif
+
 namespace dx {
+
+constexpr bool kDiag = DX_DIAG != 0;
 
 char *error_buffer();  // thread-local, 512 bytes
 

@@ -28,7 +28,7 @@ constexpr int kStageFloats = (kBM + kBN) * kBK;  // 8192 floats = 32 KiB
 template <int EPI, int STAGES>
 __global__ __launch_bounds__(512, 2) void nt_dma_kernel(const NtDmaArgs a, unsigned long long *stamps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const unsigned long long t_entry = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  const unsigned long long t_entry = (kDiag && stamps) ? __builtin_amdgcn_s_memrealtime() : 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void nt_dma_kernel(const NtDmaArgs a, unsig
   int slot = 0;
   unsigned long long t_first = 0, c_first = 0;
   for (int s = 0; s < ksteps; ++s) {
-    if (stamps && s == 1) { t_first = __builtin_amdgcn_s_memrealtime(); c_first = __builtin_amdgcn_s_memtime(); }
+    if (kDiag && stamps && s == 1) { t_first = __builtin_amdgcn_s_memrealtime(); c_first = __builtin_amdgcn_s_memtime(); }
     if (STAGES == 3 && s + 1 < ksteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // not __syncthreads(): its fence would wait for the stage in flight
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(512, 2) void nt_dma_kernel(const NtDmaArgs a, unsig
     slot = slot == STAGES - 1 ? 0 : slot + 1;
   }
 #undef DX_NT_ISSUE
-  const unsigned long long t_loop = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
-  const unsigned long long c_loop = stamps ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long t_loop = (kDiag && stamps) ? __builtin_amdgcn_s_memrealtime() : 0;
+  const unsigned long long c_loop = (kDiag && stamps) ? __builtin_amdgcn_s_memtime() : 0;
 
   // epilogue: C/D layout of the 32x32 MFMA: column = l31, row = (r & 3) + 8 (r >> 2) + 4 hi
   const int n = n0 + wn * 32 + l31;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void nt_dma_kernel(const NtDmaArgs a, unsig
       a.out[row0 + static_cast<long long>(32 * t + (r & 3) + 8 * (r >> 2)) * a.ldc] = v;
     }
   }
-  if (stamps && lane == 0) {  // DX_NT_DIAG: 100 MHz ticks (entry, first stage done, loop end, exit) + loop cycles
+  if (kDiag && stamps && lane == 0) {  // DX_NT_DIAG: 100 MHz ticks (entry, first stage done, loop end, exit) + loop cycles
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long *o = stamps + (static_cast<long long>(blockIdx.x) * 8 + wave) * 5;
     o[0] = t_entry; o[1] = t_first; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = c_loop - c_first;
@@ -163,12 +163,17 @@ int launch_as(const NtDmaArgs &a, hipStream_t stream) {
     configured = true;
   }
   const int grid = (a.M / kBM) * cdiv(a.N, kBN);
+#if DX_DIAG
   static const int diag = getenv("DX_NT_DIAG") ? atoi(getenv("DX_NT_DIAG")) : 0;
+#else
+  constexpr int diag = 0;
+#endif
   if (!diag) {
     hipLaunchKernelGGL((nt_dma_kernel<EPI, STAGES>), dim3(grid), dim3(512), lds, stream, a, nullptr);
     DX_LAUNCH_CHECK();
     return DX_OK;
   }
+#if DX_DIAG
   // diagnostic: in-kernel stamps, summarised on stderr (synchronous; never on the product path)
   unsigned long long *dev = nullptr;
   const size_t count = static_cast<size_t>(grid) * 8 * 5;
@@ -192,6 +197,7 @@ int launch_as(const NtDmaArgs &a, hipStream_t stream) {
   fprintf(stderr, "[nt_dma M=%d N=%d K=%d grid=%d] span %.1f us | per wave: to first stage %.2f us, %d stages %.2f us "
           "(%.0f cycles/stage, ideal %d, clock %.2f GHz), epilogue %.2f us\n", a.M, a.N, a.K, grid, (last - first) * 0.01,
           med(pro), ks, lm, cm / ks, 32 * 64 * (grid > 256 && STAGES == 2 ? 4 : 2), cm / lm * 1e-3, med(epi));
+#endif
   return DX_OK;
 }
 

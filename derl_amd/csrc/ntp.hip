@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
                                                                                                unsigned long long *stamps) {
   using S = ntp::Shape<BM, BN, TM, TN, RING, NLOAD, WGS>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const unsigned long long t_entry = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  const unsigned long long t_entry = (kDiag && stamps) ? __builtin_amdgcn_s_memrealtime() : 0;
   const NTArgs &a = p.nt;
   const Gather &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -232,17 +232,17 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
         ++slot;
       }
     slot = S::RING - 1;
-    unsigned long long l_vm = 0, l_bar = 0, l_all = stamps ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long l_vm = 0, l_bar = 0, l_all = (kDiag && stamps) ? __builtin_amdgcn_s_memtime() : 0;
     for (int gstep = 0; gstep < issued; ++gstep) {
       // hand step gstep over: its fill is the oldest in flight, at most RING - 2 younger fills behind it
-      const unsigned long long l0 = (stamps && (p.diag & 2)) ? __builtin_amdgcn_s_memtime() : 0;
+      const unsigned long long l0 = (kDiag && stamps && (p.diag & 2)) ? __builtin_amdgcn_s_memtime() : 0;
       if (S::RING == 3 && issued - gstep >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::APIECES + S::WPIECES) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned long long l1 = (stamps && (p.diag & 2)) ? __builtin_amdgcn_s_memtime() : 0;
+      const unsigned long long l1 = (kDiag && stamps && (p.diag & 2)) ? __builtin_amdgcn_s_memtime() : 0;
       __builtin_amdgcn_s_barrier();  // consumers are done with step gstep - 1: its slot is free
       asm volatile("" ::: "memory");
-      if (stamps && (p.diag & 2)) { l_vm += l1 - l0; l_bar += __builtin_amdgcn_s_memtime() - l1; }
-      if (ld.valid && !(p.diag & 4)) {
+      if (kDiag && stamps && (p.diag & 2)) { l_vm += l1 - l0; l_bar += __builtin_amdgcn_s_memtime() - l1; }
+      if (ld.valid && !(kDiag && (p.diag & 4))) {
         DX_NTP_FILL(slot)
         slot = slot == S::RING - 1 ? 0 : slot + 1;
       } else if (ld.valid) {  // diagnostic: walk the cursor without filling
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
     }
 #undef DX_NTP_FILL
 #undef DX_NTP_ROWS
-    if (stamps && lane == 0) {  // loader stamps behind the consumers': total, vmcnt wait, barrier wait
+    if (kDiag && stamps && lane == 0) {  // loader stamps behind the consumers': total, vmcnt wait, barrier wait
       unsigned long long *o = stamps + static_cast<long long>(gridDim.x) * S::NCONS * 7 +
                               (static_cast<long long>(blockIdx.x) * S::NLOAD + wave) * 3;
       o[0] = __builtin_amdgcn_s_memtime() - l_all; o[1] = l_vm; o[2] = l_bar;
@@ -291,17 +291,17 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
     asm volatile("" ::"v"(bias[j]));
   }
 
-  const unsigned long long t_loop = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
-  const unsigned long long c_loop = stamps ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long t_loop = (kDiag && stamps) ? __builtin_amdgcn_s_memrealtime() : 0;
+  const unsigned long long c_loop = (kDiag && stamps) ? __builtin_amdgcn_s_memtime() : 0;
   unsigned long long c_wait = 0;
   int nsteps = 0, ntiles = 0;
   while (cs.valid) {
-    const unsigned long long c_w0 = (stamps && (p.diag & 2)) ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long c_w0 = (kDiag && stamps && (p.diag & 2)) ? __builtin_amdgcn_s_memtime() : 0;
     __builtin_amdgcn_s_barrier();  // the loaders arrive once this step's fill has landed
     asm volatile("" ::: "memory");
-    if (stamps && (p.diag & 2)) c_wait += __builtin_amdgcn_s_memtime() - c_w0;
+    if (kDiag && stamps && (p.diag & 2)) c_wait += __builtin_amdgcn_s_memtime() - c_w0;
     ++nsteps;
-    if (p.diag & 64) {  // diagnostic: loaders alone (no fragment reads, no MFMAs)
+    if (kDiag && (p.diag & 64)) {  // diagnostic: loaders alone (no fragment reads, no MFMAs)
       slot = slot == S::RING - 1 ? 0 : slot + 1;
       advance<MODE, BM>(cs, p);
       continue;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
     // element (t, r) of column block j: uniform part (tile, wave, t, r) + lane part (hi, l31)
     const long long rowbytes = 4LL * (MODE == 0 ? a.ldc : (a.om.enabled ? a.om.OUT_H * a.om.OUT_W : g.OHW) * a.ldc);
     const long long tile0 = static_cast<long long>(tile * BM + wm * 32 * TM) * rowbytes;  // uniform
-    if (p.diag & 16) {  // diagnostic: no epilogue traffic
+    if (kDiag && (p.diag & 16)) {  // diagnostic: no epilogue traffic
     } else if (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
         for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
     ++ntiles;
   }
-  if (stamps && lane == 0) {  // DX_NTP_DIAG: 100 MHz ticks (entry, loop start, exit), loop cycles, wait cycles, steps, tiles
+  if (kDiag && stamps && lane == 0) {  // DX_NTP_DIAG: 100 MHz ticks (entry, loop start, exit), loop cycles, wait cycles, steps, tiles
     unsigned long long *o = stamps + (static_cast<long long>(blockIdx.x) * S::NCONS + wave) * 7;
     o[0] = t_entry; o[1] = t_loop; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = __builtin_amdgcn_s_memtime() - c_loop;
     o[4] = c_wait; o[5] = nsteps; o[6] = ntiles;
@@ -447,9 +447,13 @@ bool ntp_small_on() {  // DX_NTP_SMALL=0: rollout-sized forward stages on the la
   return v != 0;
 }
 
-int ntp_workgroups(int per_cu) {  // DX_NTP_NWG: resident workgroups (default: every CU full)
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NTP_NWG"); v = e ? atoi(e) : 0; }
+int ntp_workgroups(int per_cu) {  // every CU full (diag build: DX_NTP_NWG forces a count)
+  int v = 0;
+#if DX_DIAG
+  static int forced = -1;
+  if (forced < 0) { const char *e = getenv("DX_NTP_NWG"); forced = e ? atoi(e) : 0; }
+  v = forced;
+#endif
   const int n = v > 0 ? v : 256 * per_cu;
   return n < 8 ? 8 : n / 8 * 8;
 }
@@ -462,13 +466,18 @@ int launch_as(const NtpArgs &p, hipStream_t stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES));
     configured = true;
   }
-  static const int diag = getenv("DX_NTP_DIAG") ? atoi(getenv("DX_NTP_DIAG")) : 0;
   const int grid = ntp_workgroups(S::WGS);
+#if DX_DIAG
+  static const int diag = getenv("DX_NTP_DIAG") ? atoi(getenv("DX_NTP_DIAG")) : 0;
+#else
+  constexpr int diag = 0;
+#endif
   if (!diag) {
     hipLaunchKernelGGL((ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TM, S::TN, S::RING, S::NLOAD, S::WGS>), dim3(grid), dim3(S::THREADS), S::LDS_BYTES, stream, p, nullptr);
     DX_LAUNCH_CHECK();
     return DX_OK;
   }
+#if DX_DIAG
   // diagnostic: in-kernel stamps, summarised on stderr (synchronous; never on the product path)
   NtpArgs pd = p;
   pd.diag = diag;
@@ -505,6 +514,7 @@ int launch_as(const NtpArgs &p, hipStream_t stream) {
           100 * med(wfrac));
   if (!lvm.empty())
     fprintf(stderr, "        loaders: %.1f %% of their time waiting for a fill to land, %.1f %% at the barrier\n", 100 * med(lvm), 100 * med(lbar));
+#endif
   return DX_OK;
 }
 
@@ -606,7 +616,9 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
 int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, const float *bias, float *out, int M,
                     int N, int K, hipStream_t stream) {
   if (!ntp_on() || N % ShapeS::BN || K % kBK || lda < K || lda % 4 || M % ShapeS::BM || M / ShapeS::BM < 8 ||
-      1LL * (M / ShapeS::BM) * (N / ShapeS::BN) < ntp_min_tiles() || 4LL * M * N >= (1LL << 32) || (mask != nullptr) == (bias != nullptr))
+      1LL * (M / ShapeS::BM) * (N / ShapeS::BN) < ntp_min_tiles() || (mask != nullptr) == (bias != nullptr) ||
+      // 32-bit per-lane byte offsets: rows of A ((tile * BM + R) * lda * 4) and of out / mask
+      4LL * M * N >= (1LL << 32) || 4LL * M * lda >= (1LL << 32))
     return DX_ENOSUP;
   DX_REQUIRE(A && W && out && aligned(A, 16) && aligned(W, 16), "ntp_rows: bad operands");
   NtpArgs p;

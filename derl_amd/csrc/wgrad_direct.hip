@@ -176,7 +176,7 @@ __device__ __forceinline__ void conv_wgrad_direct_body(const WgradDirectArgs &a,
     // the table), and every wave is done reading the other buffer, which the next copy reuses
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (img + static_cast<int>(gridDim.x) < a.B && !(a.diag & 1)) DX_WD_COPY(img + gridDim.x, smem + (cur ^ 1) * L::BUF)
+    if (img + static_cast<int>(gridDim.x) < a.B && !(kDiag && (a.diag & 1))) DX_WD_COPY(img + gridDim.x, smem + (cur ^ 1) * L::BUF)
     // bias gradient = column sums of the output gradient: thread (oc = lane, rows wave + NW t)
     const float *Gs = smem + cur * L::BUF + XN;
     for (int r = wave; r < OHW; r += NW) bias_acc += Gs[r * OC + lane];
@@ -203,7 +203,7 @@ __device__ __forceinline__ void conv_wgrad_direct_body(const WgradDirectArgs &a,
   // accumulators -> this workgroup's slab [oc][tap][ic]
   constexpr int K = TAPS * IC;
   float *slab = a.slab + static_cast<long long>(blockIdx.x) * OC * K;
-  if ((a.diag & 2) && acc[0][0] != 12345.678f) return;
+  if (kDiag && (a.diag & 2) && acc[0][0] != 12345.678f) return;
   // tile (r, j), column n = tap T[n / LPT], channel 4 (n % LPT) + j: the four tiles of a read
   // hold four consecutive channels -> one 16-byte store per accumulator register
 #pragma unroll
@@ -283,17 +283,23 @@ bool wgrad_direct_supported(int IH, int IW, int IC, int OH, int OW, int OC, int 
 // Workgroups (= slabs) of a launch.  conv2: two 4-wave workgroups per CU; below 2,048 images one per
 // CU (four images each at 1,024): the same kernel time and half the slabs for the finalize pass.
 int wgrad_direct_workgroups(int stage, long long batch) {
+#if DX_DIAG
   static int forced = -1;  // DX_WD_NWG: timing experiments
   if (forced < 0) { const char *e = getenv("DX_WD_NWG"); forced = e ? atoi(e) : 0; }
   if (forced > 0 && stage == ST_CONV2_WGRAD) return forced;
+#endif
   return stage == ST_CONV1_WGRAD || batch < 2048 ? 256 : 512;
 }
 
 int launch_wgrad_direct(const WgradDirectArgs &a_in, int stage, int nwg, hipStream_t stream) {
   WgradDirectArgs a = a_in;
+#if DX_DIAG
   static int diag = -1;
   if (diag < 0) { const char *e = getenv("DX_WD_DIAG"); diag = e ? atoi(e) : 0; }
   a.diag = diag;
+#else
+  a.diag = 0;
+#endif
   DX_REQUIRE(a.x && a.g && a.slab && a.bias_slab && a.B > 0 && nwg > 0 && nwg <= a.B,
              "wgrad_direct: bad arguments (B=%d, workgroups=%d)", a.B, nwg);
   DX_REQUIRE(aligned(a.x, 16) && aligned(a.g, 16), "wgrad_direct: activations must be 16-byte aligned");

@@ -81,11 +81,11 @@ __global__ __launch_bounds__(512, 2) void fc_wgrad_kernel(const FcWgradArgs a) {
 
   // diag bit 3: in-kernel stamps around the stage loop (shader cycles and 100 MHz ticks), written
   // INSTEAD of the result: [workgroup][wave] -> {loop cycles, loop ticks, stages, kernel-entry tick}
-  const unsigned long long t_entry = (a.diag & 8) ? __builtin_amdgcn_s_memrealtime() : 0;
+  const unsigned long long t_entry = (kDiag && (a.diag & 8)) ? __builtin_amdgcn_s_memrealtime() : 0;
   if (sbeg < send) DX_FC_ISSUE(sbeg, 0)
   if (sbeg + 1 < send) DX_FC_ISSUE(sbeg + 1, 1)
-  const unsigned long long c0 = (a.diag & 8) ? __builtin_amdgcn_s_memtime() : 0;
-  const unsigned long long r0 = (a.diag & 8) ? __builtin_amdgcn_s_memrealtime() : 0;
+  const unsigned long long c0 = (kDiag && (a.diag & 8)) ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long r0 = (kDiag && (a.diag & 8)) ? __builtin_amdgcn_s_memrealtime() : 0;
   int slot = 0;
   for (int s = sbeg; s < send; ++s) {
     // stage s has landed for this wave (the pieces of stage s + 1 may still be in flight); after
@@ -93,9 +93,9 @@ __global__ __launch_bounds__(512, 2) void fc_wgrad_kernel(const FcWgradArgs a) {
     if (s + 1 < send) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerWave) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // not __syncthreads(): its fence makes the compiler wait vmcnt(0), i.e. for the stage in flight
-    if (!(a.diag & 2)) __builtin_amdgcn_s_barrier();
+    if (!(kDiag && (a.diag & 2))) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (s + 2 < send && !(a.diag & 1)) {
+    if (s + 2 < send && !(kDiag && (a.diag & 1))) {
       const int nslot = slot >= 1 ? slot - 1 : slot + 2;
       DX_FC_ISSUE(s + 2, nslot)
     }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void fc_wgrad_kernel(const FcWgradArgs a) {
 
   // tile (i, j): MFMA row r' = (r & 3) + 8 (r >> 2) + 4 hi is column n = 128 wn + 4 r' + i,
   // MFMA column l31 is k = k0 + 64 wk + 2 l31 + j
-  if (a.diag & 8) {
+  if (kDiag && (a.diag & 8)) {
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
       unsigned long long *o = reinterpret_cast<unsigned long long *>(a.slab) + (static_cast<long long>(blockIdx.x) * 8 + wave) * 4;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void fc_wgrad_kernel(const FcWgradArgs a) {
   }
   const int kk = k0 + 64 * wk + 2 * l31;
   if (k0 + 64 * wk >= a.K) return;  // wave-uniform: the empty half of the last k block
-  if ((a.diag & 4) && acc[0][0][0] != 12345.678f) return;
+  if (kDiag && (a.diag & 4) && acc[0][0][0] != 12345.678f) return;
   float *slab = a.slab + static_cast<long long>(z) * kN * a.K + kk;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -191,9 +191,13 @@ int launch_fc_wgrad(const FcWgradArgs &a_in, hipStream_t stream) {
              "fc_wgrad: unsupported problem M=%d K=%d slices=%d", a.M, a.K, a.msplit);
   DX_REQUIRE(aligned(a.G, 16) && aligned(a.A, 16) && aligned(a.slab, 8), "fc_wgrad: misaligned pointer");
   a.gk = cdiv(a.K, kBK);
+#if DX_DIAG
   static int diag = -1;
   if (diag < 0) { const char *e = getenv("DX_FC_DIAG"); diag = e ? atoi(e) : 0; }
   a.diag = diag;
+#else
+  a.diag = 0;
+#endif
   constexpr int lds = kStages * kStageFloats * 4;
   static bool configured = false;
   if (!configured) {

@@ -135,8 +135,8 @@ class MlpEngine:
     self.reserve(mbsize)
     updates = context.num_minibatches
     dev = self.device
-    context.normalized = torch.empty(samples, dtype=f32, device=dev)
-    context.norm_eps = loss["normalize_eps"]
+    normalize = context.norm_eps is not None  # NormalizeAdvantages opted in with its epsilon
+    context.normalized = torch.empty(samples, dtype=f32, device=dev) if normalize else None
     context.losses = torch.empty((updates, 8), dtype=f32, device=dev)
     if getattr(self, "_epoch_scratch", None) is None:
       self._epoch_scratch = torch.empty(3, dtype=torch.float64, device=dev)
@@ -151,12 +151,13 @@ class MlpEngine:
     e.old_log_prob = old_lp.data_ptr() if ppo else None
     e.old_values = old_v.data_ptr() if ppo else None
     e.advantages, e.value_targets = adv.data_ptr(), vt.data_ptr()
-    e.normalize, e.norm_eps = 1, float(loss["normalize_eps"])
+    e.normalize, e.norm_eps = int(normalize), float(context.norm_eps) if normalize else 0.0
     cliprange = loss.get("cliprange")
     e.cliprange = float(cliprange) if cliprange is not None else -1.0
     e.value_loss_coef, e.entropy_coef = float(loss["value_loss_coef"]), float(loss["entropy_coef"])
     e.global_batch = 0
-    e.adv_normalized, e.stats = context.normalized.data_ptr(), self._epoch_scratch.data_ptr()
+    e.adv_normalized = context.normalized.data_ptr() if normalize else None
+    e.stats = self._epoch_scratch.data_ptr()
     e.exp_avg, e.exp_avg_sq = optimizer.exp_avg.data_ptr(), optimizer.exp_avg_sq.data_ptr()
     e.sumsq_partials, e.npartials = optimizer.partials.data_ptr(), optimizer.partials.numel()
     e.loss_partials, e.loss_partials_capacity = self._epoch_partials.data_ptr(), int(capacity)

@@ -27,7 +27,14 @@ class EpochContext:
     self.num_minibatches = -(-sample_size // mbsize)
     self.consumed = False
     self.losses = None
-    self.normalized = None
+    # Written by NormalizeAdvantages when it normalises the epoch's FIRST minibatch: its epsilon
+    # and the tensor it produced.  That is how the transform opts in to the native epoch: the
+    # trainer normalises the remaining minibatches the same way only if these are set and the
+    # minibatch it is handed still carries that very tensor; a pipeline without the transform
+    # trains natively on the raw advantages, anything else goes update by update.
+    self.norm_eps = None
+    self.norm_first = None
+    self.normalized = None  # every minibatch's normalised advantages, filled by the native epoch
 
 
 class TransformInteractions(RunnerWrapper):
@@ -77,7 +84,9 @@ class IterateWithMinibatches(RunnerWrapper):
     # minibatch's "state": work over ALL minibatches of a rollout once their order is known
     # (NormalizeAdvantages.prepare: one all-reduce per rollout instead of one per minibatch)
     self.prepare = prepare
-    self._pinned, self._pinned_event = None, None
+    # two pinned staging buffers used in turn: the upload of rollout n + 1's permutations never
+    # waits for the GPU to have read rollout n's (one buffer capped the host's run-ahead at one rollout)
+    self._pinned, self._pinned_event, self._pinned_turn = [None, None], [None, None], 0
 
   @staticmethod
   def _gather_epoch(interactions, order_dev):
@@ -125,14 +134,16 @@ class IterateWithMinibatches(RunnerWrapper):
     orders_dev = None
     if device is not None:
       shape = (self.num_epochs, sample_size)
-      if self._pinned is None or tuple(self._pinned.shape) != shape:
-        self._pinned = torch.empty(shape, dtype=torch.int32).pin_memory()
-      elif self._pinned_event is not None:
-        self._pinned_event.synchronize()  # the previous upload has read the staging buffer
-      np.stack(orders, out=self._pinned.numpy(), casting="unsafe")
-      orders_dev = self._pinned.to(device, non_blocking=True)
-      self._pinned_event = torch.cuda.Event()
-      self._pinned_event.record(torch.cuda.current_stream(device))
+      turn = self._pinned_turn
+      self._pinned_turn = turn ^ 1
+      if self._pinned[turn] is None or tuple(self._pinned[turn].shape) != shape:
+        self._pinned[turn] = torch.empty(shape, dtype=torch.int32).pin_memory()
+      elif self._pinned_event[turn] is not None:
+        self._pinned_event[turn].synchronize()  # the upload before last has read this buffer
+      np.stack(orders, out=self._pinned[turn].numpy(), casting="unsafe")
+      orders_dev = self._pinned[turn].to(device, non_blocking=True)
+      self._pinned_event[turn] = torch.cuda.Event()
+      self._pinned_event[turn].record(torch.cuda.current_stream(device))
     return sample_size, device, orders, orders_dev
 
   def _prefetch_allowed(self):

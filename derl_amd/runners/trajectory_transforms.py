@@ -123,6 +123,8 @@ class NormalizeAdvantages:
       start = k * context.mbsize
       trajectory["advantages"] = context.normalized[start:start + flat.numel()].reshape(advantages.shape)
       return
+    first_of_epoch = (epoch is not None and epoch[1] == 0 and not epoch[0].consumed
+                      and distributed.world_size() == 1)
     ready = state.get(self.STATE_KEY) if isinstance(state, dict) else None
     if ready is not None:
       out = ops.adv_normalize(flat, self.epsilon, stats=ready, stats_ready=True)
@@ -133,6 +135,8 @@ class NormalizeAdvantages:
     else:
       out = ops.adv_normalize(flat, self.epsilon)
     trajectory["advantages"] = out.reshape(advantages.shape)
+    if first_of_epoch:  # opt in to the native epoch (EpochContext): same rule, this epsilon
+      epoch[0].norm_eps, epoch[0].norm_first = self.epsilon, trajectory["advantages"]
 
 
 class Take:

@@ -34,7 +34,7 @@ extern "C" {
 #define DX_ENOSUP (-3)   /* configuration not supported by the compiled kernels     */
 #define DX_EWS (-4)      /* workspace too small                                     */
 
-#define DX_ABI_VERSION 1
+#define DX_ABI_VERSION 2
 
 int dx_abi_version(void);
 const char *dx_last_error(void);

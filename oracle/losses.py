@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from .distributions import categorical_log_prob_entropy, diag_normal_log_prob_entropy
-from .models import nature_cnn_forward, mujoco_forward
+from .models import mlp_forward, nature_cnn_forward, mujoco_forward
 
 
 def ppo_loss_terms(log_prob, entropy, values, old_log_prob, advantages, old_values,
@@ -138,6 +138,15 @@ def _cast_data(data, dtype):
 def _forward_dist(params, data, kind, relu_masks=None):
   if kind == "cnn":
     logits, values = nature_cnn_forward(params, data["observations"], relu_masks)
+    log_prob, entropy, _ = categorical_log_prob_entropy(logits, data["actions"])
+  elif kind == "mlp_cat":
+    # vector observations with Discrete actions (BASELINE config 1; not in the reference, whose
+    # make_model cannot build it): the reference's MLP (models.py:224-237) once per output and its
+    # categorical distribution math (policies.py:64,76-77)
+    weight = params["module_list.0.0.weight"]
+    x = torch.as_tensor(np.asarray(data["observations"])).to(weight.dtype)
+    logits = mlp_forward(params, "module_list.0", x)
+    values = mlp_forward(params, "module_list.1", x)
     log_prob, entropy, _ = categorical_log_prob_entropy(logits, data["actions"])
   else:
     mean, std, values = mujoco_forward(params, data["observations"])

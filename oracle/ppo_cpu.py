@@ -125,9 +125,11 @@ class CpuPPO:
     self.update(self.rollout())
 
 
-def available_cores():
+def available_cores(capped=True):
   """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota
-  (a GPU box shows every host core but grants a share of them)."""
+  (a GPU box shows every host core but grants a share of them) and -- ``capped`` -- by
+  DERL_AMD_CPU_THREADS (default 16: torch-CPU's conv / GEMM kernels at these shapes stop
+  scaling there; the cap is stated in the baseline's ``sample`` string)."""
   import os
   cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
   for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
@@ -145,6 +147,8 @@ def available_cores():
           cores = min(cores, max(1, quota // period))
     except (OSError, ValueError, IndexError):
       continue
+  if not capped:
+    return cores
   return min(cores, int(os.environ.get("DERL_AMD_CPU_THREADS", "16")))
 
 
@@ -156,6 +160,9 @@ def time_cpu_baseline(nenvs=256, nsteps=128, iterations=3, warmup=1, threads=Non
   (never below 1) so that it fits, and the returned ``sample`` string says what was run.
   Returns dict(value env-steps/s, seconds, cores, sample, iterations, warmup)."""
   threads = threads or available_cores()
+  granted = available_cores(capped=False)
+  cap_note = (f" (capped: the box grants {granted} cores, DERL_AMD_CPU_THREADS lifts the cap)"
+              if granted > threads else f" (all {granted} cores granted to this process)")
   ppo = CpuPPO(nenvs=nenvs, nsteps=nsteps, threads=threads, **kwargs)
   warm_seconds = 0.0
   for _ in range(warmup):
@@ -173,4 +180,4 @@ def time_cpu_baseline(nenvs=256, nsteps=128, iterations=3, warmup=1, threads=Non
               warmup=warmup,
               sample=f"{warmup} warm-up + {iterations} timed PPO iteration(s) of nenvs={nenvs} x "
                      f"nsteps={nsteps} (3 epochs x 4 minibatches of {nenvs * nsteps // 4}), NatureCNN, "
-                     f"synthetic frames, torch-CPU fp32 on {threads} threads")
+                     f"synthetic frames, torch-CPU fp32 on {threads} threads{cap_note}")

@@ -87,6 +87,24 @@ def test_diagnostics_live_in_their_own_header_and_library(lib):
     assert hasattr(diag, name), f"{name} declared in derl_amd_diag.h but not exported"
 
 
+WRONG_RESULT_SWITCHES = ("DX_NTP_DIAG", "DX_NT_DIAG", "DX_WD_DIAG", "DX_FC_DIAG", "DX_NTP_NWG", "DX_WD_NWG")
+
+
+def test_bisecting_switches_are_compiled_out_of_the_product_library(lib):
+  """The in-kernel stamps and bisecting switches of the ring / weight-gradient kernels (some
+  compute wrong results on purpose) exist only in the -DDX_DIAG=1 flavour, libderl_amd_diag.so:
+  the product library never reads those variables -- their names are not even in its image."""
+  from derl_amd import build
+  if not os.path.exists(build.HIPCC):
+    pytest.skip("no hipcc on this box: the diag flavour cannot be built")
+  image = open(lib.LIB_PATH, "rb").read()
+  for name in WRONG_RESULT_SWITCHES:
+    assert name.encode() not in image, f"{name} is read by the product library"
+  diag = open(build.build_diag_library(), "rb").read()
+  for name in WRONG_RESULT_SWITCHES:
+    assert name.encode() in diag, f"{name} is gone from the diagnostic flavour too"
+
+
 def test_host_layer_under_address_sanitizer():
   """The sanitizer build of the shim: every product source compiled
   host-only with -fsanitize=address, driven through the validation / planning layer of every

@@ -1,0 +1,192 @@
+"""The native-epoch path of the MLP policies (Trainer._step_epoch -> dx_mlp_ppo_epoch): every
+minibatch update of an epoch enqueued from ONE C call, against the per-update path
+(Trainer.native_epochs = False) and against the CPU oracle stepping the same minibatches
+(derl/alg/common.py:66-78 inside derl/runners/onpolicy.py:44-62).
+
+PeriodicSummaries arms recording on every rollout and a recording step never takes the native
+path, so the tests switch recording off after each ``next()`` -- what bench.py and
+tools/bench_configs.py do -- and count the native calls to prove the path was entered."""
+import numpy as np
+import numpy.testing as nt
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+class DeviceVectorEnv:
+  """Device-resident batched env with vector observations and Discrete actions (the contract of
+  derl/env/env_batch.py:35-134 as the device runner uses it): counter-seeded torch generator."""
+  host_rng_free = True
+
+  def __init__(self, nenvs, obs_dim, num_actions, seed):
+    from derl_amd.env.spaces import Box, Discrete
+    self.nenvs, self.unwrapped = nenvs, self
+    self.device = torch.device("cuda")
+    self.observation_space = Box(-10., 10., (obs_dim,), np.float32)
+    self.action_space = Discrete(num_actions)
+    self.generator = torch.Generator(device=self.device)
+    self.generator.manual_seed(seed)
+    self.seed = seed
+
+  def reset(self, out=None):
+    shape = (self.nenvs,) + self.observation_space.shape
+    out = torch.empty(shape, dtype=torch.float32, device=self.device) if out is None else out
+    return out.normal_(generator=self.generator)
+
+  def step(self, actions, out=None, rewards_out=None, resets_out=None):
+    obs = self.reset(out)
+    rewards = (actions.to(torch.float32) - 1.0) * torch.randn(self.nenvs, device=self.device,
+                                                            generator=self.generator)
+    resets = torch.rand(self.nenvs, device=self.device, generator=self.generator) < 0.05
+    return obs, rewards_out.copy_(rewards), resets_out.copy_(resets), None
+
+
+def make_alg(kind, native, nenvs, horizon, epochs, nmb):
+  import derl_amd as derl
+  torch.manual_seed(0)
+  np.random.seed(11)
+  if kind == "gaussian":
+    env = derl.env.make("HalfCheetah-v3", nenvs=nenvs, seed=3)
+  else:
+    env = DeviceVectorEnv(nenvs, 11, 5, seed=3)
+  kwargs = derl.PPOFactory.get_kwargs("mujoco")
+  kwargs.update(nenvs=nenvs, num_runner_steps=horizon, num_epochs=epochs, num_minibatches=nmb,
+                num_train_steps=nenvs * horizon * 4, entropy_coef=0.01)
+  alg = derl.PPOFactory(**kwargs).make(env)
+  alg.trainer.native_epochs = native
+  calls = []
+  inner = alg.trainer.optimizer.native_epoch
+
+  def counted(loss_fn, context):
+    calls.append(context.num_minibatches)
+    return inner(loss_fn, context)
+
+  alg.trainer.optimizer.native_epoch = counted
+  return alg, calls
+
+
+def run(kind, native, nenvs, horizon, epochs, nmb, rollouts, keep_host=False):
+  import derl_amd as derl
+  alg, calls = make_alg(kind, native, nenvs, horizon, epochs, nmb)
+  per_epoch = -(-(nenvs * horizon) // ((nenvs * horizon) // nmb))
+  start = {k: v.detach().clone() for k, v in alg.model.state_dict().items()}
+  it = alg.runner.run()
+  losses, advantages, terms, host, step_counts = [], [], [], [], []
+  for i in range(rollouts * epochs * per_epoch):
+    data = next(it)
+    derl.summary.stop_recording()
+    advantages.append(data["advantages"].clone())
+    if i == per_epoch:
+      after_first_epoch = alg.model.engine.params.clone()
+    if keep_host and i < per_epoch:
+      host.append({k: v.cpu().numpy() for k, v in data.items() if isinstance(v, torch.Tensor)})
+      step_counts.append(alg.runner.step_count)
+    losses.append(alg.step(data).clone())
+    terms.append(alg.loss_fn.last_terms.clone())
+  opt = alg.trainer.optimizer
+  return dict(alg=alg, calls=calls, start=start, losses=torch.stack(losses), advantages=advantages,
+              terms=torch.stack(terms), params=alg.model.engine.params.clone(), m=opt.exp_avg.clone(),
+              v=opt.exp_avg_sq.clone(), steps=opt.step_count, host=host, step_counts=step_counts,
+              per_epoch=per_epoch, after_first_epoch=after_first_epoch)
+
+
+# 33 envs x 16 steps = 528 samples in 5 minibatches of 105 + a ragged sixth of 3
+@pytest.mark.parametrize("kind", ["gaussian", "categorical"])
+def test_native_epoch_equals_per_update_path_and_oracle(kind):
+  nenvs, horizon, epochs, nmb, rollouts = 33, 16, 2, 5, 2
+  fast = run(kind, True, nenvs, horizon, epochs, nmb, rollouts, keep_host=True)
+  slow = run(kind, False, nenvs, horizon, epochs, nmb, rollouts)
+  assert fast["per_epoch"] == 6
+  assert fast["calls"] == [6] * (rollouts * epochs), "the native epoch path was not entered"
+  assert slow["calls"] == []
+  assert fast["steps"] == slow["steps"] == rollouts * epochs * 6
+  # same launches on the same buffers in the same order: bit-identical
+  assert torch.equal(fast["losses"], slow["losses"])
+  assert torch.equal(fast["terms"], slow["terms"])
+  for a, b in zip(fast["advantages"], slow["advantages"]):  # incl. context.normalized slices
+    assert torch.equal(a, b)
+  assert torch.equal(fast["params"], slow["params"])
+  assert torch.equal(fast["m"], slow["m"]) and torch.equal(fast["v"], slow["v"])
+  # the oracle on the first epoch's minibatches (incl. the ragged one), from the same start
+  alg = fast["alg"]
+  names = [k for k, _ in alg.model.named_parameters()]
+  params = {k: v.cpu().numpy().astype(np.float32).copy() for k, v in fast["start"].items()}
+  state = {k: dict(m=np.zeros_like(v), v=np.zeros_like(v)) for k, v in params.items()}
+  okind = "mlp" if kind == "gaussian" else "mlp_cat"
+  for i, host in enumerate(fast["host"]):
+    assert host["actions"].shape[0] == (105 if i < 5 else 3)
+    terms, grads = oracle.ppo_loss_and_grads(params, host, okind, 0.2, 0.25, 0.01)
+    nt.assert_allclose(fast["losses"][i].item(), terms["loss"], rtol=1e-4, atol=1e-5, err_msg=f"minibatch {i}")
+    clipped, _ = oracle.clip_grad_norm([grads[k] for k in names], 0.5)
+    lr = oracle.linear_anneal(3e-4, nenvs * horizon * 4, fast["step_counts"][i])
+    for k, g in zip(names, clipped):
+      params[k], state[k]["m"], state[k]["v"] = oracle.adam_step(
+          params[k], g, state[k]["m"], state[k]["v"], i + 1, lr, eps=1e-5)
+  got = alg.model.engine.named_views(fast["after_first_epoch"])
+  for k in names:  # six Adam steps of <= lr each
+    nt.assert_allclose(got[k].cpu().numpy(), params[k], rtol=0, atol=5e-6, err_msg=k)
+
+
+def test_native_epoch_normalises_only_when_the_transform_opted_in():
+  """A pipeline WITHOUT NormalizeAdvantages (or with another epsilon) must train on exactly what
+  its per-update path sees: the native epoch takes its normalisation from the transform's own
+  record in the EpochContext, not from a constant."""
+  import derl_amd as derl
+  from derl_amd.runners.onpolicy import IterateWithMinibatches, TransformInteractions
+  from derl_amd.runners.trajectory_transforms import NormalizeAdvantages
+
+  def rewire(alg, eps):
+    # ppo_runner_wrap's chain: TransformInteractions([normalize]) <- IterateWithMinibatches <- ...
+    iterate = alg.runner.runner
+    assert isinstance(iterate, IterateWithMinibatches)
+    if eps is None:
+      alg.runner = iterate
+    else:
+      normalize = NormalizeAdvantages(epsilon=eps)
+      iterate.prepare = normalize.prepare
+      alg.runner = TransformInteractions(iterate, [normalize])
+    return alg
+
+  for eps in (None, 0.25):
+    results = []
+    for native in (True, False):
+      alg, calls = make_alg("gaussian", native, 32, 16, 2, 4)
+      rewire(alg, eps)
+      it = alg.runner.run()
+      seen = []
+      for _ in range(8):
+        data = next(it)
+        derl.summary.stop_recording()
+        seen.append(data["advantages"].clone())
+        alg.step(data)
+      results.append((alg.model.engine.params.clone(), seen, list(calls)))
+    assert results[0][2] == [4, 4] and results[1][2] == []
+    assert torch.equal(results[0][0], results[1][0]), f"eps={eps}: native epoch trained on other data"
+    for a, b in zip(results[0][1], results[1][1]):
+      assert torch.equal(a, b)
+
+
+def test_native_epoch_declines_when_a_transform_edited_the_minibatch():
+  """A transform that replaces ``log_prob`` (or the advantages) after NormalizeAdvantages ran makes
+  the minibatch differ from the epoch's arrays: the trainer must go update by update."""
+  import derl_amd as derl
+  from derl_amd.runners.onpolicy import TransformInteractions
+
+  def halve(key):
+    def transform(trajectory):
+      trajectory[key] = trajectory[key] * 0.5
+    return transform
+
+  for key in ("log_prob", "advantages"):
+    alg, calls = make_alg("gaussian", True, 32, 16, 1, 4)
+    alg.runner = TransformInteractions(alg.runner, [halve(key)])
+    it = alg.runner.run()
+    for _ in range(4):
+      data = next(it)
+      derl.summary.stop_recording()
+      alg.step(data)
+    assert calls == [], f"native epoch ran although a transform replaced '{key}'"
+    assert alg.trainer.optimizer.step_count == 4

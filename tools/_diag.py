@@ -18,7 +18,6 @@ _handle = None
 def load():
   global _handle
   if _handle is None:
-    _lib.load()  # the diag library links against libderl_amd.so
     if not os.path.exists(build.DIAG_LIB):
       build.build_diag_library()
     _handle = ctypes.CDLL(build.DIAG_LIB)

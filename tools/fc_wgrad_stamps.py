@@ -1,6 +1,6 @@
 """In-kernel timing of the fc wgrad stage loop (DX_FC_DIAG bit 3): cycles per 16-row stage per
 wave, the clock the chip holds inside the loop, and how the workgroups' start times spread.
-usage: DX_FC_DIAG=8 python tools/fc_wgrad_stamps.py   (add 1 / 2 to drop the copies / barrier)"""
+usage: DERL_AMD_LIBRARY=diag DX_FC_DIAG=8 python tools/fc_wgrad_stamps.py   (add 1 / 2 to drop the copies / barrier)"""
 import ctypes
 import os
 import sys
@@ -13,6 +13,7 @@ from derl_amd import _lib  # noqa: E402
 from derl_amd.cnn_engine import CnnEngine  # noqa: E402
 
 assert int(os.environ.get("DX_FC_DIAG", "0")) & 8, "set DX_FC_DIAG=8 (+1, +2)"
+assert os.environ.get("DERL_AMD_LIBRARY") == "diag", "the switches exist in the diag flavour only: DERL_AMD_LIBRARY=diag"
 batch = 8192
 dev = torch.device("cuda:0")
 eng = CnnEngine(4, max_batch=batch, device=dev)
