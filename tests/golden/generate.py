@@ -202,8 +202,12 @@ def gen_steps(only=None):
       # rollout boundary between step 1 and 2 so the LR changes once
       if step == 2:
         alg.runner.step_count += 4096
-      if "min_relu_margin" in cfg:
+      if cfg["kind"] == "cnn":
+        # how close the reference's OWN run comes to a ReLU boundary at this step: below ~3e-6 the
+        # side a unit falls on depends on float32 summation order, and from that step on another
+        # implementation may only be compared through a same-start oracle (tests/test_ppo_e2e_gpu.py)
         out[f"relu_margin.{step}"] = np.float64(relu_margin(model, mb["observations"]))
+      if "min_relu_margin" in cfg:
         assert out[f"relu_margin.{step}"] >= cfg["min_relu_margin"], (name, step, out[f"relu_margin.{step}"])
       losses.append(alg.step(data).item())
       out[f"lr.{step}"] = np.float32(lr.get_tensor().item())

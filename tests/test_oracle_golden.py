@@ -131,9 +131,28 @@ def test_training_steps_match_reference(name):
     else:
       terms, grads = oracle.a2c_loss_and_grads(
           params, data, cfg["kind"], cfg["value_loss_coef"], cfg["entropy_coef"])
-    loose = name == "a2c_step_cnn" and step > 0  # RMSprop's first step is a sign step
-    nt.assert_allclose(terms["loss"], g["losses"][step], rtol=2e-3 if loose else 1e-5,
-                       atol=1e-5)
+    # A float32 restatement with another summation order can follow the reference's trajectory only
+    # while the reference's own run stays clear of every ReLU boundary: generate.py records the
+    # smallest |conv pre-activation| / layer scale of every step (relu_margin.<step>).  Where it
+    # was below 3e-6 at an EARLIER step, a unit's side was decided by rounding and (with RMSprop's
+    # first normalised steps of ~10 lr per weight) parameters may sit 1e-4 off: the bounds are then
+    # the wider ones -- keyed on the fixture's record, not on the case's name.  The tight per-step
+    # statement for such cases is the same-start float64 comparison of the GPU suite.
+    near_boundary = cfg["kind"] == "cnn" and step > 0 and \
+        min(float(g[f"relu_margin.{s}"]) for s in range(step)) < 3e-6
+
+    def tight_else_wide(check):
+      """check(loose) with the tight bounds; the wide ones only if the fixture says the reference
+      passed a ReLU boundary within rounding before this step."""
+      try:
+        check(False)
+      except AssertionError:
+        if not near_boundary:
+          raise
+        check(True)
+
+    tight_else_wide(lambda loose: nt.assert_allclose(terms["loss"], g["losses"][step],
+                                                     rtol=2e-3 if loose else 1e-5, atol=1e-5))
     if step == 0:
       nt.assert_allclose(terms["loss"], g["loss0"], rtol=1e-6, atol=1e-6)
       for k in names:
@@ -152,8 +171,8 @@ def test_training_steps_match_reference(name):
         params[k], state[k]["v"] = oracle.rmsprop_step(
             params[k], gk, state[k]["v"], lr, cfg["optimizer_alpha"],
             cfg["optimizer_epsilon"])
-      _check_summary(params[k], g, f"param{step}.{k}", rtol=1e-5,
-                     atol=2e-4 if loose else 2e-6)
+      tight_else_wide(lambda loose, k=k: _check_summary(params[k], g, f"param{step}.{k}", rtol=1e-5,
+                                                        atol=2e-4 if loose else 2e-6))
 
 
 def test_closed_form_head_grads_match_autograd():
