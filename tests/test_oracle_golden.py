@@ -134,16 +134,16 @@ def test_training_steps_match_reference(name):
     # A float32 restatement with another summation order can follow the reference's trajectory only
     # while the reference's own run stays clear of every ReLU boundary: generate.py records the
     # smallest |conv pre-activation| / layer scale of every step (relu_margin.<step>).  Where it
-    # was below 3e-6 at an EARLIER step, a unit's side was decided by rounding and (with RMSprop's
+    # was below 3e-6 at or before a step, a unit's side was decided by rounding and (with RMSprop's
     # first normalised steps of ~10 lr per weight) parameters may sit 1e-4 off: the bounds are then
     # the wider ones -- keyed on the fixture's record, not on the case's name.  The tight per-step
     # statement for such cases is the same-start float64 comparison of the GPU suite.
-    near_boundary = cfg["kind"] == "cnn" and step > 0 and \
-        min(float(g[f"relu_margin.{s}"]) for s in range(step)) < 3e-6
+    near_boundary = cfg["kind"] == "cnn" and \
+        min(float(g[f"relu_margin.{s}"]) for s in range(step + 1)) < 3e-6
 
     def tight_else_wide(check):
       """check(loose) with the tight bounds; the wide ones only if the fixture says the reference
-      passed a ReLU boundary within rounding before this step."""
+      passed a ReLU boundary within rounding at or before this step."""
       try:
         check(False)
       except AssertionError:
