@@ -63,6 +63,15 @@ SIGNATURES = {
     "dx_cnn_act": [P, P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
     "dx_cnn_rollout_synth": [P, P, c_int, c_int, P, P, P, P, P, c_uint64, c_uint64, c_uint64,
                              c_uint64, c_float, c_float, P],
+    "dx_cnn_ppo_epoch": [P, P, P],
+    "dx_comm_unique_id": [P],
+    "dx_comm_init": [P, c_int, c_int],
+    "dx_comm_info": [P, P, P, P],
+    "dx_comm_destroy": [],
+    "dx_allreduce_grads": [P, c_longlong, P],
+    "dx_allreduce_wait": [P],
+    "dx_allreduce_sum_f64": [P, c_longlong, P],
+    "dx_comm_broadcast_f32": [P, c_longlong, c_int, P],
 }
 
 
@@ -166,6 +175,24 @@ class MlpEpoch(ctypes.Structure):
       ("npartials", c_int), ("loss_partials_capacity", c_int), ("loss_partials", c_void_p),
       ("max_grad_norm", c_double), ("lr", c_double), ("beta1", c_double), ("beta2", c_double),
       ("adam_eps", c_double), ("first_step", c_longlong), ("grad_norm_out", c_void_p),
+      ("loss_out", c_void_p), ("grad_norm_stride", c_int), ("reserved0", c_int)]
+
+
+class CnnEpoch(ctypes.Structure):
+  """Mirror of ``dx_cnn_epoch`` (include/derl_amd.h); dx_cnn_ppo_epoch checks the size."""
+  _fields_ = [
+      ("struct_bytes", c_int), ("mbsize", c_int), ("samples", c_longlong),
+      ("obs", c_void_p), ("obs_is_u8", c_int), ("mode", c_int), ("index", c_void_p),
+      ("actions", c_void_p), ("old_log_prob", c_void_p), ("advantages", c_void_p),
+      ("old_values", c_void_p), ("value_targets", c_void_p), ("normalize", c_int),
+      ("norm_eps", c_float), ("stats_ready", c_void_p), ("stats", c_void_p),
+      ("adv_normalized", c_void_p), ("cliprange", c_float), ("value_loss_coef", c_float),
+      ("entropy_coef", c_float), ("world", c_int), ("allreduce", c_int), ("optimizer", c_int),
+      ("npartials", c_int), ("state0", c_void_p), ("state1", c_void_p),
+      ("sumsq_partials", c_void_p), ("loss_partials", c_void_p),
+      ("loss_partials_capacity", c_int), ("grad_norm_stride", c_int),
+      ("max_grad_norm", c_double), ("lr", c_double), ("beta1", c_double), ("beta2", c_double),
+      ("opt_eps", c_double), ("first_step", c_longlong), ("grad_norm_out", c_void_p),
       ("loss_out", c_void_p)]
 
 

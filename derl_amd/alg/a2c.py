@@ -24,6 +24,11 @@ class A2CLoss(ActorCriticDeviceLoss):
     terms, _ = self._evaluate(trajectory, None, self.value_loss_coef, self.entropy_coef)
     return terms[3]
 
+  def epoch_arguments(self):
+    """Hyper-parameters of the fused loss kernels for a native update (Trainer.step)."""
+    return dict(mode=1, cliprange=None, value_loss_coef=self.value_loss_coef,
+                entropy_coef=self.entropy_coef)
+
   def evaluate_native(self, data):
     """(loss scalar on the device, model-backward closure); see PPOLoss.evaluate_native."""
     terms, backward_fn = self._evaluate(data, None, self.value_loss_coef, self.entropy_coef)

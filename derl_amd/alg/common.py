@@ -104,20 +104,35 @@ class Trainer:
   # -- native epochs ------------------------------------------------------------------------
   native_epochs = True  # False: always one host call per update
 
+  def _native_ready(self, alg):
+    """The engine, or None when this trainer / algorithm cannot hand updates to a native call:
+    needs a flat optimizer with ``native_epoch``, the stock ``Alg.loss``, a loss with
+    ``epoch_arguments`` and an engine with ``ppo_epoch``; a sharded run additionally the library's
+    own communicator (the gloo rehearsal mode reduces from Python, update by update)."""
+    if not self.native_epochs:
+      return None
+    engine = getattr(alg.model, "engine", None)
+    if (not hasattr(self.optimizer, "native_epoch") or type(alg).loss is not Alg.loss
+        or not hasattr(engine, "ppo_epoch") or not hasattr(alg.loss_fn, "epoch_arguments")):
+      return None
+    if distributed.sharded() and not (getattr(engine, "native_allreduce", False)
+                                      and distributed.native_comm()):
+      return None
+    return engine
+
   def _epoch_fast_path(self, alg, data):
     """(context, k) when EVERY update of this minibatch's epoch can be (or already was) enqueued
-    from one native call: MLP engine, flat Adam, single process, no summaries being recorded,
-    the minibatch is the untouched slice of the epoch's arrays and its advantages are either the
-    raw slice or what NormalizeAdvantages made of it (the transform records its epsilon in the
-    context: the native epoch normalises with THAT epsilon, or not at all).  A caller that abandons an
-    epoch halfway still gets all of its updates applied -- set ``native_epochs = False`` then."""
-    if not self.native_epochs or summary.should_record() or distributed.world_size() > 1:
+    from one native call: the minibatch is the untouched slice of the epoch's arrays (frames: the
+    epoch's index into the untouched rollout buffer) and its advantages are either the raw slice
+    or what NormalizeAdvantages made of it (the transform records its epsilon in the context: the
+    native epoch normalises with THAT epsilon, or not at all).  A caller that abandons an epoch
+    halfway still gets all of its updates applied -- set ``native_epochs = False`` then."""
+    engine = self._native_ready(alg)
+    if engine is None:
       return None
     state = data.get("state")
     entry = state.get("epoch") if isinstance(state, dict) else None
-    engine = getattr(alg.model, "engine", None)
-    if (entry is None or not hasattr(self.optimizer, "native_epoch") or type(alg).loss is not Alg.loss
-        or not hasattr(engine, "ppo_epoch") or not hasattr(alg.loss_fn, "epoch_arguments")):
+    if entry is None:
       return None
     context, k = entry
     start = k * context.mbsize
@@ -128,11 +143,20 @@ class Trainer:
 
     # still the epoch's own slices?  (a transform that replaced any of them -- or a pipeline whose
     # advantages are neither the raw slice nor NormalizeAdvantages' output -- trains step by step)
-    keys = ["value_targets", "actions", "observations"]
+    keys = ["value_targets", "actions"]
     if getattr(alg.loss_fn, "mode", 0) == 0:
       keys += ["log_prob", "values"]
     for key in keys:
       if not same(data.get(key), context.shuffled.get(key)):
+        return None
+    observations = data.get("observations")
+    if "observations" in context.shuffled:
+      if not same(observations, context.shuffled["observations"]):
+        return None
+    else:  # frames referenced by index: the same rollout buffer, the epoch's own index slice
+      base = context.lazy.get("observations")
+      if (base is None or context.order_dev is None or getattr(observations, "base", None) is not base
+          or not same(getattr(observations, "index", None), context.order_dev)):
         return None
     mine = data.get("advantages")
     if context.norm_eps is None:
@@ -148,14 +172,37 @@ class Trainer:
       return None  # joined mid-epoch: step by step
     return context, k
 
+  def _single_update_context(self, alg, data):
+    """A one-minibatch "epoch" for engines that take a single update natively (the CNN engine:
+    PPO minibatches outside an IterateWithMinibatches epoch, every A2C update): the arrays the
+    loss would upload anyway, checked like the loss checks them."""
+    engine = self._native_ready(alg)
+    if engine is None or not getattr(engine, "single_native_update", False):
+      return None
+    arrays = alg.loss_fn.native_update_arrays(data)
+    if arrays is None:
+      return None
+    from ..runners.onpolicy import EpochContext  # pylint: disable=import-outside-toplevel
+    observations, index = arrays.pop("observations"), arrays.pop("index")
+    batch = arrays["actions"].shape[0]
+    return EpochContext(arrays, batch, batch, order_dev=index, lazy={"observations": observations})
+
   def _step_epoch(self, alg, context, k):
+    recording = summary.should_record()
     for anneal in self.anneals:
+      if recording:
+        anneal.summarize(alg.runner.step_count)
       anneal.step_to(alg.runner.step_count)
     if not context.consumed:
       self.optimizer.max_grad_norm = self.max_grad_norm
-      self.optimizer.native_epoch(alg.loss_fn, context)
+      self.optimizer.native_epoch(alg.loss_fn, context, record_norms=recording)
       context.consumed = True
     alg.loss_fn.last_terms = context.losses[k]
+    if recording:
+      alg.loss_fn._summaries(context.losses[k])  # pylint: disable=protected-access
+      if context.grad_norms is not None:
+        summary.add_scalar(f"{alg.name}/grad_norm", context.grad_norms[k].clone(),
+                           global_step=self.step_count)
     alg.loss_fn.call_count += 1
     self.step_count += 1
     return context.losses[k, 0]
@@ -164,6 +211,9 @@ class Trainer:
     fast = self._epoch_fast_path(alg, data)
     if fast is not None:
       return self._step_epoch(alg, *fast)
+    single = self._single_update_context(alg, data)
+    if single is not None:
+      return self._step_epoch(alg, single, 0)
     native = None
     if isinstance(self.optimizer, _FlatOptimizer) and type(alg).loss is Alg.loss:
       native = getattr(alg.loss_fn, "evaluate_native", None)
@@ -172,7 +222,7 @@ class Trainer:
       # per update (the head gradient already sits in the engine when the loss returns)
       loss, backward_fn = native(data)
       self.optimizer.zero_grad()
-      if distributed.world_size() > 1 and hasattr(alg.model.engine, "tail_offset"):
+      if distributed.sharded() and hasattr(alg.model.engine, "tail_offset"):
         backward_fn(None, on_part=self.optimizer.reduce_part)  # all-reduce overlapped with backward
       else:
         backward_fn(None)

@@ -52,6 +52,29 @@ class ActorCriticDeviceLoss(Loss):
     self.last_terms = terms
     return terms, backward_fn
 
+  def native_update_arrays(self, data):
+    """The device arrays of ONE minibatch as the engine's native update reads them (keys of
+    ``EpochContext.shuffled`` plus ``observations`` / ``index``), after the same checks and
+    uploads ``__call__`` makes; None when the observations are not a batch of frames."""
+    from ..models import GatheredRows  # pylint: disable=import-outside-toplevel
+    self._check(data, need_old=self.mode == 0)
+    f32 = torch.float32
+    observations, index = data["observations"], None
+    if isinstance(observations, GatheredRows):
+      observations, index = observations.base, observations.index
+    observations = self.model.prepare(observations)
+    if observations.ndim != 4:
+      return None
+    actions = self.to_device(data["actions"])
+    arrays = dict(observations=observations, index=index,
+                  actions=actions if actions.dtype == torch.int64 else actions.long(),
+                  advantages=self.to_device(data["advantages"], f32).reshape(-1),
+                  value_targets=self.to_device(data["value_targets"], f32).reshape(-1))
+    if self.mode == 0:
+      arrays["log_prob"] = self.to_device(data["log_prob"], f32).reshape(-1)
+      arrays["values"] = self.to_device(data["values"], f32).reshape(-1)
+    return arrays
+
   def _summaries(self, terms):
     tags = dict(policy_loss=1, entropy=2, value_loss=3, advantages=4, value_preds=5,
                 value_targets=6, r_squared=7, loss=0)

@@ -6,7 +6,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, distributed
 
 PARAM_NAMES = ("base.conv-0", "base.conv-1", "base.conv-2", "base.linear",
                "output_layers.0", "output_layers.1")
@@ -183,6 +183,107 @@ class CnnEngine:
       _lib.call("dx_cnn_backward_part", ctypes.byref(self.ctx), _lib.ptr(obs), is_u8,
                 _lib.ptr(sample_idx), batch, int(part), _lib.stream_ptr(self.device))
     return self.grads
+
+  # what Trainer looks at before handing updates to ``ppo_epoch``
+  native_allreduce = True      # the gradient exchange happens inside the native call
+  single_native_update = True  # a lone minibatch (A2C; PPO outside an epoch) goes the same way
+  native_rmsprop = True
+
+  def ppo_epoch(self, context, loss, optimizer, first_step, record_norms=False):
+    """Enqueues every minibatch update of ``context`` (runners.onpolicy.EpochContext) from one C
+    call (dx_cnn_ppo_epoch): advantage normalisation, weight packing, forward on the frames the
+    epoch's index selects, fused loss, backward (with the two gradient all-reduces of a sharded run
+    in between), gradient norm, clip + Adam / RMSprop per minibatch.  Returns the number of
+    updates; the packed mirrors are current when it returns."""
+    arrays = context.shuffled
+    samples, mbsize = int(context.sample_size), int(context.mbsize)
+    f32 = torch.float32
+    dev = self.device
+
+    def need(key, dtype=f32):
+      t = arrays.get(key)
+      if not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous() or t.shape[0] != samples:
+        raise _lib.NativeError(f"native epoch: '{key}' is not an epoch array of {samples} rows on the device")
+      if t.dtype != dtype:
+        raise _lib.NativeError(f"native epoch: '{key}' must be {dtype}, got {t.dtype}")
+      return t
+
+    obs = context.lazy.get("observations")
+    if obs is None:
+      obs = arrays.get("observations")
+    index = context.order_dev
+    if index is not None:
+      if index.dtype != torch.int32 or not index.is_cuda or not index.is_contiguous() or index.numel() != samples:
+        raise _lib.NativeError("native epoch: the epoch's index must be a contiguous int32 GPU tensor")
+    elif obs is None or obs.shape[0] != samples:
+      raise _lib.NativeError("native epoch: observations do not match the epoch's sample count")
+    if (not isinstance(obs, torch.Tensor) or not obs.is_cuda or not obs.is_contiguous()
+        or obs.dtype not in (torch.uint8, f32) or tuple(obs.shape[1:]) != self.input_shape):
+      raise _lib.NativeError(f"native epoch: observations must be a contiguous (n,{self.input_shape}) "
+                             "uint8 / float32 GPU tensor")
+    ppo = loss["mode"] == 0
+    actions = need("actions", torch.int64)
+    old_lp = need("log_prob") if ppo else None
+    old_v = need("values").reshape(-1) if ppo else None
+    adv = need("advantages").reshape(-1)
+    vt = need("value_targets").reshape(-1)
+    self.reserve(mbsize)
+    self._ensure_backward()
+    updates = context.num_minibatches
+    normalize = context.norm_eps is not None  # NormalizeAdvantages opted in with its epsilon
+    context.normalized = torch.empty(samples, dtype=f32, device=dev) if normalize else None
+    context.losses = torch.empty((updates, 8), dtype=f32, device=dev)
+    stats_ready = context.stats_ready if normalize else None
+    sharded = distributed.sharded()
+    if sharded and normalize and stats_ready is None:
+      raise _lib.NativeError("native epoch: a sharded run needs the prepared global advantage statistics")
+    if stats_ready is not None and (stats_ready.dtype != torch.float64 or not stats_ready.is_contiguous()
+                                    or tuple(stats_ready.shape) != (updates, 3)):
+      raise _lib.NativeError("native epoch: statistics must be a contiguous (minibatches, 3) float64 tensor")
+    if getattr(self, "_epoch_scratch", None) is None:
+      self._epoch_scratch = torch.empty(3, dtype=torch.float64, device=dev)
+    capacity = 8 * ((mbsize + 7) // 8)
+    if getattr(self, "_epoch_partials", None) is None or self._epoch_partials.numel() < capacity:
+      self._epoch_partials = torch.empty(capacity, dtype=torch.float64, device=dev)
+    state0, state1, beta1, beta2 = optimizer.native_state()
+    e = _lib.CnnEpoch()
+    e.struct_bytes = ctypes.sizeof(_lib.CnnEpoch)
+    e.mbsize, e.samples = mbsize, samples
+    e.obs, e.obs_is_u8, e.mode = obs.data_ptr(), int(obs.dtype == torch.uint8), int(loss["mode"])
+    e.index = index.data_ptr() if index is not None else None
+    e.actions = actions.data_ptr()
+    e.old_log_prob = old_lp.data_ptr() if ppo else None
+    e.old_values = old_v.data_ptr() if ppo else None
+    e.advantages, e.value_targets = adv.data_ptr(), vt.data_ptr()
+    e.normalize, e.norm_eps = int(normalize), float(context.norm_eps) if normalize else 0.0
+    e.stats_ready = stats_ready.data_ptr() if stats_ready is not None else None
+    e.stats = self._epoch_scratch.data_ptr()
+    e.adv_normalized = context.normalized.data_ptr() if normalize else None
+    cliprange = loss.get("cliprange")
+    e.cliprange = float(cliprange) if cliprange is not None else -1.0
+    e.value_loss_coef, e.entropy_coef = float(loss["value_loss_coef"]), float(loss["entropy_coef"])
+    e.world, e.allreduce = distributed.world_size(), int(sharded)
+    e.optimizer, e.npartials = int(optimizer.native_kind), optimizer.partials.numel()
+    e.state0 = state0.data_ptr()
+    e.state1 = state1.data_ptr() if state1 is not None else None
+    e.sumsq_partials = optimizer.partials.data_ptr()
+    e.loss_partials, e.loss_partials_capacity = self._epoch_partials.data_ptr(), int(capacity)
+    e.max_grad_norm = float(optimizer.max_grad_norm) if optimizer.max_grad_norm is not None else 0.0
+    e.lr, e.beta1, e.beta2 = optimizer.current_lr(), beta1, beta2
+    e.opt_eps, e.first_step = float(optimizer.eps), int(first_step)
+    if record_norms:  # one pre-clip norm per minibatch for the summaries
+      context.grad_norms = torch.empty(updates, dtype=f32, device=dev)
+      e.grad_norm_out, e.grad_norm_stride = context.grad_norms.data_ptr(), 1
+    else:
+      e.grad_norm_out, e.grad_norm_stride = optimizer.grad_norm.data_ptr(), 0
+    e.loss_out = context.losses.data_ptr()
+    keep = (obs, index, actions, old_lp, old_v, adv, vt, stats_ready)  # alive until enqueued
+    _lib.call("dx_cnn_ppo_epoch", ctypes.byref(self.ctx), ctypes.byref(e), _lib.stream_ptr(dev))
+    del keep
+    if record_norms:
+      optimizer.grad_norm.copy_(context.grad_norms[-1:])
+    self._packed_version = self._version()  # the call ends with dx_cnn_pack
+    return updates
 
   @property
   def tail_offset(self):

@@ -1,0 +1,98 @@
+// All minibatch updates of one PPO epoch (or the single update of an A2C rollout) of the
+// Nature-CNN actor-critic enqueued from ONE native call -- the loop of derl/alg/common.py:66-78
+// (Trainer.step: loss -> backward -> clip -> optimizer step) over the minibatches of
+// derl/runners/onpolicy.py:44-62 with the per-minibatch advantage normalisation of
+// derl/runners/trajectory_transforms.py:84-92.  Per minibatch: normalise -> pack -> forward
+// (frames gathered by the epoch's index inside the conv loader) -> fused loss -> backward of the
+// linear layer + heads -> [all-reduce of that tail of the gradient buffer, started on the
+// library's RCCL stream] -> backward of the conv layers -> [all-reduce of the head of the buffer]
+// -> norm -> clip + Adam / RMSprop.  The launches are the ones the per-step entry points issue, in
+// the same order on the same buffers (bit-identical results); what is gone is the host
+// interpreter between them -- at the 8-GPU shard size of BASELINE config 2 (32 envs per GPU) the
+// interpreter took as long as the kernels -- and the exchange step now sits INSIDE the call
+// (dx_allreduce_grads between the two halves of the backward).
+#include "common.hpp"
+
+namespace dx {
+bool comm_active();
+int comm_allreduce_async(float *buf, long long count, hipStream_t stream);
+int comm_wait(hipStream_t stream);
+}  // namespace dx
+
+using namespace dx;
+
+extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream) {
+  DX_TRACE("dx_cnn_ppo_epoch");
+  DX_REQUIRE(c != nullptr && e != nullptr, "dx_cnn_ppo_epoch: null argument");
+  DX_REQUIRE(e->struct_bytes == static_cast<int>(sizeof(dx_cnn_epoch)),
+             "dx_cnn_ppo_epoch: struct size mismatch (caller %d, library %d)", e->struct_bytes,
+             static_cast<int>(sizeof(dx_cnn_epoch)));
+  DX_REQUIRE(c->struct_bytes == static_cast<int>(sizeof(dx_cnn_ctx)) && c->param_count > 0,
+             "dx_cnn_ppo_epoch: ctx not initialised by dx_cnn_init");
+  DX_REQUIRE(e->samples >= 1 && e->mbsize >= 1 && e->mbsize <= c->max_batch,
+             "dx_cnn_ppo_epoch: %lld samples in minibatches of %d (max_batch %d)", e->samples, e->mbsize,
+             c->max_batch);
+  DX_REQUIRE(e->obs && e->actions && e->advantages && e->value_targets && e->state0 && e->sumsq_partials &&
+                 e->loss_partials && e->loss_out && c->grads && c->dhead,
+             "dx_cnn_ppo_epoch: null buffer");
+  DX_REQUIRE(!e->normalize || (e->adv_normalized && (e->stats_ready || e->stats)),
+             "dx_cnn_ppo_epoch: normalisation needs adv_normalized and statistics (given or scratch)");
+  DX_REQUIRE(e->mode == 1 || (e->mode == 0 && e->old_log_prob && e->old_values),
+             "dx_cnn_ppo_epoch: mode 0 (PPO) needs the rollout's log_prob / values; mode must be 0 or 1");
+  DX_REQUIRE(e->optimizer == 1 || (e->optimizer == 0 && e->state1), "dx_cnn_ppo_epoch: optimizer 0 = Adam (two "
+             "state buffers), 1 = RMSprop");
+  DX_REQUIRE(e->world >= 1, "dx_cnn_ppo_epoch: world < 1");
+  DX_REQUIRE(!e->allreduce || comm_active(), "dx_cnn_ppo_epoch: allreduce requested without a communicator "
+             "(dx_comm_init)");
+  DX_REQUIRE(e->loss_partials_capacity >= 8 * ((e->mbsize + 7) / 8), "dx_cnn_ppo_epoch: loss_partials too small");
+  hipStream_t s = as_stream(stream);
+  const long long tail = c->off_w[3];  // grads[tail ..) = linear layer + heads
+  int k = 0;
+  for (long long start = 0; start < e->samples; start += e->mbsize, ++k) {
+    const int B = static_cast<int>(e->samples - start < e->mbsize ? e->samples - start : e->mbsize);
+    const float *adv = e->advantages + start;
+    if (e->normalize) {  // what NormalizeAdvantages launches per minibatch; kept for the caller
+      float *norm = e->adv_normalized + start;
+      // sharded: the GLOBAL {sum, sumsq, n} of this minibatch, summed over the ranks beforehand
+      double *stats = e->stats_ready ? const_cast<double *>(e->stats_ready) + 3LL * k : e->stats;
+      if (int rc = dx_adv_normalize_f32(adv, norm, B, e->norm_eps, stats, e->stats_ready != nullptr, stream)) return rc;
+      adv = norm;
+    }
+    if (int rc = dx_cnn_pack(c, stream)) return rc;  // the previous update changed the parameters
+    const int32_t *idx = e->index ? e->index + start : nullptr;
+    const void *obs = e->obs;
+    if (!idx)  // no gather: minibatch k is rows [start, start + B) of obs
+      obs = static_cast<const char *>(e->obs) +
+            start * c->in_h * c->in_w * c->in_c * (e->obs_is_u8 ? 1 : 4);
+    if (int rc = dx_cnn_forward(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
+    const float *olp = e->old_log_prob ? e->old_log_prob + start : nullptr;
+    const float *ov = e->old_values ? e->old_values + start : nullptr;
+    if (int rc = dx_categorical_loss_f32(c->head, e->actions + start, olp, adv, ov, e->value_targets + start, B,
+                                         c->num_actions, e->mode, e->cliprange, e->value_loss_coef, e->entropy_coef,
+                                         static_cast<long long>(B) * e->world, c->dhead, e->loss_partials,
+                                         e->loss_partials_capacity, e->loss_out + 8LL * k, stream))
+      return rc;
+    if (e->allreduce) {
+      if (int rc = dx_cnn_backward_part(c, obs, e->obs_is_u8, idx, B, 0, stream)) return rc;
+      if (int rc = comm_allreduce_async(c->grads + tail, c->param_count - tail, s)) return rc;
+      if (int rc = dx_cnn_backward_part(c, obs, e->obs_is_u8, idx, B, 1, stream)) return rc;
+      if (int rc = comm_allreduce_async(c->grads, tail, s)) return rc;
+      if (int rc = comm_wait(s)) return rc;
+    } else {
+      if (int rc = dx_cnn_backward(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
+    }
+    if (int rc = dx_grad_sumsq_f32(c->grads, c->param_count, e->sumsq_partials, e->npartials, stream)) return rc;
+    float *norm_out = e->grad_norm_out ? e->grad_norm_out + static_cast<long long>(e->grad_norm_stride) * k : nullptr;
+    if (e->optimizer == 0) {
+      if (int rc = dx_clip_adam_step_f32(c->params, c->grads, e->state0, e->state1, c->param_count, e->sumsq_partials,
+                                         e->npartials, e->max_grad_norm, e->lr, e->beta1, e->beta2, e->opt_eps,
+                                         e->first_step + k, norm_out, stream))
+        return rc;
+    } else {
+      if (int rc = dx_clip_rmsprop_step_f32(c->params, c->grads, e->state0, c->param_count, e->sumsq_partials,
+                                            e->npartials, e->max_grad_norm, e->lr, e->beta1, e->opt_eps, norm_out, stream))
+        return rc;
+    }
+  }
+  return dx_cnn_pack(c, stream);  // the mirrors follow the last update: the next rollout can act at once
+}

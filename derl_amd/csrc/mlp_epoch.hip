@@ -58,7 +58,9 @@ extern "C" int dx_mlp_ppo_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, void
     if (int rc = dx_grad_sumsq_f32(c->grads, c->param_count, e->sumsq_partials, e->npartials, stream)) return rc;
     if (int rc = dx_clip_adam_step_f32(c->params, c->grads, e->exp_avg, e->exp_avg_sq, c->param_count,
                                        e->sumsq_partials, e->npartials, e->max_grad_norm, e->lr, e->beta1, e->beta2,
-                                       e->adam_eps, e->first_step + k, e->grad_norm_out, stream))
+                                       e->adam_eps, e->first_step + k,
+                                       e->grad_norm_out ? e->grad_norm_out + static_cast<long long>(e->grad_norm_stride) * k : nullptr,
+                                       stream))
       return rc;
   }
   return DX_OK;

@@ -1,11 +1,27 @@
-"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL
-over xGMI on ROCm; "gloo" for CPU rehearsals).  The hot path has exactly one real exchange
-step -- the gradient all-reduce per optimizer step -- plus a 3-double
-all-reduce for the per-minibatch advantage statistics."""
+"""Data-parallel plumbing: one process per GPU.
+
+The data path's collectives -- the gradient all-reduce per optimizer step, the
+per-rollout all-reduce of the minibatch advantage statistics and the initial parameter broadcast --
+run on an RCCL communicator owned by the native library (``dx_comm_init`` / ``dx_allreduce_grads``,
+include/derl_amd.h), so that a native update can issue them from inside one C call.
+``torch.distributed`` (backend "nccl" = RCCL on ROCm) is the launcher contract and the bootstrap:
+it carries the communicator's 128-byte unique id from rank 0 to the others, barriers and the
+bench's max-over-ranks -- nothing on the data path.
+
+Backend "gloo" is a REHEARSAL mode for boxes with fewer GPUs than ranks (RCCL refuses two ranks on
+one GPU): the same sharding rules with torch.distributed doing the reductions.
+``DERL_AMD_FORCE_COLLECTIVES=1`` makes a single process take the sharded code path end to end
+(RCCL accepts a one-rank communicator): what the GPU suite uses to execute the RCCL branch on a
+one-GPU box."""
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
+
+from . import _lib
+
+_native = False  # the library's communicator exists
 
 
 def is_initialized():
@@ -20,11 +36,26 @@ def rank():
   return dist.get_rank() if is_initialized() else 0
 
 
+def forced():
+  return os.environ.get("DERL_AMD_FORCE_COLLECTIVES", "0") not in ("", "0")
+
+
+def sharded():
+  """True when the data path must issue its collectives: more than one rank, or a single rank
+  with the collectives forced (tests)."""
+  return world_size() > 1 or (forced() and _native)
+
+
+def native_comm():
+  return _native
+
+
 def init_from_env(backend=None):
   """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* (the
-  torch.distributed.run contract) if WORLD_SIZE > 1; binds this rank to its GPU."""
+  torch.distributed.run contract) if WORLD_SIZE > 1 (or the collectives are forced), binds this
+  rank to its GPU and -- on backend nccl -- creates the library's RCCL communicator."""
   world = int(os.environ.get("WORLD_SIZE", "1"))
-  if world <= 1 or is_initialized():
+  if (world <= 1 and not forced()) or is_initialized():
     return world_size()
   local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
   if backend is None:
@@ -32,21 +63,94 @@ def init_from_env(backend=None):
     backend = os.environ.get("DERL_AMD_DIST_BACKEND") or (
         "nccl" if torch.cuda.is_available() else "gloo")
   if backend == "nccl":
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
   os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  os.environ.setdefault("MASTER_PORT", "29517")
+  os.environ.setdefault("RANK", "0")
+  os.environ.setdefault("WORLD_SIZE", "1")
   dist.init_process_group(backend=backend)
+  if backend == "nccl":
+    init_native_comm()
   return world_size()
 
 
+def init_native_comm():
+  """Creates the library's RCCL communicator over the ranks of the default process group: rank 0
+  makes the unique id (dx_comm_unique_id), one torch.distributed broadcast hands it out, every
+  rank joins (dx_comm_init) on its current device."""
+  global _native  # pylint: disable=global-statement
+  if _native:
+    return
+  if not is_initialized():
+    raise RuntimeError("init_native_comm: torch.distributed is not initialised (the unique id "
+                       "travels over it)")
+  ident = (ctypes.c_ubyte * 128)()
+  if rank() == 0:
+    _lib.call("dx_comm_unique_id", ctypes.byref(ident))
+  on_gpu = dist.get_backend() == "nccl"
+  carrier = torch.tensor(list(ident), dtype=torch.uint8)
+  if on_gpu:
+    carrier = carrier.cuda()
+  dist.broadcast(carrier, src=0)
+  ident = (ctypes.c_ubyte * 128)(*carrier.cpu().tolist())
+  _lib.call("dx_comm_init", ctypes.byref(ident), rank(), world_size())
+  _native = True
+
+
+def destroy():
+  """Tears down the library's communicator and the process group (end of a run / a test)."""
+  global _native  # pylint: disable=global-statement
+  if _native:
+    _lib.call("dx_comm_destroy")
+    _native = False
+  if is_initialized():
+    dist.destroy_process_group()
+
+
+def comm_info():
+  """(rank, world, all-reduces issued, bytes reduced) of the library's communicator."""
+  r, w = ctypes.c_int(0), ctypes.c_int(0)
+  n, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+  _lib.call("dx_comm_info", ctypes.byref(r), ctypes.byref(w), ctypes.byref(n), ctypes.byref(b))
+  return r.value, w.value, n.value, b.value
+
+
+def _native_ok(tensor):
+  return _native and isinstance(tensor, torch.Tensor) and tensor.is_cuda and tensor.is_contiguous()
+
+
+class _NativeHandle:
+  """What all_reduce_sum_async returns on the native communicator: ``wait()`` orders the current
+  stream after every reduction issued so far (dx_allreduce_wait)."""
+  def __init__(self, device):
+    self.device = device
+
+  def wait(self):
+    _lib.call("dx_allreduce_wait", _lib.stream_ptr(self.device))
+
+
 def all_reduce_sum(tensor):
-  if world_size() > 1:
+  """In-place SUM over the ranks, ordered like a kernel on the current stream."""
+  if not sharded():
+    return tensor
+  if _native_ok(tensor) and tensor.dtype == torch.float64:
+    _lib.call("dx_allreduce_sum_f64", _lib.ptr(tensor), tensor.numel(), _lib.stream_ptr(tensor.device))
+  elif _native_ok(tensor) and tensor.dtype == torch.float32:
+    _lib.call("dx_allreduce_grads", _lib.ptr(tensor), tensor.numel(), _lib.stream_ptr(tensor.device))
+    _lib.call("dx_allreduce_wait", _lib.stream_ptr(tensor.device))
+  elif world_size() > 1:
     dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
   return tensor
 
 
 def all_reduce_sum_async(tensor):
   """Starts the all-reduce on the communicator's stream (ordered after the work already on the
-  current stream) and returns the handle; ``handle.wait()`` orders the current stream after it."""
+  current stream) and returns a handle; ``handle.wait()`` orders the current stream after it."""
+  if not sharded():
+    return None
+  if _native_ok(tensor) and tensor.dtype == torch.float32:
+    _lib.call("dx_allreduce_grads", _lib.ptr(tensor), tensor.numel(), _lib.stream_ptr(tensor.device))
+    return _NativeHandle(tensor.device)
   if world_size() > 1:
     return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
   return None
@@ -59,7 +163,12 @@ def all_reduce_mean_grads(flat_grads):
 
 
 def broadcast_(tensor, src=0):
-  if world_size() > 1:
+  if not sharded():
+    return tensor
+  if _native_ok(tensor) and tensor.dtype == torch.float32:
+    _lib.call("dx_comm_broadcast_f32", _lib.ptr(tensor), tensor.numel(), int(src),
+              _lib.stream_ptr(tensor.device))
+  elif world_size() > 1:
     dist.broadcast(tensor, src=src)
   return tensor
 

@@ -109,7 +109,7 @@ class MlpEngine:
     _lib.call("dx_mlp_backward", ctypes.byref(self.ctx), int(batch), _lib.stream_ptr(self.device))
     return self.grads
 
-  def ppo_epoch(self, context, loss, optimizer, first_step):
+  def ppo_epoch(self, context, loss, optimizer, first_step, record_norms=False):
     """Enqueues every minibatch update of ``context`` (runners.onpolicy.EpochContext): advantage
     normalisation, forward, fused loss, backward, gradient norm, clip + Adam per minibatch, all
     from one C call.  Returns the number of updates."""
@@ -164,8 +164,16 @@ class MlpEngine:
     e.max_grad_norm = float(optimizer.max_grad_norm) if optimizer.max_grad_norm is not None else 0.0
     e.lr, e.beta1, e.beta2 = optimizer.current_lr(), float(optimizer.betas[0]), float(optimizer.betas[1])
     e.adam_eps, e.first_step = float(optimizer.eps), int(first_step)
-    e.grad_norm_out, e.loss_out = optimizer.grad_norm.data_ptr(), context.losses.data_ptr()
+    if record_norms:  # one pre-clip norm per minibatch for the summaries
+      context.grad_norms = torch.empty(updates, dtype=f32, device=dev)
+      e.grad_norm_out, e.grad_norm_stride = context.grad_norms.data_ptr(), 1
+    else:
+      e.grad_norm_out, e.grad_norm_stride = optimizer.grad_norm.data_ptr(), 0
+    e.loss_out = context.losses.data_ptr()
     keep = (obs, actions, old_lp, old_v, adv, vt)  # alive until the call has been enqueued
     _lib.call("dx_mlp_ppo_epoch", ctypes.byref(self.ctx), ctypes.byref(e), _lib.stream_ptr(dev))
     del keep
+    if record_norms:
+      optimizer.grad_norm.copy_(context.grad_norms[-1:])
+    self.mark_dirty()
     return updates

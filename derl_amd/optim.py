@@ -26,7 +26,7 @@ class _FlatOptimizer:
     self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.engine.device)
     self.param_groups = [dict(params=list(model.parameters()), lr=lr)]
     self._pending = []
-    if distributed.world_size() > 1:
+    if distributed.sharded():
       # replicas start from rank 0's parameters whatever each process seeded its init with
       distributed.broadcast_(self.engine.params)
       self.engine.mark_dirty()
@@ -42,7 +42,7 @@ class _FlatOptimizer:
     model's backward when one half of the flat gradient buffer is final -- part 0 = linear layer
     + heads (95 % of the bytes, ready before the conv layers' backward starts), part 1 = the
     conv layers -- and starts that half's all-reduce on the communicator's stream."""
-    if distributed.world_size() == 1:
+    if not distributed.sharded():
       return
     off = self.engine.tail_offset
     grads = self.engine.grads
@@ -77,12 +77,19 @@ class Adam(_FlatOptimizer):
                        self.betas[0], self.betas[1], self.eps, self.grad_norm)
     self.engine.mark_dirty()
 
-  def native_epoch(self, loss_fn, context):
-    """Every minibatch update of an epoch from one native call (MLP engines: dx_mlp_ppo_epoch);
-    fills ``context.losses`` / ``context.normalized`` and advances the step count."""
-    updates = self.engine.ppo_epoch(context, loss_fn.epoch_arguments(), self, self.step_count + 1)
+  native_kind = 0  # dx_cnn_epoch.optimizer
+
+  def native_state(self):
+    return self.exp_avg, self.exp_avg_sq, float(self.betas[0]), float(self.betas[1])
+
+  def native_epoch(self, loss_fn, context, record_norms=False):
+    """Every minibatch update of an epoch from one native call (dx_mlp_ppo_epoch /
+    dx_cnn_ppo_epoch); fills ``context.losses`` / ``context.normalized`` (and, when summaries are
+    being recorded, ``context.grad_norms``) and advances the step count.  The engine leaves its
+    packed mirrors in the state its kernels need."""
+    updates = self.engine.ppo_epoch(context, loss_fn.epoch_arguments(), self, self.step_count + 1,
+                                    record_norms=record_norms)
     self.step_count += updates
-    self.engine.mark_dirty()
 
   def state_dict(self):
     return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq)
@@ -101,6 +108,19 @@ class RMSprop(_FlatOptimizer):
                           self.max_grad_norm, self.current_lr(), self.alpha, self.eps,
                           self.grad_norm)
     self.engine.mark_dirty()
+
+  native_kind = 1  # dx_cnn_epoch.optimizer
+
+  def native_state(self):
+    return self.square_avg, None, float(self.alpha), 0.0
+
+  def native_epoch(self, loss_fn, context, record_norms=False):
+    """See Adam.native_epoch (engines whose native call knows RMSprop: dx_cnn_ppo_epoch)."""
+    if not getattr(self.engine, "native_rmsprop", False):
+      raise TypeError("this engine's native epoch implements Adam only")
+    updates = self.engine.ppo_epoch(context, loss_fn.epoch_arguments(), self, self.step_count + 1,
+                                    record_norms=record_norms)
+    self.step_count += updates
 
   def state_dict(self):
     return dict(step=self.step_count, square_avg=self.square_avg)

@@ -22,11 +22,16 @@ class EpochContext:
   ``normalized`` (every minibatch's normalised advantages) are filled in."""
   STATE_KEY = "epoch"
 
-  def __init__(self, shuffled, sample_size, mbsize):
+  def __init__(self, shuffled, sample_size, mbsize, order_dev=None, lazy=None):
     self.shuffled, self.sample_size, self.mbsize = shuffled, sample_size, mbsize
     self.num_minibatches = -(-sample_size // mbsize)
+    # arrays with big rows (frames) are not permuted: minibatch k reads rows
+    # order_dev[k * mbsize : (k + 1) * mbsize] of lazy[key] (GatheredRows); order_dev None = identity
+    self.order_dev, self.lazy = order_dev, lazy or {}
     self.consumed = False
-    self.losses = None
+    self.losses = None      # (minibatches, 8) loss terms, filled by the native epoch
+    self.grad_norms = None  # (minibatches,) pre-clip gradient norms when summaries are recorded
+    self.stats_ready = None  # (minibatches, 3) global advantage statistics of a sharded run
     # Written by NormalizeAdvantages when it normalises the epoch's FIRST minibatch: its epsilon
     # and the tensor it produced.  That is how the transform opts in to the native epoch: the
     # trainer normalises the remaining minibatches the same way only if these are set and the
@@ -188,7 +193,13 @@ class IterateWithMinibatches(RunnerWrapper):
       for epoch, order in enumerate(orders):
         order_dev = orders_dev[epoch] if orders_dev is not None else None
         shuffled = self._gather_epoch(interactions, order_dev)
-        context = EpochContext(shuffled, sample_size, mbsize) if shuffled else None
+        context = None
+        if shuffled:
+          lazy = {key: val for key, val in interactions.items()
+                  if key != "state" and key not in shuffled and isinstance(val, torch.Tensor) and val.is_cuda}
+          context = EpochContext(shuffled, sample_size, mbsize, order_dev, lazy)
+          if extras is not None:
+            context.stats_ready = getattr(extras, "epoch_stats", lambda _: None)(epoch)
         for start in range(0, sample_size, mbsize):
           stop = min(start + mbsize, sample_size)
           index_host = order[start:stop]

@@ -98,7 +98,7 @@ class NormalizeAdvantages:
   def prepare(self, interactions, orders_dev, mbsize):
     """orders_dev: (epochs, samples) int32 composed permutations on the device."""
     advantages = interactions.get("advantages")
-    if (distributed.world_size() == 1 or not isinstance(advantages, torch.Tensor)
+    if (not distributed.sharded() or not isinstance(advantages, torch.Tensor)
         or not advantages.is_cuda or advantages.dtype != torch.float32
         or advantages.numel() != orders_dev.shape[1]):
       return None
@@ -108,7 +108,12 @@ class NormalizeAdvantages:
     for epoch in range(orders_dev.shape[0]):
       ops.adv_stats_segments(flat, orders_dev[epoch], mbsize, stats=stats[epoch])
     distributed.all_reduce_sum(stats)
-    return lambda epoch, k: {self.STATE_KEY: stats[epoch, k]}
+
+    def extras(epoch, k):
+      return {self.STATE_KEY: stats[epoch, k]}
+
+    extras.epoch_stats = lambda epoch: stats[epoch]  # (minibatches, 3): what a native epoch takes
+    return extras
 
   def __call__(self, trajectory):
     advantages = trajectory["advantages"]
@@ -123,19 +128,20 @@ class NormalizeAdvantages:
       start = k * context.mbsize
       trajectory["advantages"] = context.normalized[start:start + flat.numel()].reshape(advantages.shape)
       return
-    first_of_epoch = (epoch is not None and epoch[1] == 0 and not epoch[0].consumed
-                      and distributed.world_size() == 1)
+    first_of_epoch = epoch is not None and epoch[1] == 0 and not epoch[0].consumed
     ready = state.get(self.STATE_KEY) if isinstance(state, dict) else None
     if ready is not None:
       out = ops.adv_normalize(flat, self.epsilon, stats=ready, stats_ready=True)
-    elif distributed.world_size() > 1:
+    elif distributed.sharded():
       stats = ops.adv_stats(flat)
       distributed.all_reduce_sum(stats)
       out = ops.adv_normalize(flat, self.epsilon, stats=stats, stats_ready=True)
     else:
       out = ops.adv_normalize(flat, self.epsilon)
     trajectory["advantages"] = out.reshape(advantages.shape)
-    if first_of_epoch:  # opt in to the native epoch (EpochContext): same rule, this epsilon
+    if first_of_epoch and (ready is not None or not distributed.sharded()):
+      # opt in to the native epoch (EpochContext): same rule, this epsilon (a sharded run only with
+      # the prepared global statistics of every minibatch)
       epoch[0].norm_eps, epoch[0].norm_first = self.epsilon, trajectory["advantages"]
 
 

@@ -259,6 +259,54 @@ int dx_cnn_rollout_synth(const dx_cnn_ctx *ctx, uint8_t *obs, int T, int N, int6
                          float *log_prob, float *values, float *rewards, uint8_t *resets,
                          uint64_t policy_seed, uint64_t policy_counter, uint64_t env_seed,
                          uint64_t env_counter, float p_reward, float p_reset, void *stream);
+/* Every minibatch update of one PPO epoch (or the one update of an A2C rollout) from ONE call --
+ * the loop of derl/alg/common.py:66-78 (Trainer.step) over the minibatches of
+ * derl/runners/onpolicy.py:44-62, with derl/runners/trajectory_transforms.py:84-92 in front of
+ * each.  Minibatch k is samples [k * mbsize, min((k + 1) * mbsize, samples)) of the EPOCH-ORDERED
+ * per-sample arrays; its frames are obs[index[...]] (index = the epoch's composed permutation,
+ * gathered inside the conv loader) or, with index == NULL, the rows of obs themselves.  Same
+ * launches in the same order as dx_adv_normalize_f32 -> dx_cnn_pack -> dx_cnn_forward ->
+ * dx_categorical_loss_f32 -> dx_cnn_backward[_part] -> dx_grad_sumsq_f32 -> dx_clip_*_step_f32 per
+ * minibatch: bit-identical results.  With `allreduce` the two halves of the flat gradient buffer
+ * are summed over the ranks through the library's communicator (dx_comm_init) between / after the
+ * two halves of the backward, overlapping the conv layers' backward. */
+typedef struct dx_cnn_epoch {
+  int struct_bytes;
+  int mbsize;
+  long long samples;
+  const void *obs;             /* (rows, in_h, in_w, in_c) uint8 or float32                 */
+  int obs_is_u8;
+  int mode;                    /* 0 = PPO, 1 = A2C                                          */
+  const int32_t *index;        /* (samples) rows of obs in epoch order, or NULL (identity)  */
+  const int64_t *actions;      /* (samples), epoch order like every array below             */
+  const float *old_log_prob;   /* (samples) or NULL (A2C)                                   */
+  const float *advantages;     /* (samples), raw                                            */
+  const float *old_values;     /* (samples) or NULL (A2C)                                   */
+  const float *value_targets;  /* (samples)                                                 */
+  int normalize;               /* 1: (a - mean) / (std + norm_eps) per minibatch            */
+  float norm_eps;
+  const double *stats_ready;   /* (minibatches, 3) GLOBAL {sum, sumsq, n} per minibatch (sharded
+                                  runs: summed over the ranks beforehand) or NULL: local      */
+  double *stats;               /* (3) scratch when stats_ready == NULL                      */
+  float *adv_normalized;       /* (samples): every minibatch's normalised advantages        */
+  float cliprange, value_loss_coef, entropy_coef;
+  int world;                   /* ranks: gradients are scaled by 1 / (B * world)            */
+  int allreduce;               /* 1: all-reduce the gradient halves (needs dx_comm_init)    */
+  int optimizer;               /* 0 = Adam (state0 = exp_avg, state1 = exp_avg_sq, beta1,
+                                  beta2), 1 = RMSprop (state0 = square_avg, beta1 = alpha)   */
+  int npartials;
+  float *state0, *state1;
+  double *sumsq_partials;
+  double *loss_partials;
+  int loss_partials_capacity;
+  int grad_norm_stride;        /* 0: grad_norm_out[0] = the last minibatch's; 1: one each   */
+  double max_grad_norm;        /* <= 0: no clipping                                         */
+  double lr, beta1, beta2, opt_eps;
+  long long first_step;        /* Adam's step number of minibatch 0 (1-based)               */
+  float *grad_norm_out;        /* pre-clip norms (see grad_norm_stride) or NULL             */
+  float *loss_out;             /* (ceil(samples / mbsize), 8)                               */
+} dx_cnn_epoch;
+int dx_cnn_ppo_epoch(const dx_cnn_ctx *ctx, const dx_cnn_epoch *epoch, void *stream);
 /* One launch of the network (one profiler row), for per-kernel timing and layer tests.
  * Stages in execution order: 0 conv0_fwd, 1 conv1_fwd, 2 conv2_fwd, 3 fc_fwd, 4 heads_fwd,
  * 5 heads_wgrad, 6 heads_dgrad, 7 fc_wgrad, 8 fc_dgrad, 9 conv2_wgrad, 10 conv2_dgrad,
@@ -339,8 +387,10 @@ typedef struct dx_mlp_epoch {
   double max_grad_norm;        /* <= 0: no clipping                                       */
   double lr, beta1, beta2, adam_eps;
   long long first_step;        /* Adam's step number of minibatch 0 (1-based)             */
-  float *grad_norm_out;        /* (1) pre-clip norm of the LAST minibatch, or NULL        */
+  float *grad_norm_out;        /* pre-clip norms (see grad_norm_stride), or NULL          */
   float *loss_out;             /* (ceil(samples / mbsize), 8)                             */
+  int grad_norm_stride;        /* 0: grad_norm_out[0] = the last minibatch's; 1: one each */
+  int reserved0;
 } dx_mlp_epoch;
 int dx_mlp_ppo_epoch(const dx_mlp_ctx *ctx, const dx_mlp_epoch *epoch, void *stream);
 
@@ -368,6 +418,42 @@ int dx_normal_loss_f32(const float *head_out, const float *logstd, const float *
 int dx_synth_atari_step(void *frames, long long frame_bytes_total, float *rewards,
                         uint8_t *resets, int nenvs, uint64_t seed, uint64_t counter,
                         float p_reward, float p_reset, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Gradient exchange.  derl has no distributed code; the step these sit
+ * inside is derl/alg/common.py:66-78 (Trainer.step: backward -> [all-reduce] -> clip ->
+ * optimizer step).  One process per GPU; the library owns ONE RCCL communicator (resolved
+ * with dlopen at dx_comm_init -- no link-time dependency) plus a high-priority stream the
+ * gradient reductions run on.
+ *   dx_comm_unique_id   rank 0 makes the 128-byte id (HOST buffer); the host side hands it to
+ *                       the other ranks by any means (derl_amd/distributed.py: one
+ *                       torch.distributed broadcast -- the only thing torch.distributed does).
+ *   dx_comm_init        collective: every rank calls it with the same id, on its own device.
+ *   dx_allreduce_grads  in-place SUM of count floats, ASYNCHRONOUS to `stream`: it starts once
+ *                       the work already enqueued on `stream` is done, and runs on the
+ *                       library's stream; `stream` continues without waiting.  Each rank's loss
+ *                       kernel scales by 1 / global_batch, so the SUM is the single-process
+ *                       mean gradient.
+ *   dx_allreduce_wait   makes `stream` wait for every reduction issued so far (no-op without a
+ *                       communicator: single-process callers need not branch).
+ *   dx_allreduce_sum_f64 / dx_comm_broadcast_f32   in-stream (ordered like a kernel on `stream`):
+ *                       the per-minibatch advantage statistics {sum, sumsq, n} of a rollout
+ *                       (derl/runners/trajectory_transforms.py:89-92 made global) and the
+ *                       initial parameter broadcast.
+ * World size 1 is valid (RCCL accepts one rank): the same code path, used by the GPU tests.
+ * Not thread-safe against concurrent use of the same communicator.
+ * --------------------------------------------------------------------------------- */
+#define DX_COMM_ID_BYTES 128
+int dx_comm_unique_id(void *id_out_host);
+int dx_comm_init(const void *unique_id_host, int rank, int world);
+/* any output may be NULL; world = 0 when there is no communicator */
+int dx_comm_info(int *rank_host, int *world_host, long long *allreduces_issued_host,
+                 long long *allreduce_bytes_host);
+int dx_comm_destroy(void);
+int dx_allreduce_grads(float *flat_grads, long long count, void *stream);
+int dx_allreduce_wait(void *stream);
+int dx_allreduce_sum_f64(double *buf, long long count, void *stream);
+int dx_comm_broadcast_f32(float *buf, long long count, int root, void *stream);
 
 #ifdef __cplusplus
 }

@@ -212,8 +212,71 @@ def gpu_learns():
   print(f"rank {rank}: gpu_learns OK", flush=True)
 
 
+def rccl_one_rank():
+  """The RCCL branch of the data path, executed: backend nccl, ONE rank (RCCL accepts a one-rank
+  communicator), collectives forced (DERL_AMD_FORCE_COLLECTIVES=1).  The library's communicator is
+  bootstrapped through torch.distributed (dx_comm_unique_id -> broadcast -> dx_comm_init); two
+  Trainer.steps then issue the parameter broadcast, the advantage-statistics all-reduce and the
+  two overlapped gradient all-reduces per step through dx_comm_* -- and must equal the
+  single-process step bit for bit (a sum over one rank is the identity)."""
+  import derl_amd as derl
+  from derl_amd.optim import Adam
+  assert torch.distributed.get_backend() == "nccl" and distributed.world_size() == 1
+  assert distributed.native_comm() and distributed.sharded()
+  assert distributed.comm_info()[:2] == (0, 1)
+  derl.summary.stop_recording()
+  A, B = 4, 32
+  weights = gi.nature_cnn_weights(A, 3)
+  mb = gi.cnn_minibatch(B, A, 5)
+  logits, vals = oracle.nature_cnn_forward(weights, mb["observations"])
+  lp, _, _ = oracle.categorical_log_prob_entropy(logits, mb["actions"])
+  full = dict(observations=mb["observations"], actions=mb["actions"],
+              log_prob=(lp.numpy() + mb["logp_noise"]).astype(np.float32),
+              advantages=mb["advantages"], values=(vals.numpy() + mb["value_noise"]).astype(np.float32),
+              value_targets=(vals.numpy() + mb["target_noise"]).astype(np.float32))
+
+  class Runner:
+    step_count = 1000
+
+  def run(with_collectives):
+    saved = distributed.forced
+    distributed.forced = (lambda: True) if with_collectives else (lambda: False)
+    try:
+      model = derl.NatureCNNModel([A, 1], max_batch=32)
+      model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+      runner = Runner()
+      runner.policy = derl.ActorCriticPolicy(model)
+      lr = derl.LinearAnneal(2.5e-4, 1e6, name="lr")
+      trainer = derl.Trainer(Adam(model, lr=lr.get_tensor(), eps=1e-5), anneals=[lr], max_grad_norm=0.5)
+      alg = derl.PPO(runner, trainer, cliprange=0.1, value_loss_coef=0.25, entropy_coef=0.01)
+      data = dict(full)
+      derl.NormalizeAdvantages()(data)
+      losses = [alg.step(data).item() for _ in range(2)]
+      torch.cuda.synchronize()
+      return losses, model.engine.params.clone()
+    finally:
+      distributed.forced = saved
+
+  before = distributed.comm_info()
+  losses_c, params_c = run(True)
+  after = distributed.comm_info()
+  # per run: 1 statistics all-reduce (3 doubles) + 2 steps x 2 halves of the gradient buffer
+  assert after[2] - before[2] == 5, (before, after)
+  assert after[3] - before[3] == 24 + 2 * 4 * params_c.numel(), (before, after)
+  losses_s, params_s = run(False)
+  assert distributed.comm_info()[2] == after[2], "the single-process run issued a collective"
+  assert losses_c == losses_s and torch.equal(params_c, params_s)
+  # the in-stream float32 sum and the broadcast
+  ones = torch.ones(1000, device="cuda")
+  distributed.all_reduce_sum(ones)
+  distributed.broadcast_(ones)
+  assert float(ones.sum().item()) == 1000.0
+  print("rank 0: rccl_one_rank OK", flush=True)
+
+
 if __name__ == "__main__":
-  distributed.init_from_env(backend="gloo")
+  mode = sys.argv[1]
+  distributed.init_from_env(backend="nccl" if mode.startswith("rccl") else "gloo")
   {"cpu_math": cpu_math, "gpu_step": gpu_step, "gpu_minibatch_stats": gpu_minibatch_stats,
-   "gpu_learns": gpu_learns}[sys.argv[1]]()
-  torch.distributed.destroy_process_group()
+   "gpu_learns": gpu_learns, "rccl_one_rank": rccl_one_rank}[mode]()
+  distributed.destroy()

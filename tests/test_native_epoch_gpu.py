@@ -1,11 +1,10 @@
-"""The native-epoch path of the MLP policies (Trainer._step_epoch -> dx_mlp_ppo_epoch): every
+"""The native-epoch path (Trainer._step_epoch -> dx_mlp_ppo_epoch / dx_cnn_ppo_epoch): every
 minibatch update of an epoch enqueued from ONE C call, against the per-update path
 (Trainer.native_epochs = False) and against the CPU oracle stepping the same minibatches
 (derl/alg/common.py:66-78 inside derl/runners/onpolicy.py:44-62).
 
-PeriodicSummaries arms recording on every rollout and a recording step never takes the native
-path, so the tests switch recording off after each ``next()`` -- what bench.py and
-tools/bench_configs.py do -- and count the native calls to prove the path was entered."""
+The tests count the native calls to prove the path was entered; most switch summary recording off
+after each ``next()`` like bench.py does, one records through the native path on purpose."""
 import numpy as np
 import numpy.testing as nt
 import pytest
@@ -50,9 +49,11 @@ def make_alg(kind, native, nenvs, horizon, epochs, nmb):
   np.random.seed(11)
   if kind == "gaussian":
     env = derl.env.make("HalfCheetah-v3", nenvs=nenvs, seed=3)
+  elif kind == "cnn":
+    env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=nenvs, seed=3)
   else:
     env = DeviceVectorEnv(nenvs, 11, 5, seed=3)
-  kwargs = derl.PPOFactory.get_kwargs("mujoco")
+  kwargs = derl.PPOFactory.get_kwargs("atari" if kind == "cnn" else "mujoco")
   kwargs.update(nenvs=nenvs, num_runner_steps=horizon, num_epochs=epochs, num_minibatches=nmb,
                 num_train_steps=nenvs * horizon * 4, entropy_coef=0.01)
   alg = derl.PPOFactory(**kwargs).make(env)
@@ -60,9 +61,9 @@ def make_alg(kind, native, nenvs, horizon, epochs, nmb):
   calls = []
   inner = alg.trainer.optimizer.native_epoch
 
-  def counted(loss_fn, context):
+  def counted(loss_fn, context, **kwargs):
     calls.append(context.num_minibatches)
-    return inner(loss_fn, context)
+    return inner(loss_fn, context, **kwargs)
 
   alg.trainer.optimizer.native_epoch = counted
   return alg, calls
@@ -94,7 +95,7 @@ def run(kind, native, nenvs, horizon, epochs, nmb, rollouts, keep_host=False):
 
 
 # 33 envs x 16 steps = 528 samples in 5 minibatches of 105 + a ragged sixth of 3
-@pytest.mark.parametrize("kind", ["gaussian", "categorical"])
+@pytest.mark.parametrize("kind", ["gaussian", "categorical", "cnn"])
 def test_native_epoch_equals_per_update_path_and_oracle(kind):
   nenvs, horizon, epochs, nmb, rollouts = 33, 16, 2, 5, 2
   fast = run(kind, True, nenvs, horizon, epochs, nmb, rollouts, keep_host=True)
@@ -110,6 +111,8 @@ def test_native_epoch_equals_per_update_path_and_oracle(kind):
     assert torch.equal(a, b)
   assert torch.equal(fast["params"], slow["params"])
   assert torch.equal(fast["m"], slow["m"]) and torch.equal(fast["v"], slow["v"])
+  if kind == "cnn":  # the conv path's oracle parity: the golden Trainer.step tests (same native call)
+    return
   # the oracle on the first epoch's minibatches (incl. the ragged one), from the same start
   alg = fast["alg"]
   names = [k for k, _ in alg.model.named_parameters()]
@@ -190,3 +193,72 @@ def test_native_epoch_declines_when_a_transform_edited_the_minibatch():
       alg.step(data)
     assert calls == [], f"native epoch ran although a transform replaced '{key}'"
     assert alg.trainer.optimizer.step_count == 4
+
+
+def _scalars_of_a_run(native):
+  """Every scalar the summaries record over one rollout's updates, as (tag, global_step, value)."""
+  import derl_amd as derl
+  alg, calls = make_alg("cnn", native, 8, 16, 2, 4)
+  seen = []
+  original = derl.summary.add_scalar
+
+  def capture(tag, value, global_step=None, **kwargs):
+    seen.append((tag, global_step, float(value)))
+
+  derl.summary.add_scalar = capture
+  try:
+    it = alg.runner.run()
+    for _ in range(8):
+      alg.step(next(it))  # PeriodicSummaries armed recording for this (first) rollout
+  finally:
+    derl.summary.add_scalar = original
+    derl.summary.stop_recording()
+  return seen, calls
+
+
+def test_native_epoch_records_the_same_summaries():
+  """A recording rollout (every rollout of a default `derl ppo` run is one) takes the native epoch
+  too: the loss terms of every minibatch, its pre-clip gradient norm and the learning rate come out
+  with the tags, global steps and values of the per-update path (derl/alg/ppo.py:56-62,90-96,
+  derl/alg/common.py:61-64)."""
+  fast, calls = _scalars_of_a_run(True)
+  slow, none = _scalars_of_a_run(False)
+  assert calls == [4, 4] and none == []
+  assert sorted(fast) == sorted(slow)
+  tags = {t for t, _, _ in fast}
+  assert {"ppo/loss", "ppo/policy_loss", "ppo/entropy", "ppo/value_loss", "ppo/grad_norm"} <= tags, tags
+  assert sum(1 for t, _, _ in fast if t == "ppo/grad_norm") == 8
+
+
+@pytest.mark.parametrize("nenvs", [16])
+def test_a2c_update_goes_through_the_native_call(nenvs):
+  """A2C has no minibatch epochs: each rollout's single update is handed to the same native call
+  as a one-minibatch epoch (RMSprop inside dx_cnn_ppo_epoch) -- bit-identical to the per-update
+  path over several rollouts."""
+  import derl_amd as derl
+
+  def run(native):
+    torch.manual_seed(0)
+    np.random.seed(5)
+    env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=nenvs, seed=2)
+    kwargs = derl.A2CFactory.get_kwargs()
+    kwargs.update(nenvs=nenvs, num_train_steps=nenvs * 5 * 6)
+    alg = derl.A2CFactory(**kwargs).make(env)
+    alg.trainer.native_epochs = native
+    calls = []
+    inner = alg.trainer.optimizer.native_epoch
+
+    def counted(loss_fn, context, **kw):
+      calls.append(context.num_minibatches)
+      return inner(loss_fn, context, **kw)
+
+    alg.trainer.optimizer.native_epoch = counted
+    losses = []
+    for data in alg.runner.run():
+      derl.summary.stop_recording()
+      losses.append(alg.step(data).item())
+    return losses, alg.model.engine.params.clone(), alg.trainer.optimizer.square_avg.clone(), calls
+
+  fast, slow = run(True), run(False)
+  assert fast[3] == [1] * 6 and slow[3] == []
+  assert fast[0] == slow[0] and torch.equal(fast[1], slow[1]) and torch.equal(fast[2], slow[2])
