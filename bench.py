@@ -137,6 +137,7 @@ def main():
   parser.add_argument("--cpu-budget-s", type=float, default=150.0,
                       help="cuts the timed CPU iterations (never below 1) to fit this many seconds")
   parser.add_argument("--no-roofline", action="store_true")
+  parser.add_argument("--no-other-configs", action="store_true")
   parser.add_argument("--allow-gloo", action="store_true",
                       help="rehearsal only: accept a non-RCCL backend for WORLD_SIZE > 1 (the JSON "
                            "line then says so and is not a scaling measurement)")
@@ -202,6 +203,15 @@ def main():
     torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
   elapsed = float(elapsed.item())
 
+  # what ONE iteration costs the host when nothing holds it back: the queue is empty (synchronised),
+  # so the enqueue calls never block on a full command ring -- inside the timed region the host runs
+  # ahead until HIP's queue is full and then advances at the GPU's pace, which makes
+  # host_enqueue_ms_per_step ~ ms_per_step whenever the GPU is the bottleneck
+  unblocked_start = time.perf_counter()
+  iteration()
+  host_unblocked_s = time.perf_counter() - unblocked_start
+  torch.cuda.synchronize()
+
   env_steps = args.steps * args.nsteps * nenvs_total
   value = env_steps / elapsed
   # the gradient exchange of one update: the flat fp32 gradient buffer, all-reduced in two pieces
@@ -228,8 +238,12 @@ def main():
                  "minibatch_per_gpu": nenvs * args.nsteps // kwargs["num_minibatches"],
                  "updates_per_step": updates_per_iter, "parallelism": f"dp{world}",
                  "ranks_seen": ranks_seen, "backend": backend,
+                 "collectives": ("RCCL communicator owned by the native library (dx_comm_init / "
+                                 "dx_allreduce_grads inside dx_cnn_ppo_epoch)" if distributed.native_comm()
+                                 else "none" if world == 1 else "torch.distributed (rehearsal)"),
                  "allreduce_bytes_per_update": allreduce_bytes,
                  "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 3),
+                 "host_enqueue_ms_unblocked": round(host_unblocked_s * 1e3, 3),
                  "arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32); first conv layer on bf16 MFMA with "
                                "exact operands (uint8 pixels, 3-term bf16 split of the fp32 side), "
                                "fp32 accumulation everywhere",
@@ -311,11 +325,20 @@ def main():
                               "cores": base["cores"], "kind": "port", "sample": base["sample"],
                               "seconds": round(base["seconds"], 2)}
 
+  if rank == 0 and world == 1 and not args.no_other_configs:
+    # the other single-GPU BASELINE configs ("plus the other configs"), bounded in time:
+    # config 3 at its full shape, config 5 as its per-GPU shard (512 of the 4096 envs)
+    from tools.bench_configs import measure
+    result["other_configs"] = {
+        "PPO HalfCheetah-v3 nenvs=2048 nsteps=64 MLP (configs[2])": measure("c3", 20, budget_s=6.0),
+        "A2C Breakout nenvs=4096 nsteps=5 on 8 GPUs: one GPU's shard of 512 envs (configs[4])":
+            measure("c5", 400, budget_s=4.0)}
+
   if rank == 0:
     print(json.dumps(result), flush=True)
   if world > 1:
     distributed.barrier()  # rank 0 may still be measuring the roofline
-    torch.distributed.destroy_process_group()
+    distributed.destroy()
 
 
 if __name__ == "__main__":

@@ -24,6 +24,7 @@ P = c_void_p
 SIGNATURES = {
     "dx_abi_version": [],
     "dx_last_error": [],
+    "dx_launch_count": [],
     "dx_device_info": [c_int, c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "dx_gae_f32": [P, P, P, P, c_int, c_int, c_float, c_float, P, P, P],
     "dx_adv_stats_f32": [P, c_longlong, P, P],
@@ -90,7 +91,7 @@ class CnnCtx(ctypes.Structure):
                                           "pb_c2d", "pb_fcd", "pb_c0f")]
       + [(n, c_void_p) for n in ("params", "grads", "packed", "y0", "y1", "y2", "hid", "head",
                                  "dy0", "dy1", "dy2", "dhid", "dhead", "slabs", "hid_slabs")])
-_RESTYPES = {"dx_last_error": c_char_p}
+_RESTYPES = {"dx_last_error": c_char_p, "dx_launch_count": c_longlong}
 
 _lib = None
 

@@ -62,11 +62,16 @@ int wgrad_direct_min_batch() {
 }
 
 // DX_ROLLOUT_LANES=1: the native rollout on the caller's stream only (default 2: see
-// dx_cnn_rollout_synth)
+// dx_cnn_rollout_synth); DX_ROLLOUT_LANE_MIN: fewest envs a lane may have (default 64)
 int rollout_lanes() {
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_ROLLOUT_LANES"); v = e ? atoi(e) : 2; }
   return v;
+}
+int rollout_lane_min() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_ROLLOUT_LANE_MIN"); v = e ? atoi(e) : 64; }
+  return v < 1 ? 1 : v;
 }
 
 // The one piece of state the library owns: a side stream and two events per device for the
@@ -716,8 +721,12 @@ int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_
   // are bit-identical to the one-lane rollout and the samples come from the same stream positions
   // (both are indexed by the env's position in the whole batch); log-probs and values agree to
   // float32 rounding (a half batch may take a different tile shape).  DX_ROLLOUT_LANES=1: off.
+  // Lanes need >= 64 envs each.  Smaller lanes were measured (round 3, tools/lanes_probe.sh): a
+  // 32-env shard as 2 / 4 chains of 16 / 8 envs takes 12.7 / 14.3 ms per iteration against 11.8 as
+  // one chain -- kernels of different queues do not fill each other's dependent-launch gaps at
+  // this size, and the host pays 5.5 / 15.7 ms of launches instead of 3.5.
   int lanes = rollout_lanes() < kMaxLanes ? rollout_lanes() : kMaxLanes;
-  while (lanes > 1 && !(N / lanes >= 64 && N % (4 * lanes) == 0 && (frame / lanes) % 16 == 0 &&
+  while (lanes > 1 && !(N / lanes >= rollout_lane_min() && N % (4 * lanes) == 0 && (frame / lanes) % 16 == 0 &&
                         static_cast<long long>(lanes) * fc_ksplit(N / lanes, c->flat) * (N / lanes) * kHid <= c->hid_slab_count))
     --lanes;
   SideStream *side = lanes > 1 ? side_stream() : nullptr;

@@ -39,8 +39,14 @@ inline int fail(int code, const char *fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);               \
   } while (0)
 
-// after a kernel launch: catches bad launch configurations without synchronising
-#define DX_LAUNCH_CHECK() DX_HIP(hipGetLastError())
+// after a kernel launch: catches bad launch configurations without synchronising (and counts the
+// launch: dx_launch_count(), how bench.py reports launches per update)
+void count_launch();
+#define DX_LAUNCH_CHECK()          \
+  do {                             \
+    ::dx::count_launch();          \
+    DX_HIP(hipGetLastError());     \
+  } while (0)
 
 // roctx range around a C-ABI call (tracing): DX_ROCTX=1 resolves
 // roctxRangePushA / roctxRangePop from libroctx64.so at first use, so that a rocprofv3

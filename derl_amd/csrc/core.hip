@@ -1,5 +1,6 @@
 // ABI version, error string and device probe.
 #include "common.hpp"
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
@@ -35,6 +36,11 @@ TraceRange::~TraceRange() {
   if (active) g_pop();
 }
 
+namespace {
+std::atomic<long long> g_launches{0};
+}
+void count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+
 char *error_buffer() {
   static thread_local char buf[512] = "";
   return buf;
@@ -44,6 +50,8 @@ char *error_buffer() {
 extern "C" int dx_abi_version(void) { return DX_ABI_VERSION; }
 
 extern "C" const char *dx_last_error(void) { return dx::error_buffer(); }
+
+extern "C" long long dx_launch_count(void) { return dx::g_launches.load(std::memory_order_relaxed); }
 
 extern "C" int dx_device_info(int device, char *name_host, int *cu_count, int *lds_bytes) {
   DX_TRACE("dx_device_info");

@@ -71,6 +71,14 @@ struct NtpArgs {
   int ntiles;         // MODE 0: row tiles
   int nimg, ngroups;  // MODE 1: images, groups of 128 images
   int tiles_per_xcd;  // MODE 1: ceil(ngroups / 8) * pixels
+  // MODE 2: rows_inner = the walk of an XCD's tiles has the row groups innermost (u -> column tile
+  // u / G, row group u % G, G = groups_per_xcd): the XCD's resident workgroups then cover ALL of its
+  // row groups x a few column tiles, so its rows (G x 128 x K floats: 2 MB of dhid at minibatch 8192)
+  // stay in its L2 for the whole launch and every 64-column slice of W passes through once.  Column
+  // tiles innermost (the MODE 1 walk) cycled all of W (6.4 MB > the 4 MB L2) once per row group:
+  // fc_dgrad fetched 484 MB for 126 MB of operands.
+  int rows_inner, groups_per_xcd;
+  FastDiv div_groups;
   int TA, TB, PA, PB;  // run grid and the element pitch of a step in ta / tb (see Cursor)
   // MODE 0: the K steps of a tile in the order they are walked (element offsets into the input
   // window and into a row of Wp).  The order is free (any permutation of the K axis); the
@@ -121,8 +129,12 @@ __device__ __forceinline__ void open_tile(Cursor &c, const NtpArgs &p) {
   } else {
     const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
     const uint32_t u = (blockIdx.x >> 3) + c.i * per;
-    const uint32_t gl = fdiv(u, g.div_img);
+    uint32_t gl = fdiv(u, g.div_img);
     c.pix = u - gl * g.OHW;
+    if (MODE == 2 && p.rows_inner) {
+      c.pix = fdiv(u, p.div_groups);
+      gl = u - c.pix * p.groups_per_xcd;
+    }
     c.tile = gl * 8 + xcd;
     c.valid = u < static_cast<uint32_t>(p.tiles_per_xcd) && c.tile < p.ngroups;
     if (MODE == 2) {  // plain rows: the "pixel" is the column tile, one run of K elements
@@ -441,6 +453,12 @@ int ntp_min_tiles() {
   return v;
 }
 
+bool rows_inner_on() {  // DX_NTP_ROWS_INNER=0: the linear layer's tiles walked column tiles innermost
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_NTP_ROWS_INNER"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 bool ntp_small_on() {  // DX_NTP_SMALL=0: rollout-sized forward stages on the latency kernels
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_NTP_SMALL"); v = e ? atoi(e) : 1; }
@@ -551,7 +569,8 @@ int launch_ntp_fwd(const NTArgs &a, int stage, hipStream_t stream) {
   DX_REQUIRE(aligned(g.src, 16) && aligned(a.Wp, 16) && g.C % 4 == 0, "ntp: operands must be 16-byte aligned");
   NtpArgs p;
   p.nt = a;
-  p.nimg = p.ngroups = p.tiles_per_xcd = p.diag = 0;
+  p.nimg = p.ngroups = p.tiles_per_xcd = p.diag = p.rows_inner = 0;
+  p.groups_per_xcd = 1; p.div_groups = make_fastdiv(1);
   p.TA = g.nseg; p.TB = 1; p.PA = g.nseg > 1 ? g.seg_off[1] : 0; p.PB = 0;
   const int per_run = g.seglen / kBK, taps_per_run = g.seglen / g.C, steps_per_tap = g.C / kBK;
   p.nstep = g.nseg * per_run;
@@ -601,7 +620,8 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
   DX_REQUIRE(aligned(g.src, 16) && aligned(a.Wp, 16) && g.C % 4 == 0, "ntp: operands must be 16-byte aligned");
   NtpArgs p;
   p.nt = a;
-  p.ntiles = p.diag = 0;
+  p.ntiles = p.diag = p.rows_inner = 0;
+  p.groups_per_xcd = 1; p.div_groups = make_fastdiv(1);
   p.TA = TA; p.TB = TB; p.PA = g.seg_off[TB]; p.PB = g.seg_off[1];
   p.nimg = nimg;
   p.ngroups = nimg / (large ? ShapeL::BM : ShapeS::BM);
@@ -634,6 +654,12 @@ int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, 
   p.nimg = M;
   p.ngroups = M / ShapeS::BM;
   p.tiles_per_xcd = cdiv(p.ngroups, 8) * gn;
+  // the dgrad only (measured, profiles/r03_pmc_traffic.json: fc_dgrad FETCH 484 -> 263 MB; the forward,
+  // whose row blocks (128 x 3136 floats) are the bigger operand, went 155 -> 218 MB and keeps the old walk);
+  // every XCD must own the same number of row groups
+  p.rows_inner = mask != nullptr && p.ngroups % 8 == 0 && rows_inner_on();
+  p.groups_per_xcd = p.ngroups / 8 > 0 ? p.ngroups / 8 : 1;
+  p.div_groups = make_fastdiv(p.groups_per_xcd);
   return mask ? launch_as<ST_FC_DGRAD, 2, EPI_MASK, ShapeS>(p, stream) : launch_as<ST_FC_FWD, 2, EPI_BIAS, ShapeF>(p, stream);
 }
 

@@ -38,6 +38,9 @@ extern "C" {
 
 int dx_abi_version(void);
 const char *dx_last_error(void);
+/* Kernels this library has launched in this process so far (every entry point counts its own
+ * launches; RCCL's and the caller's are not included): measurement aid, e.g. launches per update. */
+long long dx_launch_count(void);
 /* name_host: buffer of >= 256 bytes; cu_count/lds_bytes may be NULL. */
 int dx_device_info(int device, char *name_host, int *cu_count, int *lds_bytes);
 
