@@ -52,6 +52,7 @@ SIGNATURES = {
     "dx_mlp_forward": [P, P, c_int, P],
     "dx_mlp_backward": [P, c_int, P],
     "dx_mlp_ppo_epoch": [P, P, P],
+    "dx_mlp_persist_plan": [P, c_int, c_longlong, P, P],
     "dx_normal_act_f32": [P, P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
     "dx_normal_loss_f32": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
                            c_longlong, P, P, P, c_int, P, P],
@@ -176,7 +177,8 @@ class MlpEpoch(ctypes.Structure):
       ("npartials", c_int), ("loss_partials_capacity", c_int), ("loss_partials", c_void_p),
       ("max_grad_norm", c_double), ("lr", c_double), ("beta1", c_double), ("beta2", c_double),
       ("adam_eps", c_double), ("first_step", c_longlong), ("grad_norm_out", c_void_p),
-      ("loss_out", c_void_p), ("grad_norm_stride", c_int), ("reserved0", c_int)]
+      ("loss_out", c_void_p), ("grad_norm_stride", c_int), ("persistent", c_int),
+      ("workspace", c_void_p), ("workspace_bytes", c_longlong), ("stats_all", c_void_p)]
 
 
 class CnnEpoch(ctypes.Structure):

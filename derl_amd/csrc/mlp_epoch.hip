@@ -9,6 +9,22 @@
 // rollout; ~120 us of Python per update made it host-bound).
 #include "common.hpp"
 
+namespace dx {
+long long mlp_persist_workspace_bytes(int G);
+int mlp_persist_workgroups(const dx_mlp_ctx *c, int mbsize, long long samples);
+int launch_mlp_persist_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, int G, hipStream_t stream);
+}  // namespace dx
+
+extern "C" int dx_mlp_persist_plan(const dx_mlp_ctx *c, int mbsize, long long samples, int *workgroups,
+                                   long long *workspace_bytes) {
+  DX_TRACE("dx_mlp_persist_plan");
+  DX_REQUIRE(c != nullptr && workgroups != nullptr && mbsize >= 1 && samples >= 1, "dx_mlp_persist_plan: bad arguments");
+  const int G = dx::mlp_persist_workgroups(c, mbsize, samples);
+  *workgroups = G;
+  if (workspace_bytes) *workspace_bytes = G > 0 ? dx::mlp_persist_workspace_bytes(G) : 0;
+  return DX_OK;
+}
+
 extern "C" int dx_mlp_ppo_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, void *stream) {
   DX_TRACE("dx_mlp_ppo_epoch");
   DX_REQUIRE(c != nullptr && e != nullptr, "dx_mlp_ppo_epoch: null argument");
@@ -24,6 +40,10 @@ extern "C" int dx_mlp_ppo_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, void
   DX_REQUIRE(e->mode == 1 || (e->old_log_prob && e->old_values), "dx_mlp_ppo_epoch: PPO needs the rollout's log_prob / values");
   DX_REQUIRE(c->has_logstd ? e->action_is_f32 == 1 : e->action_is_f32 == 0,
              "dx_mlp_ppo_epoch: Gaussian policies take float32 actions, categorical ones int64");
+  if (e->persistent && e->global_batch <= 0) {  // one persistent launch where the shape is covered
+    const int G = dx::mlp_persist_workgroups(c, e->mbsize, e->samples);
+    if (G > 0) return dx::launch_mlp_persist_epoch(c, e, G, dx::as_stream(stream));
+  }
   const int P = c->policy_out, D = c->obs_dim;
   int k = 0;
   for (long long start = 0; start < e->samples; start += e->mbsize, ++k) {

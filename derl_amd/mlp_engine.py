@@ -109,6 +109,8 @@ class MlpEngine:
     _lib.call("dx_mlp_backward", ctypes.byref(self.ctx), int(batch), _lib.stream_ptr(self.device))
     return self.grads
 
+  persistent_epochs = True  # False: the launch-per-stage epoch also where the persistent one applies
+
   def ppo_epoch(self, context, loss, optimizer, first_step, record_norms=False):
     """Enqueues every minibatch update of ``context`` (runners.onpolicy.EpochContext): advantage
     normalisation, forward, fused loss, backward, gradient norm, clip + Adam per minibatch, all
@@ -170,6 +172,20 @@ class MlpEngine:
     else:
       e.grad_norm_out, e.grad_norm_stride = optimizer.grad_norm.data_ptr(), 0
     e.loss_out = context.losses.data_ptr()
+    # the persistent form (one launch per epoch) where the library covers the shape
+    e.persistent = 0
+    if self.persistent_epochs:
+      groups, nbytes = ctypes.c_int(0), ctypes.c_longlong(0)
+      _lib.call("dx_mlp_persist_plan", ctypes.byref(self.ctx), int(mbsize), int(samples),
+                ctypes.byref(groups), ctypes.byref(nbytes))
+      if groups.value > 0:
+        if getattr(self, "_persist_ws", None) is None or self._persist_ws.numel() < nbytes.value:
+          self._persist_ws = torch.zeros(nbytes.value, dtype=torch.uint8, device=dev)
+        if getattr(self, "_persist_stats", None) is None or self._persist_stats.numel() < 3 * updates:
+          self._persist_stats = torch.empty(3 * updates, dtype=torch.float64, device=dev)
+        e.persistent = 1
+        e.workspace, e.workspace_bytes = self._persist_ws.data_ptr(), int(self._persist_ws.numel())
+        e.stats_all = self._persist_stats.data_ptr()
     keep = (obs, actions, old_lp, old_v, adv, vt)  # alive until the call has been enqueued
     _lib.call("dx_mlp_ppo_epoch", ctypes.byref(self.ctx), ctypes.byref(e), _lib.stream_ptr(dev))
     del keep

@@ -32,6 +32,8 @@ class EpochContext:
     self.losses = None      # (minibatches, 8) loss terms, filled by the native epoch
     self.grad_norms = None  # (minibatches,) pre-clip gradient norms when summaries are recorded
     self.stats_ready = None  # (minibatches, 3) global advantage statistics of a sharded run
+    self.verified = None     # set by the trainer once minibatch 0 passed its pointer comparison
+    self.loss_rows = self.loss_scalars = None  # per-minibatch views of ``losses``
     # Written by NormalizeAdvantages when it normalises the epoch's FIRST minibatch: its epsilon
     # and the tensor it produced.  That is how the transform opts in to the native epoch: the
     # trainer normalises the remaining minibatches the same way only if these are set and the
@@ -40,6 +42,102 @@ class EpochContext:
     self.norm_eps = None
     self.norm_first = None
     self.normalized = None  # every minibatch's normalised advantages, filled by the native epoch
+
+
+class LazyMinibatch(dict):
+  """A minibatch dict whose values are cut out of the epoch's arrays on first access.
+
+  ``IterateWithMinibatches`` yields 320 of these per rollout at BASELINE config 3; building seven
+  tensor views each cost more host time than the GPU spends on the update.  Reads behave like a
+  plain dict (a pending value is produced by its thunk the first time it is looked at; iteration,
+  ``items()`` ... produce them all).  ``touched`` records any assignment or deletion from outside
+  -- a transform that edits the minibatch -- which sends the trainer down its checked path;
+  ``lazy_set`` is for transforms that supply a derived value without forcing it."""
+  __slots__ = ("_pending", "touched", "rows", "epoch")
+
+  def __init__(self, pending, rows=None, epoch=None):
+    super().__init__()
+    self._pending = pending
+    self.touched = False
+    self.rows = rows    # (start, stop) inside the epoch's arrays
+    self.epoch = epoch  # (EpochContext, minibatch number)
+
+  def _force(self, key):
+    thunk = self._pending.pop(key, None)
+    if thunk is not None:
+      dict.__setitem__(self, key, thunk())
+
+  def _force_all(self):
+    for key in list(self._pending):
+      self._force(key)
+
+  def lazy_set(self, key, thunk):
+    dict.pop(self, key, None)
+    self._pending[key] = thunk
+
+  def __getitem__(self, key):
+    if key in self._pending:
+      self._force(key)
+    return dict.__getitem__(self, key)
+
+  def get(self, key, default=None):
+    if key in self._pending:
+      self._force(key)
+    return dict.get(self, key, default)
+
+  def __contains__(self, key):
+    return key in self._pending or dict.__contains__(self, key)
+
+  def __setitem__(self, key, value):
+    self._pending.pop(key, None)
+    self.touched = True
+    dict.__setitem__(self, key, value)
+
+  def __delitem__(self, key):
+    self.touched = True
+    if self._pending.pop(key, None) is None:
+      dict.__delitem__(self, key)
+
+  def pop(self, key, *default):
+    self.touched = True
+    self._force(key)
+    return dict.pop(self, key, *default)
+
+  def setdefault(self, key, default=None):
+    if key not in self:
+      self[key] = default
+    return self[key]
+
+  def update(self, *args, **kwargs):
+    for key, value in dict(*args, **kwargs).items():
+      self[key] = value
+
+  def __iter__(self):
+    self._force_all()
+    return dict.__iter__(self)
+
+  def __len__(self):
+    return dict.__len__(self) + len(self._pending)
+
+  def keys(self):
+    self._force_all()
+    return dict.keys(self)
+
+  def values(self):
+    self._force_all()
+    return dict.values(self)
+
+  def items(self):
+    self._force_all()
+    return dict.items(self)
+
+  def copy(self):
+    self._force_all()
+    return dict(self)
+
+  def __repr__(self):
+    self._force_all()
+    return dict.__repr__(self)
 
 
 class TransformInteractions(RunnerWrapper):
@@ -53,7 +151,7 @@ class TransformInteractions(RunnerWrapper):
 
   def run(self, obs=None):
     for interactions in self.runner.run(obs=obs):
-      if self.asarray:
+      if self.asarray and not isinstance(interactions, LazyMinibatch):  # (a minibatch holds no per-step lists)
         for key, val in interactions.items():
           if key == "state" or not isinstance(val, list):
             continue
@@ -92,6 +190,7 @@ class IterateWithMinibatches(RunnerWrapper):
     # two pinned staging buffers used in turn: the upload of rollout n + 1's permutations never
     # waits for the GPU to have read rollout n's (one buffer capped the host's run-ahead at one rollout)
     self._pinned, self._pinned_event, self._pinned_turn = [None, None], [None, None], 0
+    self._worker = None  # draws the next rollout's permutations ahead (see _prefetch_allowed)
 
   @staticmethod
   def _gather_epoch(interactions, order_dev):
@@ -107,35 +206,46 @@ class IterateWithMinibatches(RunnerWrapper):
     return dict(zip(small, gathered))
 
   @staticmethod
-  def _select_all(interactions, shuffled, start, stop, index_dev, index_host):
+  def _select_all(interactions, shuffled, start, stop, order_dev, order):
     """One minibatch of every array: slices of the epoch's permuted small arrays, lazy index
-    references for arrays with big rows (frames), fancy indexing for host arrays."""
-    out = {}
+    references for arrays with big rows (frames), fancy indexing for host arrays -- each produced
+    when it is first looked at (LazyMinibatch)."""
+    pending = {}
+    plain = {}
     for key, val in interactions.items():
       if key in shuffled:
-        out[key] = shuffled[key][start:stop]
+        pending[key] = lambda a=shuffled[key]: a[start:stop]
       elif key == "state":
-        out[key] = val
+        plain[key] = val
       elif isinstance(val, torch.Tensor) and val.is_cuda:
-        out[key] = GatheredRows(val, index_dev)
+        pending[key] = lambda v=val: GatheredRows(v, order_dev[start:stop])
       elif isinstance(val, torch.Tensor):
-        out[key] = val[torch.from_numpy(index_host.astype(np.int64))]
+        pending[key] = lambda v=val: v[torch.from_numpy(order[start:stop].astype(np.int64))]
       elif isinstance(val, np.ndarray):
-        out[key] = val[index_host]
+        pending[key] = lambda v=val: v[order[start:stop]]
       else:
-        out[key] = val
+        plain[key] = val
+    out = LazyMinibatch(pending, rows=(start, stop))
+    for key, val in plain.items():
+      dict.__setitem__(out, key, val)
     return out
 
-  def _draw_orders(self, sample_size, device):
-    """The composed permutations of all epochs (nothing else consumes np.random between the
-    reference's per-epoch draws, so the stream is identical) and, for device data, their upload
-    with ONE pinned non-blocking copy: a pageable H2D copy per epoch would drain the stream."""
+  def _draw_host(self, sample_size):
+    """The composed permutations of all epochs: the reference's per-epoch ``np.random.permutation``
+    draws (nothing else consumes np.random between them, so the stream is identical)."""
     order = np.arange(sample_size)
     orders = []
     for _ in range(self.num_epochs):
       if self.shuffle_before_epoch:
         order = order[np.random.permutation(sample_size)]
       orders.append(order)
+    return orders
+
+  def _draw_orders(self, sample_size, device, orders=None):
+    """``_draw_host`` (unless the permutations were drawn ahead) and, for device data, their upload
+    with ONE pinned non-blocking copy: a pageable H2D copy per epoch would drain the stream."""
+    if orders is None:
+      orders = self._draw_host(sample_size)
     orders_dev = None
     if device is not None:
       shape = (self.num_epochs, sample_size)
@@ -152,8 +262,9 @@ class IterateWithMinibatches(RunnerWrapper):
     return sample_size, device, orders, orders_dev
 
   def _prefetch_allowed(self):
-    """The permutations of the NEXT rollout may be drawn while the GPU still works on the current
-    one (otherwise it idles ~1.5 ms per PPO iteration behind np.random.permutation) only if that
+    """The permutations of the NEXT rollout may be drawn ahead -- on a worker thread, while this
+    thread enqueues the current rollout's updates (numpy's permutation releases the GIL; at config
+    3's 131,072 samples x 10 epochs the draws are 11 ms of a 25 ms iteration) -- only if that
     cannot reorder the global np.random stream against the reference's: the runner is
     device-resident AND the env declares ``host_rng_free`` (the built-in synthetic envs; a host
     env behind HostEnvBridge / ParallelEnvBatch may draw from np.random inside ``step``, and then
@@ -167,14 +278,13 @@ class IterateWithMinibatches(RunnerWrapper):
 
   def run(self, obs=None):
     inner = self.runner.run(obs=obs)
-    last = None  # (sample_size, device) of the previous rollout
+    ahead = None  # (sample_size, future of the NEXT rollout's permutations)
     while True:
-      drawn = None
-      if last is not None and self._prefetch_allowed():
-        drawn = self._draw_orders(*last)
       try:
         interactions = next(inner)
       except StopIteration:
+        if ahead is not None:
+          ahead[1].result()  # never leave a draw running behind the caller's back
         return
       sample_size = interactions["observations"].shape[0]
       device = None
@@ -182,10 +292,19 @@ class IterateWithMinibatches(RunnerWrapper):
         if isinstance(val, torch.Tensor) and val.is_cuda:
           device = val.device
           break
-      if drawn is None or drawn[0] != sample_size or drawn[1] != device:
-        drawn = self._draw_orders(sample_size, device)
-      last = (sample_size, device)
-      _, _, orders, orders_dev = drawn
+      host_orders = None
+      if ahead is not None:
+        drawn_for, future = ahead
+        host_orders = future.result()
+        ahead = None
+        if drawn_for != sample_size:  # cannot happen with a fixed horizon; the draw is consumed either way
+          host_orders = None
+      _, _, orders, orders_dev = self._draw_orders(sample_size, device, host_orders)
+      if self._prefetch_allowed():
+        if self._worker is None:
+          from concurrent.futures import ThreadPoolExecutor  # pylint: disable=import-outside-toplevel
+          self._worker = ThreadPoolExecutor(1)
+        ahead = (sample_size, self._worker.submit(self._draw_host, sample_size))
       mbsize = sample_size // self.num_minibatches
       extras = None
       if self.prepare is not None and orders_dev is not None:
@@ -202,14 +321,15 @@ class IterateWithMinibatches(RunnerWrapper):
             context.stats_ready = getattr(extras, "epoch_stats", lambda _: None)(epoch)
         for start in range(0, sample_size, mbsize):
           stop = min(start + mbsize, sample_size)
-          index_host = order[start:stop]
-          index_dev = order_dev[start:stop] if order_dev is not None else None
-          minibatch = self._select_all(interactions, shuffled, start, stop, index_dev, index_host)
+          minibatch = self._select_all(interactions, shuffled, start, stop, order_dev, order)
+          state = dict.get(minibatch, "state")
           if extras is not None:
-            minibatch["state"] = dict(minibatch.get("state") or {}, **extras(epoch, start // mbsize))
+            state = dict(state or {}, **extras(epoch, start // mbsize))
           if context is not None:
-            minibatch["state"] = dict(minibatch.get("state") or {},
-                                      **{EpochContext.STATE_KEY: (context, start // mbsize)})
+            minibatch.epoch = (context, start // mbsize)
+            state = dict(state or {}, **{EpochContext.STATE_KEY: minibatch.epoch})
+          if state is not None:
+            dict.__setitem__(minibatch, "state", state)  # (the iterator's own entry: not an outside edit)
           yield minibatch
 
 

@@ -116,18 +116,24 @@ class NormalizeAdvantages:
     return extras
 
   def __call__(self, trajectory):
-    advantages = trajectory["advantages"]
-    if not isinstance(advantages, torch.Tensor) or not advantages.is_cuda:
-      advantages = to_device(advantages, torch.device("cuda"), torch.float32)
-    flat = advantages.reshape(-1)
     state = trajectory.get("state")
     epoch = state.get("epoch") if isinstance(state, dict) else None
     if epoch is not None and epoch[0].normalized is not None and epoch[0].norm_eps == self.epsilon:
       # the trainer enqueued this epoch's updates natively and normalised every minibatch on the way
       context, k = epoch
+      lazy = getattr(trajectory, "lazy_set", None)
+      if lazy is not None and not trajectory.touched and trajectory.rows is not None:
+        first, stop = trajectory.rows  # a LazyMinibatch straight from the iterator: nothing is cut yet
+        lazy("advantages", lambda: context.normalized[first:stop])
+        return
+      advantages = trajectory["advantages"]
       start = k * context.mbsize
-      trajectory["advantages"] = context.normalized[start:start + flat.numel()].reshape(advantages.shape)
+      trajectory["advantages"] = context.normalized[start:start + advantages.numel()].reshape(advantages.shape)
       return
+    advantages = trajectory["advantages"]
+    if not isinstance(advantages, torch.Tensor) or not advantages.is_cuda:
+      advantages = to_device(advantages, torch.device("cuda"), torch.float32)
+    flat = advantages.reshape(-1)
     first_of_epoch = epoch is not None and epoch[1] == 0 and not epoch[0].consumed
     ready = state.get(self.STATE_KEY) if isinstance(state, dict) else None
     if ready is not None:

@@ -393,9 +393,23 @@ typedef struct dx_mlp_epoch {
   float *grad_norm_out;        /* pre-clip norms (see grad_norm_stride), or NULL          */
   float *loss_out;             /* (ceil(samples / mbsize), 8)                             */
   int grad_norm_stride;        /* 0: grad_norm_out[0] = the last minibatch's; 1: one each */
-  int reserved0;
+  int persistent;              /* 1: ONE persistent launch for the whole epoch where
+                                  dx_mlp_persist_plan covers the shape (see below)        */
+  void *workspace;             /* persistent epoch: workspace_bytes from dx_mlp_persist_plan */
+  long long workspace_bytes;
+  double *stats_all;           /* persistent epoch with normalize: (minibatches, 3) scratch */
 } dx_mlp_epoch;
 int dx_mlp_ppo_epoch(const dx_mlp_ctx *ctx, const dx_mlp_epoch *epoch, void *stream);
+/* The persistent form of the same epoch (csrc/mlp_persist.hip): every workgroup keeps the whole
+ * model in LDS and its share of the Adam moments in registers; per minibatch forward / loss /
+ * backward of its row tiles -> slab, grid barrier, fixed-order slab reduction + |g|^2 partials, grid
+ * barrier, clip + Adam on every workgroup's own copy.  Two grid barriers per update instead of ~9
+ * dependent launches.  Results equal the launch-per-stage epoch to float32 rounding (other partition
+ * of the sums), not bit for bit.  Covered: Gaussian policy, obs_dim <= 32, >= 512-row minibatches,
+ * <= 64 minibatches, single process.  *workgroups = 0 when the shape is not covered (then
+ * `persistent` is ignored and the launch-per-stage epoch runs). */
+int dx_mlp_persist_plan(const dx_mlp_ctx *ctx, int mbsize, long long samples, int *workgroups_host,
+                        long long *workspace_bytes_host);
 
 /* Diagonal-Gaussian head -- replaces Independent(Normal(mean, exp(logstd)), 1) of
  * derl/policies.py:40-42,66,76-77 and the PPO/A2C loss on it (derl/alg/ppo.py:24-108) with

@@ -262,3 +262,63 @@ def test_a2c_update_goes_through_the_native_call(nenvs):
   fast, slow = run(True), run(False)
   assert fast[3] == [1] * 6 and slow[3] == []
   assert fast[0] == slow[0] and torch.equal(fast[1], slow[1]) and torch.equal(fast[2], slow[2])
+
+
+def test_persistent_epoch_matches_launch_per_stage_epoch_and_oracle():
+  """The ONE-launch-per-epoch form (csrc/mlp_persist.hip: the model resident in LDS, two grid
+  barriers per update) against the launch-per-stage epoch on the same rollouts: other partition of
+  the gradient sums, so float32 rounding instead of bit equality -- losses 1e-5, parameters and Adam
+  moments 1e-6 after 2 rollouts x 2 epochs x 4 updates (866-row minibatches = 28 row tiles + a ragged
+  fourth of 2 rows) -- and against the CPU oracle stepping the first epoch's minibatches."""
+  import derl_amd as derl
+  nenvs, horizon, epochs, nmb, rollouts = 65, 40, 2, 3, 2
+
+  def go(persistent):
+    alg, calls = make_alg("gaussian", True, nenvs, horizon, epochs, nmb)
+    alg.model.engine.persistent_epochs = persistent
+    start = {k: v.detach().clone() for k, v in alg.model.state_dict().items()}
+    it = alg.runner.run()
+    losses, host, step_counts, after_first = [], [], [], None
+    for i in range(rollouts * epochs * 4):
+      data = next(it)
+      derl.summary.stop_recording()
+      if i == 4:
+        after_first = alg.model.engine.params.clone()
+      if i < 4:
+        host.append({k: v.cpu().numpy() for k, v in data.items() if isinstance(v, torch.Tensor)})
+        step_counts.append(alg.runner.step_count)
+      losses.append(alg.step(data).clone())
+    torch.cuda.synchronize()
+    opt = alg.trainer.optimizer
+    assert calls == [4] * (rollouts * epochs)
+    return dict(alg=alg, start=start, losses=torch.stack(losses).cpu().numpy(), host=host, step_counts=step_counts,
+                params=alg.model.engine.params.cpu().numpy(), m=opt.exp_avg.cpu().numpy(),
+                v=opt.exp_avg_sq.cpu().numpy(), after_first=after_first,
+                used=getattr(alg.model.engine, "_persist_ws", None) is not None)
+
+  fast, slow = go(True), go(False)
+  assert fast["used"] and not slow["used"], "the persistent epoch was not taken"
+  assert np.all(np.isfinite(fast["losses"])), "a grid barrier timed out"
+  nt.assert_allclose(fast["losses"], slow["losses"], rtol=1e-5, atol=1e-6)
+  nt.assert_allclose(fast["params"], slow["params"], rtol=0, atol=1e-6)
+  nt.assert_allclose(fast["m"], slow["m"], rtol=1e-4, atol=1e-8)
+  nt.assert_allclose(fast["v"], slow["v"], rtol=1e-4, atol=1e-10)
+  for a, b in zip(fast["host"], slow["host"]):  # the same minibatches, the same normalised advantages
+    for key in a:
+      nt.assert_array_equal(a[key], b[key], err_msg=key)
+  alg = fast["alg"]
+  names = [k for k, _ in alg.model.named_parameters()]
+  params = {k: v.cpu().numpy().astype(np.float32).copy() for k, v in fast["start"].items()}
+  state = {k: dict(m=np.zeros_like(v), v=np.zeros_like(v)) for k, v in params.items()}
+  for i, host in enumerate(fast["host"]):
+    assert host["actions"].shape[0] == (866 if i < 3 else 2)
+    terms, grads = oracle.ppo_loss_and_grads(params, host, "mlp", 0.2, 0.25, 0.01)
+    nt.assert_allclose(fast["losses"][i], terms["loss"], rtol=1e-4, atol=1e-5, err_msg=f"minibatch {i}")
+    clipped, _ = oracle.clip_grad_norm([grads[k] for k in names], 0.5)
+    lr = oracle.linear_anneal(3e-4, nenvs * horizon * 4, fast["step_counts"][i])
+    for k, g in zip(names, clipped):
+      params[k], state[k]["m"], state[k]["v"] = oracle.adam_step(
+          params[k], g, state[k]["m"], state[k]["v"], i + 1, lr, eps=1e-5)
+  got = alg.model.engine.named_views(fast["after_first"])
+  for k in names:
+    nt.assert_allclose(got[k].cpu().numpy(), params[k], rtol=0, atol=5e-6, err_msg=k)

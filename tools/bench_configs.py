@@ -94,9 +94,15 @@ def measure(name, iters, warmup=2, budget_s=None):
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
   launches = _lib.load().dx_launch_count() - launches0
+  # what one iteration costs the host when the queue is empty (nothing makes the enqueue calls wait)
+  t1 = time.perf_counter()
+  iteration()
+  unblocked = time.perf_counter() - t1
+  torch.cuda.synchronize()
   out = dict(config=name, env_steps_per_s=round(iters * steps_per_iter / dt, 1),
              ms_per_iteration=round(dt / iters * 1e3, 3), iterations=iters,
-             host_enqueue_ms=round(enq / iters * 1e3, 3), updates_per_iteration=updates,
+             host_enqueue_ms=round(enq / iters * 1e3, 3), host_enqueue_ms_unblocked=round(unblocked * 1e3, 3),
+             updates_per_iteration=updates,
              library_launches_per_iteration=round(launches / iters, 1),
              loss=float(alg.loss_fn.last_terms[0].item()))
   out["roofline"] = bounds(name, steps_per_iter, updates, dt / iters)
