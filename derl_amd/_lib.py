@@ -35,6 +35,7 @@ SIGNATURES = {
                               c_double, c_double, c_longlong, P, P],
     "dx_clip_rmsprop_step_f32": [P, P, P, c_longlong, P, c_int, c_double, c_double, c_double,
                                  c_double, P, P],
+    "dx_host_compose_permutations": [P, P, c_longlong, c_int, c_int, P],
     "dx_gather_rows": [P, P, P, c_longlong, c_longlong, P],
     "dx_gather_rows_multi": [P, P, P, c_int, P, c_longlong, P],
     "dx_reward_summary_f32": [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P, P],

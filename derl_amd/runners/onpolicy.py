@@ -1,8 +1,11 @@
 """On-policy runner wrappers (derl/runners/onpolicy.py:11-82)."""
+import ctypes
 import math
 
 import numpy as np
 import torch
+
+from .. import _lib
 
 from .env_runner import EnvRunner, RunnerWrapper
 from .summary import PeriodicSummaries
@@ -187,9 +190,10 @@ class IterateWithMinibatches(RunnerWrapper):
     # minibatch's "state": work over ALL minibatches of a rollout once their order is known
     # (NormalizeAdvantages.prepare: one all-reduce per rollout instead of one per minibatch)
     self.prepare = prepare
-    # two pinned staging buffers used in turn: the upload of rollout n + 1's permutations never
-    # waits for the GPU to have read rollout n's (one buffer capped the host's run-ahead at one rollout)
-    self._pinned, self._pinned_event, self._pinned_turn = [None, None], [None, None], 0
+    # three pinned staging buffers used in turn (the current rollout's, the one being drawn ahead, and
+    # one whose upload may still be in flight): a buffer is rewritten only after the upload that last
+    # read it has completed
+    self._pinned, self._pinned_event, self._pinned_turn = [None] * 3, [None] * 3, 0
     self._worker = None  # draws the next rollout's permutations ahead (see _prefetch_allowed)
 
   @staticmethod
@@ -230,35 +234,60 @@ class IterateWithMinibatches(RunnerWrapper):
       dict.__setitem__(out, key, val)
     return out
 
-  def _draw_host(self, sample_size):
-    """The composed permutations of all epochs: the reference's per-epoch ``np.random.permutation``
-    draws (nothing else consumes np.random between them, so the stream is identical)."""
-    order = np.arange(sample_size)
-    orders = []
-    for _ in range(self.num_epochs):
-      if self.shuffle_before_epoch:
-        order = order[np.random.permutation(sample_size)]
-      orders.append(order)
-    return orders
-
-  def _draw_orders(self, sample_size, device, orders=None):
-    """``_draw_host`` (unless the permutations were drawn ahead) and, for device data, their upload
-    with ONE pinned non-blocking copy: a pageable H2D copy per epoch would drain the stream."""
-    if orders is None:
-      orders = self._draw_host(sample_size)
-    orders_dev = None
-    if device is not None:
-      shape = (self.num_epochs, sample_size)
+  def _draw_host(self, sample_size, pinned=False):
+    """The composed permutations of all epochs as an (epochs, samples) int32 array: the reference's
+    per-epoch ``np.random.permutation`` draws (nothing else consumes np.random between them, so the
+    stream is identical), made by the native library from NumPy's own generator state
+    (dx_host_compose_permutations: bit-for-bit the NumPy result, and the call does not hold the
+    GIL, so a worker thread can really run beside the training loop).  ``pinned``: into the next
+    pinned staging buffer (a torch tensor; its previous upload is waited for first)."""
+    shape = (self.num_epochs, sample_size)
+    if pinned:
       turn = self._pinned_turn
-      self._pinned_turn = turn ^ 1
+      self._pinned_turn = (turn + 1) % len(self._pinned)
       if self._pinned[turn] is None or tuple(self._pinned[turn].shape) != shape:
         self._pinned[turn] = torch.empty(shape, dtype=torch.int32).pin_memory()
       elif self._pinned_event[turn] is not None:
-        self._pinned_event[turn].synchronize()  # the upload before last has read this buffer
-      np.stack(orders, out=self._pinned[turn].numpy(), casting="unsafe")
-      orders_dev = self._pinned[turn].to(device, non_blocking=True)
-      self._pinned_event[turn] = torch.cuda.Event()
-      self._pinned_event[turn].record(torch.cuda.current_stream(device))
+        self._pinned_event[turn].synchronize()  # the upload that last read this buffer is done
+      staging = self._pinned[turn]
+      out = staging.numpy()
+    else:
+      staging, turn = None, None
+      out = np.empty(shape, np.int32)
+    try:
+      lib = _lib.load()
+    except _lib.NativeError:
+      lib = None  # host-only use without the built library: NumPy's own calls (same stream, same result)
+    if lib is not None:
+      name, key, pos, has_gauss, cached = np.random.get_state()
+      key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+      position = ctypes.c_int(int(pos))
+      _lib.check(lib.dx_host_compose_permutations(
+          key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(position), int(sample_size), int(self.num_epochs),
+          int(bool(self.shuffle_before_epoch)), out.ctypes.data_as(ctypes.c_void_p)), "dx_host_compose_permutations")
+      np.random.set_state((name, key, position.value, has_gauss, cached))
+    else:
+      order = np.arange(sample_size)
+      for epoch in range(self.num_epochs):
+        if self.shuffle_before_epoch:
+          order = order[np.random.permutation(sample_size)]
+        out[epoch] = order
+    return out, staging, turn
+
+  def _draw_orders(self, sample_size, device, drawn=None):
+    """``_draw_host`` (unless the permutations were drawn ahead) and, for device data, their upload
+    with ONE pinned non-blocking copy: a pageable H2D copy per epoch would drain the stream."""
+    if drawn is None:
+      drawn = self._draw_host(sample_size, pinned=device is not None)
+    orders, staging, turn = drawn
+    orders_dev = None
+    if device is not None:
+      if staging is None:  # drawn without a staging buffer (cannot happen on the prefetch path)
+        staging = torch.from_numpy(orders).pin_memory()
+      orders_dev = staging.to(device, non_blocking=True)
+      if turn is not None:
+        self._pinned_event[turn] = torch.cuda.Event()
+        self._pinned_event[turn].record(torch.cuda.current_stream(device))
     return sample_size, device, orders, orders_dev
 
   def _prefetch_allowed(self):
@@ -292,19 +321,20 @@ class IterateWithMinibatches(RunnerWrapper):
         if isinstance(val, torch.Tensor) and val.is_cuda:
           device = val.device
           break
-      host_orders = None
+      drawn = None
       if ahead is not None:
         drawn_for, future = ahead
-        host_orders = future.result()
+        drawn = future.result()
         ahead = None
-        if drawn_for != sample_size:  # cannot happen with a fixed horizon; the draw is consumed either way
-          host_orders = None
-      _, _, orders, orders_dev = self._draw_orders(sample_size, device, host_orders)
+        if drawn_for != (sample_size, device is not None):  # cannot happen with a fixed horizon
+          drawn = None
+      _, _, orders, orders_dev = self._draw_orders(sample_size, device, drawn)
       if self._prefetch_allowed():
         if self._worker is None:
           from concurrent.futures import ThreadPoolExecutor  # pylint: disable=import-outside-toplevel
           self._worker = ThreadPoolExecutor(1)
-        ahead = (sample_size, self._worker.submit(self._draw_host, sample_size))
+        ahead = ((sample_size, device is not None),
+                 self._worker.submit(self._draw_host, sample_size, device is not None))
       mbsize = sample_size // self.num_minibatches
       extras = None
       if self.prepare is not None and orders_dev is not None:

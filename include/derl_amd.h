@@ -106,6 +106,16 @@ int dx_clip_rmsprop_step_f32(float *params, float *grads, float *square_avg, lon
                              const double *sumsq_partials, int npartials, double max_norm,
                              double lr, double alpha, double eps, float *norm_out, void *stream);
 
+/* The composed minibatch permutations of ALL epochs of a rollout -- the host side of
+ * derl/runners/onpolicy.py:44-49 (one np.random.permutation per epoch; the shuffles compose) --
+ * drawn from NumPy's legacy MT19937 stream without the Python GIL: mt_key_host (624 words) and
+ * *mt_pos_host are np.random.get_state()'s and are advanced in place (np.random.set_state puts
+ * them back), orders_out_host is (epochs, n) int32 with row e = the order of epoch e.  Bit-for-bit
+ * what `order = order[np.random.permutation(n)]` per epoch produces (tests/test_host_logic.py).
+ * Host memory only; no GPU work. */
+int dx_host_compose_permutations(uint32_t *mt_key_host, int *mt_pos_host, long long n, int epochs,
+                                 int shuffle, int32_t *orders_out_host);
+
 /* Row gather dst[i] = src[idx[i]] (rows of row_bytes bytes) -- the minibatch selection of
  * derl/runners/onpolicy.py:44-49,59-62 for the small per-sample arrays (frames are
  * gathered by index inside the conv loader instead of being copied). */

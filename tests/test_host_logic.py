@@ -167,3 +167,44 @@ def test_package_installs_with_launcher(tmp_path):
   where = subprocess.run([sys.executable, "-c", "import derl; print(derl.__file__)"], capture_output=True,
                          text=True, cwd=str(tmp_path), env=env, timeout=300)
   assert where.stdout.strip().startswith(str(target)), where.stdout + where.stderr
+
+
+def test_native_permutation_composer_is_numpy_bit_for_bit():
+  """dx_host_compose_permutations (csrc/host_permute.hip: MT19937 + NumPy's legacy shuffle restated
+  in C so that the draws do not hold the GIL) against `order = order[np.random.permutation(n)]` per
+  epoch (derl/runners/onpolicy.py:44-49) from the same generator state: the same orders AND the same
+  generator state afterwards, for sizes around the block boundary of the generator and BASELINE's
+  shapes."""
+  import ctypes
+  from derl_amd import _lib
+  lib = _lib.load()
+
+  def native(n, epochs):
+    name, key, pos, has_gauss, cached = np.random.get_state()
+    key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+    position = ctypes.c_int(int(pos))
+    out = np.empty((epochs, n), np.int32)
+    assert lib.dx_host_compose_permutations(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(position), n,
+                                            epochs, 1, out.ctypes.data_as(ctypes.c_void_p)) == 0
+    np.random.set_state((name, key, position.value, has_gauss, cached))
+    return out
+
+  def reference(n, epochs):
+    order, rows = np.arange(n), []
+    for _ in range(epochs):
+      order = order[np.random.permutation(n)]
+      rows.append(order)
+    return np.stack(rows)
+
+  for seed, n, epochs in [(0, 1, 2), (1, 2, 3), (5, 1024, 3), (7, 1030, 2), (3, 623, 5), (4, 625, 5),
+                          (11, 32768, 3), (13, 131072, 10)]:
+    np.random.seed(seed)
+    np.random.rand(seed % 7)  # start somewhere inside a block of 624 words
+    want = reference(n, epochs)
+    tail_want = np.random.randint(0, 1 << 30, 8)
+    np.random.seed(seed)
+    np.random.rand(seed % 7)
+    got = native(n, epochs)
+    tail_got = np.random.randint(0, 1 << 30, 8)
+    nt.assert_array_equal(got, want, err_msg=f"seed {seed} n {n}")
+    nt.assert_array_equal(tail_got, tail_want, err_msg="generator state after the draws")
