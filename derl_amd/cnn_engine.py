@@ -277,12 +277,13 @@ class CnnEngine:
     else:
       e.grad_norm_out, e.grad_norm_stride = optimizer.grad_norm.data_ptr(), 0
     e.loss_out = context.losses.data_ptr()
+    e.mirrors_current = int(self._packed_version == self._version())
     keep = (obs, index, actions, old_lp, old_v, adv, vt, stats_ready)  # alive until enqueued
     _lib.call("dx_cnn_ppo_epoch", ctypes.byref(self.ctx), ctypes.byref(e), _lib.stream_ptr(dev))
     del keep
     if record_norms:
       optimizer.grad_norm.copy_(context.grad_norms[-1:])
-    self._packed_version = self._version()  # the call ends with dx_cnn_pack
+    self._packed_version = self._version()  # every update inside the call is followed by dx_cnn_pack
     return updates
 
   @property

@@ -58,7 +58,10 @@ extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void
       if (int rc = dx_adv_normalize_f32(adv, norm, B, e->norm_eps, stats, e->stats_ready != nullptr, stream)) return rc;
       adv = norm;
     }
-    if (int rc = dx_cnn_pack(c, stream)) return rc;  // the previous update changed the parameters
+    // (after every update below the mirrors are repacked; the first minibatch needs a pack only when
+    // the caller's parameters changed since its last pack)
+    if (k == 0 && !e->mirrors_current)
+      if (int rc = dx_cnn_pack(c, stream)) return rc;
     const int32_t *idx = e->index ? e->index + start : nullptr;
     const void *obs = e->obs;
     if (!idx)  // no gather: minibatch k is rows [start, start + B) of obs
@@ -93,6 +96,8 @@ extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void
                                             e->npartials, e->max_grad_norm, e->lr, e->beta1, e->opt_eps, norm_out, stream))
         return rc;
     }
+    // the mirrors follow every update (after the last one: the next rollout can act at once)
+    if (int rc = dx_cnn_pack(c, stream)) return rc;
   }
-  return dx_cnn_pack(c, stream);  // the mirrors follow the last update: the next rollout can act at once
+  return DX_OK;
 }

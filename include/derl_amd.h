@@ -313,6 +313,9 @@ typedef struct dx_cnn_epoch {
   double *loss_partials;
   int loss_partials_capacity;
   int grad_norm_stride;        /* 0: grad_norm_out[0] = the last minibatch's; 1: one each   */
+  int mirrors_current;         /* 1: the packed mirrors match ctx->params (no pack before the
+                                  first minibatch; every update is followed by one)          */
+  int reserved0;
   double max_grad_norm;        /* <= 0: no clipping                                         */
   double lr, beta1, beta2, opt_eps;
   long long first_step;        /* Adam's step number of minibatch 0 (1-based)               */
