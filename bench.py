@@ -38,12 +38,12 @@ PEAK_HBM_GBPS = 8000.0
 
 
 def pmc_traffic(stage, minibatch):
-  """HBM bytes per launch of `stage` from the committed PMC passes (profiles/r02_pmc_traffic.json,
+  """HBM bytes per launch of `stage` from the committed PMC passes (profiles/r03_a_pmc_traffic.json,
   made by tools/pmc_passes.sh + tools/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
   separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes).  Counters cannot be read from
   inside this process, so the figure is the one measured at minibatch 8192 and only reported for
   that shape; otherwise null."""
-  path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+  path = os.path.join(ROOT, "profiles", "r03_a_pmc_traffic.json")
   if minibatch != 8192 or not os.path.exists(path):
     return None
   with open(path) as f:
