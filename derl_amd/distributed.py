@@ -10,6 +10,8 @@ bench's max-over-ranks -- nothing on the data path.
 
 Backend "gloo" is a REHEARSAL mode for boxes with fewer GPUs than ranks (RCCL refuses two ranks on
 one GPU): the same sharding rules with torch.distributed doing the reductions.
+``DERL_AMD_NATIVE_COMM=0`` keeps the library's communicator out (torch.distributed's RCCL
+collectives from Python, update by update: the round-2 path).
 ``DERL_AMD_FORCE_COLLECTIVES=1`` makes a single process take the sharded code path end to end
 (RCCL accepts a one-rank communicator): what the GPU suite uses to execute the RCCL branch on a
 one-GPU box."""
@@ -69,8 +71,13 @@ def init_from_env(backend=None):
   os.environ.setdefault("RANK", "0")
   os.environ.setdefault("WORLD_SIZE", "1")
   dist.init_process_group(backend=backend)
-  if backend == "nccl":
-    init_native_comm()
+  if backend == "nccl" and os.environ.get("DERL_AMD_NATIVE_COMM", "1") not in ("", "0"):
+    try:
+      init_native_comm()
+    except _lib.NativeError as error:
+      # every rank fails or succeeds alike (the id broadcast comes first); without the library's
+      # communicator the run continues on torch.distributed's own RCCL collectives, update by update
+      print(f"derl_amd: native RCCL communicator unavailable ({error}); using torch.distributed", flush=True)
   return world_size()
 
 
