@@ -95,6 +95,8 @@ def time_stages(model, obs, idx, batch, iters=10):
       launch(stage)
       marks[it][stage + 1].record()
   torch.cuda.synchronize()
+  lib = _lib.load()
+  time_stages.routes = {name: lib.dx_cnn_last_route(stage).decode() for stage, name in enumerate(STAGES)}
   return {name: sum(marks[it][stage].elapsed_time(marks[it][stage + 1]) for it in range(iters)) * 1e3 / iters
           for stage, name in enumerate(STAGES)}
 
@@ -293,7 +295,8 @@ def main():
 
     def stage_row(n):
       fl = stage_flops(n, mb, A)
-      row = {"train_us": round(train[n], 1),
+      row = {"route": getattr(time_stages, "routes", {}).get(n, ""),
+             "train_us": round(train[n], 1),
              "train_TFLOPs": round(fl / (train[n] * 1e-6) / 1e12, 2) if fl else None,
              "us_per_iteration": round(train[n] * updates_per_iter, 1)}
       if n in BF16X3_STAGES:

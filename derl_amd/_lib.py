@@ -63,6 +63,7 @@ SIGNATURES = {
     "dx_cnn_backward": [P, P, c_int, P, c_int, P],
     "dx_cnn_backward_part": [P, P, c_int, P, c_int, c_int, P],
     "dx_cnn_stage": [P, c_int, P, c_int, P, c_int, P],
+    "dx_cnn_last_route": [c_int],
     "dx_cnn_act": [P, P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
     "dx_cnn_rollout_synth": [P, P, c_int, c_int, P, P, P, P, P, c_uint64, c_uint64, c_uint64,
                              c_uint64, c_float, c_float, P],
@@ -93,7 +94,7 @@ class CnnCtx(ctypes.Structure):
                                           "pb_c2d", "pb_fcd", "pb_c0f")]
       + [(n, c_void_p) for n in ("params", "grads", "packed", "y0", "y1", "y2", "hid", "head",
                                  "dy0", "dy1", "dy2", "dhid", "dhead", "slabs", "hid_slabs")])
-_RESTYPES = {"dx_last_error": c_char_p, "dx_launch_count": c_longlong}
+_RESTYPES = {"dx_last_error": c_char_p, "dx_launch_count": c_longlong, "dx_cnn_last_route": c_char_p}
 
 _lib = None
 

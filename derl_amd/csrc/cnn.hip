@@ -113,6 +113,8 @@ bool nt_dma_on() {
   return v != 0;
 }
 
+const char *g_route[ST_COUNT] = {};  // kernel family of the last launch of every stage (run_stage)
+
 constexpr int kBiasChunks = 256;  // row chunks of the linear layer's bias-gradient launch (512 workgroups)
 
 int roundup(long long v, int m) { return static_cast<int>((v + m - 1) / m * m); }
@@ -464,6 +466,12 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     t.msplit = plan.s[layer].msplit; t.mper = plan.s[layer].mper;
     return launch_tn(t, u8, stage, s);
   };
+  // which kernel family ran this stage (dx_cnn_last_route: the perf guard against a batch silently
+  // leaving the ring / direct kernels, and what bench.py prints per stage)
+  auto took = [&](const char *family, int rc) {
+    if (rc != DX_ENOSUP && stage >= 0 && stage < ST_COUNT) g_route[stage] = family;
+    return rc;
+  };
   NTArgs a;
   switch (stage) {
     case ST_CONV0_FWD:
@@ -475,11 +483,11 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
         d.obs = static_cast<const uint8_t *>(obs); d.idx = sample_idx;
         d.in_h = c->in_h; d.in_w = c->in_w; d.h0 = c->h0; d.w0 = c->w0;
         d.M = static_cast<int>(M0); d.bias = w + c->off_b[0]; d.out = c->y0;
-        const int rc = launch_conv0_lat_b16(d, planes(c, c->pb_c0f), s);
+        const int rc = took("conv0_lat_b16", launch_conv0_lat_b16(d, planes(c, c->pb_c0f), s));
         if (rc != DX_ENOSUP) return rc;
       }
       if (obs_is_u8 && conv0_f32() && M0 <= 32LL * conv0_lat_max_tiles()) {  // fp32-MFMA latency kernel
-        const int rc = launch_nt_lat(a, true, EPI_BIAS_RELU, stage, s);
+        const int rc = took("igemm_lat", launch_nt_lat(a, true, EPI_BIAS_RELU, stage, s));
         if (rc != DX_ENOSUP) return rc;
       }
       if (obs_is_u8 && conv0_direct_supported(c->in_h, c->in_w, IC0, c->h0, c->w0)) {
@@ -489,21 +497,21 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
         d.in_h = c->in_h; d.in_w = c->in_w; d.h0 = c->h0; d.w0 = c->w0;
         d.M = static_cast<int>(M0); d.ntiles = static_cast<int>((M0 + 255) / 256);
         d.Wp = pk + c->pk_c0f; d.bias = w + c->off_b[0]; d.out = c->y0;
-        return conv0_f32() ? launch_conv0_fwd(d, s) : launch_conv0_fwd_b16(d, s);
+        return conv0_f32() ? took("conv0_f32", launch_conv0_fwd(d, s)) : took("conv0_b16", launch_conv0_fwd_b16(d, s));
       }
-      return launch_nt(a, obs_is_u8 != 0, EPI_BIAS_RELU, stage, s);
+      return took("igemm_nt", launch_nt(a, obs_is_u8 != 0, EPI_BIAS_RELU, stage, s));
     case ST_CONV1_FWD:
       a = nt_args(conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), pk + c->pk_c1f,
                   w + c->off_b[1], c->y1, kC1, M1, kC1, 16 * kC0);
       a.Wb = planes(c, c->pb_c1f); a.wb_plane = kC1 * 16LL * kC0;
-      if (const int rc = launch_ntp_fwd(a, stage, s); rc != DX_ENOSUP) return rc;
-      return launch_nt(a, false, EPI_BIAS_RELU, stage, s);
+      if (const int rc = took("ntp", launch_ntp_fwd(a, stage, s)); rc != DX_ENOSUP) return rc;
+      return took("igemm_nt", launch_nt(a, false, EPI_BIAS_RELU, stage, s));
     case ST_CONV2_FWD:
       a = nt_args(conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), pk + c->pk_c2f,
                   w + c->off_b[2], c->y2, kC2, M2, kC2, 9 * kC1);
       a.Wb = planes(c, c->pb_c2f); a.wb_plane = kC2 * 9LL * kC1;
-      if (const int rc = launch_ntp_fwd(a, stage, s); rc != DX_ENOSUP) return rc;
-      return launch_nt(a, false, EPI_BIAS_RELU, stage, s);
+      if (const int rc = took("ntp", launch_ntp_fwd(a, stage, s)); rc != DX_ENOSUP) return rc;
+      return took("igemm_nt", launch_nt(a, false, EPI_BIAS_RELU, stage, s));
     case ST_FC_FWD: {
       // small minibatches (multi-GPU shards): 49 sequential 64-deep K steps on 128 workgroups are
       // a latency chain; split K 7 ways into the rollout slabs and sum them into hid
@@ -514,15 +522,15 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a.ksplit = ks;
       a.slab_stride = static_cast<long long>(B) * kHid;
       if (ks == 1 && ntp_fc_fwd()) {
-        if (const int rc = launch_ntp_rows(c->y2, flat, pk + c->pk_fcf, nullptr, w + c->off_b[3], c->hid, B, kHid, flat, s);
+        if (const int rc = took("ntp", launch_ntp_rows(c->y2, flat, pk + c->pk_fcf, nullptr, w + c->off_b[3], c->hid, B, kHid, flat, s));
             rc != DX_ENOSUP)
           return rc;
       }
       if (ks == 1 && nt_dma_on() && nt_dma_supported(B, kHid, flat)) {
         const NtDmaArgs d{c->y2, pk + c->pk_fcf, w + c->off_b[3], nullptr, c->hid, B, kHid, flat, flat, kHid};
-        return launch_nt_dma(d, EPI_BIAS, s);
+        return took("nt_dma", launch_nt_dma(d, EPI_BIAS, s));
       }
-      if (int rc = launch_nt(a, false, EPI_BIAS, stage, s)) return rc;
+      if (int rc = took(ks > 1 ? "igemm_nt split-K" : "igemm_nt", launch_nt(a, false, EPI_BIAS, stage, s))) return rc;
       if (ks == 1) return DX_OK;
       PermuteJob jr{c->hid_slabs, c->hid, static_cast<long long>(B) * kHid, 1, 1, 1, 1, 0, 0, 0, 0, ks,
                     static_cast<long long>(B) * kHid, 0};
@@ -530,54 +538,54 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     }
     case ST_HEADS_FWD:
       a = nt_args(rows_gather(c->hid, kHid), pk + c->pk_hdf, pk + c->pk_hdb, c->head, kHeadLd, B, kHeadLd, kHid);
-      return launch_nt(a, false, EPI_BIAS, stage, s);
+      return took("igemm_nt", launch_nt(a, false, EPI_BIAS, stage, s));
     case ST_HEADS_WGRAD:
-      return tn(L_HD, rows_gather(c->hid, kHid), c->dhead, kHeadLd, B, kHeadLd, kHid, false);
+      return took("igemm_tn", tn(L_HD, rows_gather(c->hid, kHid), c->dhead, kHeadLd, B, kHeadLd, kHid, false));
     case ST_HEADS_DGRAD:
       a = nt_args(rows_gather(c->dhead, kHeadLd), pk + c->pk_hdd, nullptr, c->dhid, kHid, B, kHid, kHeadLd);
-      return launch_nt(a, false, EPI_NONE, stage, s);
+      return took("igemm_nt", launch_nt(a, false, EPI_NONE, stage, s));
     case ST_FC_WGRAD:
       if (plan.s[L_FC].direct) {
         if (int rc = launch_colsum(c->dhid, c->slabs + plan.s[L_FC].b_off, B, kHid, plan.s[L_FC].bsplit, s)) return rc;
         const FcWgradArgs d{c->dhid, c->y2, c->slabs + plan.s[L_FC].w_off, B, flat, plan.s[L_FC].msplit, 0, 0};
-        return launch_fc_wgrad(d, s);
+        return took("wgrad_fc", launch_fc_wgrad(d, s));
       }
-      return tn(L_FC, rows_gather(c->y2, flat), c->dhid, kHid, B, kHid, flat, false);
+      return took("igemm_tn", tn(L_FC, rows_gather(c->y2, flat), c->dhid, kHid, B, kHid, flat, false));
     case ST_FC_DGRAD:
-      if (const int rc = launch_ntp_rows(c->dhid, kHid, pk + c->pk_fcd, c->y2, nullptr, c->dy2, B, flat, kHid, s); rc != DX_ENOSUP)
+      if (const int rc = took("ntp", launch_ntp_rows(c->dhid, kHid, pk + c->pk_fcd, c->y2, nullptr, c->dy2, B, flat, kHid, s)); rc != DX_ENOSUP)
         return rc;
       if (nt_dma_on() && nt_dma_supported(B, flat, kHid)) {
         const NtDmaArgs d{c->dhid, pk + c->pk_fcd, nullptr, c->y2, c->dy2, B, flat, kHid, kHid, flat};
-        return launch_nt_dma(d, EPI_MASK, s);
+        return took("nt_dma", launch_nt_dma(d, EPI_MASK, s));
       }
       a = nt_args(rows_gather(c->dhid, kHid), pk + c->pk_fcd, nullptr, c->dy2, flat, B, flat, kHid);
       a.Wb = planes(c, c->pb_fcd); a.wb_plane = static_cast<long long>(kHid) * flat;
       a.mask_src = c->y2;
-      return launch_nt(a, false, EPI_MASK, stage, s);
+      return took("igemm_nt", launch_nt(a, false, EPI_MASK, stage, s));
     case ST_CONV2_WGRAD:
       if (plan.s[L_C2].direct) {
         const WgradDirectArgs d{c->y1, c->dy2, c->slabs + plan.s[L_C2].w_off, c->slabs + plan.s[L_C2].b_off,
                                 B, c->h1, c->w1, c->h2, c->w2, 0};
-        return launch_wgrad_direct(d, stage, plan.s[L_C2].msplit, s);
+        return took("wgrad_direct", launch_wgrad_direct(d, stage, plan.s[L_C2].msplit, s));
       }
-      return tn(L_C2, conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), c->dy2, kC2, M2,
-                kC2, 9 * kC1, false);
+      return took("igemm_tn", tn(L_C2, conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), c->dy2, kC2, M2,
+                                  kC2, 9 * kC1, false));
     case ST_CONV2_DGRAD:
       a = nt_args(dgrad_gather(c->dy2, c->h2, c->w2, kC2, c->h1, c->w1, 3, 3), pk + c->pk_c2d, nullptr,
                   c->dy1, kC1, M1, kC1, 9 * kC2);
       a.Wb = planes(c, c->pb_c2d); a.wb_plane = kC2 * 9LL * kC1;
       a.mask_src = c->y1;
-      if (const int rc = launch_ntp_pix(a, B, 3, 3, s); rc != DX_ENOSUP) return rc;
-      if (const int rc = launch_nt_pix(a, B, EPI_MASK, stage, s); rc != DX_ENOSUP) return rc;
-      return launch_nt(a, false, EPI_MASK, stage, s);
+      if (const int rc = took("ntp", launch_ntp_pix(a, B, 3, 3, s)); rc != DX_ENOSUP) return rc;
+      if (const int rc = took("igemm_pix", launch_nt_pix(a, B, EPI_MASK, stage, s)); rc != DX_ENOSUP) return rc;
+      return took("igemm_nt", launch_nt(a, false, EPI_MASK, stage, s));
     case ST_CONV1_WGRAD:
       if (plan.s[L_C1].direct) {
         const WgradDirectArgs d{c->y0, c->dy1, c->slabs + plan.s[L_C1].w_off, c->slabs + plan.s[L_C1].b_off,
                                 B, c->h0, c->w0, c->h1, c->w1, 0};
-        return launch_wgrad_direct(d, stage, plan.s[L_C1].msplit, s);
+        return took("wgrad_direct", launch_wgrad_direct(d, stage, plan.s[L_C1].msplit, s));
       }
-      return tn(L_C1, conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), c->dy1, kC1, M1,
-                kC1, 16 * kC0, false);
+      return took("igemm_tn", tn(L_C1, conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), c->dy1, kC1, M1,
+                                  kC1, 16 * kC0, false));
     case ST_CONV1_DGRAD: {
       // 4x4 stride-2 conv: input pixel (2y'+py, 2x'+px) receives taps kh = py+2a, kw = px+2b from
       // output-gradient pixel (y'-a, x'-b) for every parity (py,px), so the four parity classes
@@ -592,9 +600,9 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a.om.OHW = OHp * OWp; a.om.OW = OWp;
       a.om.div_img = make_fastdiv(a.om.OHW); a.om.div_row = make_fastdiv(OWp);
       a.om.OUT_H = c->h0; a.om.OUT_W = c->w0; a.om.osy = a.om.osx = 2; a.om.chan = kC0;
-      if (const int rc = launch_ntp_pix(a, B, 2, 2, s); rc != DX_ENOSUP) return rc;
-      if (const int rc = launch_nt_pix(a, B, EPI_MASK, stage, s); rc != DX_ENOSUP) return rc;
-      return launch_nt(a, false, EPI_MASK, stage, s);
+      if (const int rc = took("ntp", launch_ntp_pix(a, B, 2, 2, s)); rc != DX_ENOSUP) return rc;
+      if (const int rc = took("igemm_pix", launch_nt_pix(a, B, EPI_MASK, stage, s)); rc != DX_ENOSUP) return rc;
+      return took("igemm_nt", launch_nt(a, false, EPI_MASK, stage, s));
     }
     case ST_CONV0_WGRAD:
       if (obs_is_u8 && conv0_direct_supported(c->in_h, c->in_w, IC0, c->h0, c->w0)) {
@@ -604,13 +612,13 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
         d.in_h = c->in_h; d.in_w = c->in_w; d.h0 = c->h0; d.w0 = c->w0;
         d.M = static_cast<int>(M0); d.ntiles = static_cast<int>((M0 + 255) / 256);
         d.G = c->dy0; d.slab = c->slabs + plan.s[L_C0].w_off; d.bias_slab = c->slabs + plan.s[L_C0].b_off;
-        return conv0_f32() ? launch_conv0_wgrad(d, plan.s[L_C0].msplit, s)
-                           : launch_conv0_wgrad_b16(d, plan.s[L_C0].msplit, s);
+        return conv0_f32() ? took("conv0_f32", launch_conv0_wgrad(d, plan.s[L_C0].msplit, s))
+                           : took("conv0_b16", launch_conv0_wgrad_b16(d, plan.s[L_C0].msplit, s));
       }
-      return tn(L_C0, conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), c->dy0, kC0,
-                M0, kC0, 64 * IC0, obs_is_u8 != 0);
+      return took("igemm_tn", tn(L_C0, conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), c->dy0, kC0,
+                                  M0, kC0, 64 * IC0, obs_is_u8 != 0));
     case ST_FINALIZE:
-      return finalize_grads(c, plan, 3, s);
+      return took("finalize", finalize_grads(c, plan, 3, s));
     default:
       return fail(DX_EINVAL, "dx_cnn: unknown stage %d", stage);
   }
@@ -776,6 +784,11 @@ int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_
     }
   }
   return rc;
+}
+
+// Kernel family the LAST launch of `stage` took ("ntp", "wgrad_direct", "igemm_pix", ...; "" before any).
+const char *dx_cnn_last_route(int stage) {
+  return (stage >= 0 && stage < ST_COUNT && g_route[stage]) ? g_route[stage] : "";
 }
 
 // A single stage, for per-kernel timing (bench.py roofline) and layer-level tests.

@@ -328,6 +328,12 @@ int dx_cnn_ppo_epoch(const dx_cnn_ctx *ctx, const dx_cnn_epoch *epoch, void *str
  * 5 heads_wgrad, 6 heads_dgrad, 7 fc_wgrad, 8 fc_dgrad, 9 conv2_wgrad, 10 conv2_dgrad,
  * 11 conv1_wgrad, 12 conv1_dgrad, 13 conv0_wgrad, 14 finalize (slabs -> gradients).
  * forward = 0..4, backward = 5..14. */
+/* Which kernel family the most recent launch of `stage` took in this process ("ntp" = the persistent
+ * LDS-DMA ring, "wgrad_direct" / "wgrad_fc" = the image-resident / linear-layer weight gradients,
+ * "conv0_b16", "igemm_lat", "igemm_pix", "igemm_nt", "igemm_tn", "nt_dma", ...; "" before any launch).
+ * The routes depend on tile counts and divisibility by 128 images: tests pin BASELINE's minibatches
+ * to the fast families, bench.py prints the route of every stage. */
+const char *dx_cnn_last_route(int stage);
 int dx_cnn_stage(const dx_cnn_ctx *ctx, int stage, const void *obs, int obs_is_u8,
                  const int32_t *sample_idx, int B, void *stream);
 

@@ -306,3 +306,43 @@ def test_diagnostic_switches_keep_parity(switch):
                        cwd=os.path.dirname(os.path.dirname(here)))
   assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
   assert " passed" in out.stdout and "failed" not in out.stdout
+
+
+def test_baseline_minibatches_take_the_fast_kernel_families():
+  """Perf guard for the kernel routes (they depend on tile counts and on the batch being whole
+  128-image groups): BASELINE's minibatches -- 8192 on one GPU, 1024 as the 8-GPU shard, 2048 in
+  between -- must run their GEMM stages on the persistent ring (`ntp`) / the image-resident and
+  linear-layer weight-gradient kernels, and a batch that is NOT a multiple of 128 images must be
+  seen to leave them (the cliff is a property to know about, not a silent one):
+  dx_cnn_last_route reports the family every stage took."""
+  import ctypes
+  from derl_amd import _lib
+  stages = ["conv0_fwd", "conv1_fwd", "conv2_fwd", "fc_fwd", "heads_fwd", "heads_wgrad", "heads_dgrad",
+            "fc_wgrad", "fc_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad", "conv1_dgrad", "conv0_wgrad",
+            "finalize"]
+  lib = _lib.load()
+
+  def routes(batch):
+    eng = make_engine(4, gi.nature_cnn_weights(4, 3), max_batch=batch)
+    obs = torch.randint(0, 256, (batch, 84, 84, 4), dtype=torch.uint8, device=DEV)
+    eng._ensure_backward()
+    eng.pack()
+    eng.dhead[:batch * 32].zero_()
+    for stage in range(len(stages)):
+      _lib.call("dx_cnn_stage", ctypes.byref(eng.ctx), stage, _lib.ptr(obs), 1, None, batch,
+                _lib.stream_ptr(eng.device))
+    torch.cuda.synchronize()
+    return {name: lib.dx_cnn_last_route(i).decode() for i, name in enumerate(stages)}
+
+  ring = ("conv1_fwd", "conv2_fwd", "fc_dgrad", "conv2_dgrad", "conv1_dgrad")
+  for batch in (8192, 2048, 1024):
+    got = routes(batch)
+    for name in ring:
+      assert got[name] == "ntp", (batch, name, got)
+    assert got["conv2_wgrad"] == got["conv1_wgrad"] == "wgrad_direct", (batch, got)
+    assert got["fc_wgrad"] == "wgrad_fc", (batch, got)
+    assert got["conv0_fwd"] == got["conv0_wgrad"] == "conv0_b16", (batch, got)
+  assert routes(8192)["fc_fwd"] == "ntp"
+  ragged = routes(8192 - 64)  # 63.5 groups of 128 images: the dgrad tiles (one pixel x 128 images) do not exist
+  assert all(ragged[name] != "ntp" for name in ("fc_dgrad", "conv2_dgrad", "conv1_dgrad")), ragged
+  # (the forward stages tile output PIXELS and still find whole 64-row tiles: they stay on the ring)
