@@ -61,6 +61,9 @@ SIGNATURES = {
     "dx_cnn_pack": [P, P],
     "dx_cnn_forward": [P, P, c_int, P, c_int, P],
     "dx_cnn_backward": [P, P, c_int, P, c_int, P],
+    "dx_cnn_forward_trunk": [P, P, c_int, P, c_int, P],
+    "dx_cnn_heads_loss_f32": [P, P, P, P, P, P, P, c_float, P, c_int, c_int, c_float, c_float, c_float,
+                              c_longlong, P, c_int, P, P, P],
     "dx_cnn_backward_part": [P, P, c_int, P, c_int, c_int, P],
     "dx_cnn_stage": [P, c_int, P, c_int, P, c_int, P],
     "dx_cnn_last_route": [c_int],
@@ -196,7 +199,7 @@ class CnnEpoch(ctypes.Structure):
       ("npartials", c_int), ("state0", c_void_p), ("state1", c_void_p),
       ("sumsq_partials", c_void_p), ("loss_partials", c_void_p),
       ("loss_partials_capacity", c_int), ("grad_norm_stride", c_int),
-      ("mirrors_current", c_int), ("reserved0", c_int),
+      ("mirrors_current", c_int), ("reserved0", c_int), ("loss_counter", c_void_p),
       ("max_grad_norm", c_double), ("lr", c_double), ("beta1", c_double), ("beta2", c_double),
       ("opt_eps", c_double), ("first_step", c_longlong), ("grad_norm_out", c_void_p),
       ("loss_out", c_void_p)]

@@ -170,6 +170,36 @@ class CnnEngine:
               int(policy_seed), int(policy_counter), int(env_seed), int(env_counter),
               float(p_reward), float(p_reset), _lib.stream_ptr(self.device))
 
+  FUSED_HEADS_MAX_ACTIONS = 7  # dx_cnn_heads_loss_f32 keeps the A + 1 head rows in registers
+
+  def fused_heads(self):
+    return self.num_actions <= self.FUSED_HEADS_MAX_ACTIONS
+
+  def _loss_counter(self):
+    if getattr(self, "_counter", None) is None:
+      self._counter = torch.zeros(4, dtype=torch.int32, device=self.device)
+    return self._counter
+
+  def forward_trunk(self, obs, sample_idx=None):
+    """conv stack + linear layer of a training minibatch (ctx.hid); the heads run in ``heads_loss``."""
+    batch, is_u8 = self._obs_args(obs, sample_idx)
+    self.pack()
+    _lib.call("dx_cnn_forward_trunk", ctypes.byref(self.ctx), _lib.ptr(obs), is_u8,
+              _lib.ptr(sample_idx), batch, _lib.stream_ptr(self.device))
+    return batch
+
+  def heads_loss(self, batch, actions, old_log_prob, advantages, old_values, value_targets, mode, cliprange,
+                 value_loss_coef, entropy_coef, global_batch, partials, loss_out):
+    """Heads forward, categorical PPO / A2C loss, the heads' dgrad and weight-gradient slabs and the
+    loss scalars in ONE launch (dx_cnn_heads_loss_f32); continue with ``backward(part=3)`` (or 2, 1)."""
+    self._ensure_backward()
+    _lib.call("dx_cnn_heads_loss_f32", ctypes.byref(self.ctx), _lib.ptr(actions), _lib.ptr(old_log_prob),
+              _lib.ptr(advantages), _lib.ptr(old_values), _lib.ptr(value_targets), None, 0.0, None, int(batch),
+              int(mode), float(cliprange if cliprange is not None else -1.0), float(value_loss_coef),
+              float(entropy_coef), int(global_batch), _lib.ptr(partials), partials.numel(),
+              _lib.ptr(self._loss_counter()), _lib.ptr(loss_out), _lib.stream_ptr(self.device))
+    return self.head[:batch * 32].view(batch, 32)
+
   def backward(self, obs, sample_idx=None, part=None):
     """Consumes self.dhead (B, 32) and fills self.grads (same obs / sample_idx as forward).
     ``part`` 0 / 1 runs the two halves separately (``tail_offset`` splits the gradient buffer):
@@ -278,6 +308,7 @@ class CnnEngine:
       e.grad_norm_out, e.grad_norm_stride = optimizer.grad_norm.data_ptr(), 0
     e.loss_out = context.losses.data_ptr()
     e.mirrors_current = int(self._packed_version == self._version())
+    e.loss_counter = self._loss_counter().data_ptr() if self.fused_heads() else None
     keep = (obs, index, actions, old_lp, old_v, adv, vt, stats_ready)  # alive until enqueued
     _lib.call("dx_cnn_ppo_epoch", ctypes.byref(self.ctx), ctypes.byref(e), _lib.stream_ptr(dev))
     del keep

@@ -637,6 +637,40 @@ int dx_cnn_forward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const in
   return DX_OK;
 }
 
+// conv0 .. linear layer only (ctx->hid): the forward of an update whose heads run inside
+// dx_cnn_heads_loss_f32
+int dx_cnn_forward_trunk(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const int32_t *sample_idx,
+                         int B, void *stream) {
+  DX_TRACE("dx_cnn_forward_trunk");
+  if (int rc = check_ctx(c, "dx_cnn_forward_trunk", B, false)) return rc;
+  DX_REQUIRE(obs != nullptr, "dx_cnn_forward_trunk: null observations");
+  const Plan plan = make_plan(c, B);
+  for (int st = ST_CONV0_FWD; st <= ST_FC_FWD; ++st)
+    if (int rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, as_stream(stream))) return rc;
+  return DX_OK;
+}
+
+// ctx->hid (B,512) -> ctx->head, the loss scalars, ctx->dhead, ctx->dhid and the heads' weight /
+// bias gradient slabs, in ONE launch (heads.hip: heads_loss_fused_kernel).  DX_ENOSUP for more than
+// 7 actions: the caller then uses dx_cnn_forward + dx_categorical_loss_f32 + dx_cnn_backward.
+int dx_cnn_heads_loss_f32(const dx_cnn_ctx *c, const int64_t *actions, const float *old_log_prob,
+                          const float *advantages, const float *old_values, const float *value_targets,
+                          const double *norm_stats, float norm_eps, float *adv_normalized_out, int B, int mode,
+                          float cliprange, float value_loss_coef, float entropy_coef, long long global_batch,
+                          double *partials, int partials_capacity, unsigned *counter, float *loss_out,
+                          void *stream) {
+  DX_TRACE("dx_cnn_heads_loss_f32");
+  if (int rc = check_ctx(c, "dx_cnn_heads_loss_f32", B, true)) return rc;
+  const Plan plan = make_plan(c, B);
+  g_route[ST_HEADS_FWD] = g_route[ST_HEADS_WGRAD] = g_route[ST_HEADS_DGRAD] = "heads_loss_fused";
+  return launch_heads_loss_fused(c->hid, c->packed + c->pk_hdf, c->packed + c->pk_hdb, actions, old_log_prob,
+                                 advantages, old_values, value_targets, norm_stats, norm_eps, adv_normalized_out,
+                                 c->head, c->dhead, c->dhid, c->slabs + plan.s[L_HD].w_off,
+                                 c->slabs + plan.s[L_HD].b_off, plan.s[L_HD].msplit, plan.s[L_HD].mper, B,
+                                 c->num_actions, mode, cliprange, value_loss_coef, entropy_coef, global_batch,
+                                 partials, partials_capacity, counter, loss_out, as_stream(stream));
+}
+
 // ctx->dhead (B,32) -> ctx->grads (canonical layout), using the activations kept by
 // dx_cnn_forward on the SAME observations / sample_idx.
 int dx_cnn_backward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const int32_t *sample_idx,
@@ -653,20 +687,23 @@ int dx_cnn_backward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const i
 // The same backward in two calls so that a data-parallel caller can start the all-reduce of the
 // big tail of the gradient buffer early: part 0 = heads + linear layer (their gradients
 // grads[off_w[3] .. param_count) are final when it returns to the stream), part 1 = the three
-// conv layers (grads[0 .. off_w[3])).  Part 0 must be enqueued first.
+// conv layers (grads[0 .. off_w[3])).  Part 0 must be enqueued first.  After dx_cnn_heads_loss_f32
+// (which has done the heads' share): part 2 = the linear layer only in part 0's place, part 3 =
+// linear layer + conv layers with one finalisation (the single-process flow).
 int dx_cnn_backward_part(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const int32_t *sample_idx,
                          int B, int part, void *stream) {
   DX_TRACE("dx_cnn_backward_part");
   if (int rc = check_ctx(c, "dx_cnn_backward_part", B, true)) return rc;
   DX_REQUIRE(obs != nullptr, "dx_cnn_backward_part: null observations");
-  DX_REQUIRE(part == 0 || part == 1, "dx_cnn_backward_part: part must be 0 or 1, got %d", part);
+  DX_REQUIRE(part >= 0 && part <= 3, "dx_cnn_backward_part: part must be 0..3, got %d", part);
   const Plan plan = make_plan(c, B);
   hipStream_t s = as_stream(stream);
-  const int first = part == 0 ? ST_HEADS_WGRAD : ST_CONV2_WGRAD;
-  const int last = part == 0 ? ST_FC_DGRAD : ST_CONV0_WGRAD;
+  // parts 2 / 3: the heads' dgrad and weight-gradient slabs already exist (dx_cnn_heads_loss_f32)
+  const int first = part == 0 ? ST_HEADS_WGRAD : part == 1 ? ST_CONV2_WGRAD : ST_FC_WGRAD;
+  const int last = (part == 0 || part == 2) ? ST_FC_DGRAD : ST_CONV0_WGRAD;
   for (int st = first; st <= last; ++st)
     if (int rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, s)) return rc;
-  return finalize_grads(c, plan, part == 0 ? 2 : 1, s);
+  return finalize_grads(c, plan, part == 1 ? 1 : part == 3 ? 3 : 2, s);
 }
 
 // split of the 3136-deep linear layer over K for small batches (98 K-steps = 2 x 7 x 7)

@@ -67,20 +67,34 @@ extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void
     if (!idx)  // no gather: minibatch k is rows [start, start + B) of obs
       obs = static_cast<const char *>(e->obs) +
             start * c->in_h * c->in_w * c->in_c * (e->obs_is_u8 ? 1 : 4);
-    if (int rc = dx_cnn_forward(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
     const float *olp = e->old_log_prob ? e->old_log_prob + start : nullptr;
     const float *ov = e->old_values ? e->old_values + start : nullptr;
-    if (int rc = dx_categorical_loss_f32(c->head, e->actions + start, olp, adv, ov, e->value_targets + start, B,
-                                         c->num_actions, e->mode, e->cliprange, e->value_loss_coef, e->entropy_coef,
-                                         static_cast<long long>(B) * e->world, c->dhead, e->loss_partials,
-                                         e->loss_partials_capacity, e->loss_out + 8LL * k, stream))
-      return rc;
+    // heads + loss + heads' backward in one launch where the action count allows (<= 7), like the
+    // per-update path (models._cnn_loss_forward_backward): the same kernels on both paths
+    const bool fused_heads = e->loss_counter != nullptr && c->num_actions + 1 <= 8;
+    if (fused_heads) {
+      if (int rc = dx_cnn_forward_trunk(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
+      if (int rc = dx_cnn_heads_loss_f32(c, e->actions + start, olp, adv, ov, e->value_targets + start, nullptr, 0.f,
+                                         nullptr, B, e->mode, e->cliprange, e->value_loss_coef, e->entropy_coef,
+                                         static_cast<long long>(B) * e->world, e->loss_partials,
+                                         e->loss_partials_capacity, e->loss_counter, e->loss_out + 8LL * k, stream))
+        return rc;
+    } else {
+      if (int rc = dx_cnn_forward(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
+      if (int rc = dx_categorical_loss_f32(c->head, e->actions + start, olp, adv, ov, e->value_targets + start, B,
+                                           c->num_actions, e->mode, e->cliprange, e->value_loss_coef, e->entropy_coef,
+                                           static_cast<long long>(B) * e->world, c->dhead, e->loss_partials,
+                                           e->loss_partials_capacity, e->loss_out + 8LL * k, stream))
+        return rc;
+    }
     if (e->allreduce) {
-      if (int rc = dx_cnn_backward_part(c, obs, e->obs_is_u8, idx, B, 0, stream)) return rc;
+      if (int rc = dx_cnn_backward_part(c, obs, e->obs_is_u8, idx, B, fused_heads ? 2 : 0, stream)) return rc;
       if (int rc = comm_allreduce_async(c->grads + tail, c->param_count - tail, s)) return rc;
       if (int rc = dx_cnn_backward_part(c, obs, e->obs_is_u8, idx, B, 1, stream)) return rc;
       if (int rc = comm_allreduce_async(c->grads, tail, s)) return rc;
       if (int rc = comm_wait(s)) return rc;
+    } else if (fused_heads) {
+      if (int rc = dx_cnn_backward_part(c, obs, e->obs_is_u8, idx, B, 3, stream)) return rc;
     } else {
       if (int rc = dx_cnn_backward(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
     }

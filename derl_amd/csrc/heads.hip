@@ -481,6 +481,317 @@ __global__ __launch_bounds__(256) void normal_loss_kernel(const NormalLossArgs a
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Heads + loss of a TRAINING minibatch in ONE launch (round 3): head = hid Wh^T + bh, the
+// categorical PPO / A2C loss and its gradient w.r.t. the head outputs, dhid = dhead Wh (the heads'
+// dgrad), this workgroup's partial of the heads' weight / bias gradient (slab, summed by the
+// finalisation launch as before) and -- in the workgroup that finishes last -- the eight loss
+// scalars.  Replaces six launches of the update (heads forward GEMM, loss, loss reduction, heads
+// wgrad, heads dgrad, and with `stats` the advantage normalisation): the work is 5 MFLOP on 16.8 MB
+// of hid / dhid at minibatch 8192, i.e. one pass over memory.
+// One wave per row at a time, lane l owns k = 8 l .. 8 l + 7 of the 512-wide hidden row and (as
+// lane & 31) head column `col`; the A + 1 <= 8 weight rows stay in registers; cross-lane sums by
+// DPP (wave_sum_all), the per-row loss math is categorical_loss_kernel's, lane = column.
+// derl/models.py:198-214 (output layers), derl/alg/ppo.py:24-108 / a2c.py:19-79, and the autograd
+// backward of both (alg/common.py:70) for the heads.
+// sum / max over each half (32 lanes) of the wave, returned in every lane of the half: four DPP steps
+// inside the 16-lane rows and one exchange between the two rows of a half (the __shfl_xor ladder of
+// half_sum is five LDS permutes -- ~100 cycles each in a dependent chain)
+__device__ __forceinline__ float half_sum_dpp(float v) {
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror: every lane holds its 16-lane row's total
+  return v + __shfl_xor(v, 16);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return fmaxf(v, __builtin_bit_cast(float, moved));
+}
+__device__ __forceinline__ float half_max_dpp(float v) {
+  v = dpp_max<0xB1>(v);
+  v = dpp_max<0x4E>(v);
+  v = dpp_max<0x141>(v);
+  v = dpp_max<0x140>(v);
+  return fmaxf(v, __shfl_xor(v, 16));
+}
+__device__ __forceinline__ Softmax half_softmax_dpp(float logit, bool is_logit) {
+  const float mx = half_max_dpp(is_logit ? logit : -INFINITY);
+  const float e = is_logit ? expf(logit - mx) : 0.f;
+  const float s = half_sum_dpp(e);
+  Softmax r;
+  r.lse = mx + logf(s);
+  r.logp = is_logit ? logit - r.lse : 0.f;
+  r.p = e / s;
+  return r;
+}
+
+struct HeadsLossArgs {
+  const float *hid;        // [B][512]
+  const float *Wh, *bh;    // packed heads [32][512] (rows 0..A-1 policy, row A value), bias [32]
+  const int64_t *actions;
+  const float *old_log_prob, *advantages, *old_values, *value_targets;
+  const double *stats;     // optional {sum, sumsq, n} of the raw advantages: normalise here
+  float norm_eps;
+  float *adv_norm_out;     // optional: the normalised advantages (with stats)
+  float *head, *dhead;     // [B][32]
+  float *dhid;             // [B][512]
+  float *slab, *bias_slab; // [gridDim.x][32][512], [gridDim.x][32]
+  double *partials;        // [gridDim.x][8]
+  unsigned *counter;       // zero before the first launch; the last workgroup resets it
+  float *loss_out;         // [8]
+  int B, A, rows_per_wg, mode;
+  float cliprange, value_loss_coef, entropy_coef, inv_batch;
+};
+
+constexpr int kHlWaves = 8;  // waves per workgroup of heads_loss_fused_kernel
+
+__global__ __launch_bounds__(64 * kHlWaves) void heads_loss_fused_kernel(const HeadsLossArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float hl_smem[];
+  float *wsum = hl_smem;                                  // [waves][8][512] weight-gradient partials of the waves
+  float *bsum = wsum + kHlWaves * 8 * 512;                // [waves][32]
+  double *lsum = reinterpret_cast<double *>(bsum + kHlWaves * 32);  // [waves][8]
+  __shared__ unsigned ticket;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31;
+  const int A = a.A;
+  float4 wu[8], ww[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    wu[j] = *reinterpret_cast<const float4 *>(a.Wh + j * 512 + lane * 8);
+    ww[j] = *reinterpret_cast<const float4 *>(a.Wh + j * 512 + lane * 8 + 4);
+  }
+  const float bias_col = a.bh[col];
+  float meanf = 0.f, denom = 1.f;
+  if (a.stats) {  // adv_apply_kernel's expression
+    const double cnt = a.stats[2], mean = a.stats[0] / cnt;
+    double var = a.stats[1] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    meanf = static_cast<float>(mean);
+    denom = static_cast<float>(sqrt(var)) + a.norm_eps;
+  }
+  float acc[8][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+  float bacc = 0.f;
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool is_logit = col < A;
+  const int row_begin = blockIdx.x * a.rows_per_wg;
+  const int row_end = min(a.B, row_begin + a.rows_per_wg);
+  constexpr int kAhead = 4;  // rows in flight per wave (their hidden rows AND their per-row scalars)
+  for (int r0 = row_begin + wave; r0 < row_end; r0 += kHlWaves * kAhead) {
+    float4 hu[kAhead], hw[kAhead];
+    float p_adv[kAhead], p_vt[kAhead], p_olp[kAhead], p_ov[kAhead];
+    int p_act[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int row = min(r0 + kHlWaves * u, a.B - 1);
+      hu[u] = *reinterpret_cast<const float4 *>(a.hid + static_cast<long long>(row) * 512 + lane * 8);
+      hw[u] = *reinterpret_cast<const float4 *>(a.hid + static_cast<long long>(row) * 512 + lane * 8 + 4);
+      p_act[u] = static_cast<int>(a.actions[row]);
+      p_adv[u] = a.advantages[row];
+      p_vt[u] = a.value_targets[row];
+      p_olp[u] = a.mode == 0 ? a.old_log_prob[row] : 0.f;
+      p_ov[u] = a.mode == 0 ? a.old_values[row] : 0.f;
+    }
+    // The rows of a batch go through every phase TOGETHER (arrays over u, no early exit): the phases
+    // are chains of DPP reductions, v_readlane and transcendentals with long dependent latencies, and
+    // four independent chains overlap where one row at a time took 1.5-3 us (39 us for 16 rows per wave).
+    bool ok[kAhead];
+    float x[kAhead], g[kAhead], advn[kAhead], entv[kAhead], plv[kAhead], vlv[kAhead], vv[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      ok[u] = r0 + kHlWaves * u < row_end;  // uniform
+      x[u] = 0.f;  // lane j (and j + 32) ends up with head output j
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const float part = hu[u].x * wu[j].x + hu[u].y * wu[j].y + hu[u].z * wu[j].z + hu[u].w * wu[j].w +
+                           hw[u].x * ww[j].x + hw[u].y * ww[j].y + hw[u].z * ww[j].z + hw[u].w * ww[j].w;
+        const float tot = wave_sum_all(part);
+        x[u] = col == j ? tot : x[u];
+      }
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      x[u] += bias_col;
+      if (col > A) x[u] = 0.f;  // padding columns
+      // ---- categorical_loss_kernel, lane = column (both halves of the wave hold this row) ----
+      const Softmax sm = half_softmax_dpp(x[u], is_logit);
+      const float ent = -half_sum_dpp(is_logit ? sm.p * sm.logp : 0.f);
+      const int act = __builtin_amdgcn_readfirstlane(p_act[u]);  // uniform: one row per wave
+      const float lp = lane_value(sm.logp, act);
+      const float v = lane_value(x[u], A);
+      float adv = p_adv[u];
+      if (a.stats) adv = (adv - meanf) / denom;
+      const float vt = p_vt[u];
+      float pl, vl, dlp, dv;
+      if (a.mode == 0) {
+        const float old_lp = p_olp[u], old_v = p_ov[u];
+        const float ratio = expf(lp - old_lp);
+        const float l1 = -ratio * adv;
+        pl = l1;
+        bool active = true;
+        if (a.cliprange >= 0.f) {
+          const float lo = 1.f - a.cliprange, hi = 1.f + a.cliprange;
+          const float rc = fminf(fmaxf(ratio, lo), hi);
+          const float l2 = -rc * adv;
+          pl = fmaxf(l1, l2);
+          active = (l1 > l2) || (ratio >= lo && ratio <= hi);
+        }
+        dlp = active ? -adv * ratio * a.inv_batch : 0.f;
+        const float d = v - vt;
+        const float e1 = d * d;
+        vl = e1;
+        bool vactive = true;
+        if (a.cliprange >= 0.f) {
+          const float dvo = v - old_v;
+          const float vc = old_v + fminf(fmaxf(dvo, -a.cliprange), a.cliprange);
+          const float e2 = (vc - vt) * (vc - vt);
+          vl = fmaxf(e1, e2);
+          vactive = (e1 > e2) || (fabsf(dvo) <= a.cliprange);
+        }
+        dv = vactive ? a.value_loss_coef * 2.f * d * a.inv_batch : 0.f;
+      } else {
+        pl = -lp * adv;
+        dlp = -adv * a.inv_batch;
+        const float d = v - vt;
+        vl = d * d;
+        dv = a.value_loss_coef * 2.f * d * a.inv_batch;
+      }
+      float gu = 0.f;  // dL/dhead[col]
+      if (is_logit)
+        gu = dlp * ((col == act ? 1.f : 0.f) - sm.p) + a.entropy_coef * a.inv_batch * sm.p * (sm.logp + ent);
+      else if (col == A)
+        gu = dv;
+      g[u] = ok[u] ? gu : 0.f;  // rows past the slice contribute nothing
+      advn[u] = adv; entv[u] = ent; plv[u] = pl; vlv[u] = vl; vv[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      if (!ok[u]) continue;  // uniform; only stores and the scalar sums below
+      const int b = r0 + kHlWaves * u;
+      if (a.stats && a.adv_norm_out && lane == 0) a.adv_norm_out[b] = advn[u];
+      if (lane < 32) {
+        a.head[static_cast<long long>(b) * kHeadLd + col] = x[u];
+        a.dhead[static_cast<long long>(b) * kHeadLd + col] = g[u];
+        bacc += g[u];
+      }
+      // policy term, entropy, value term, adv, v, vt, (v - vt)^2, v^2 (uniform over the wave)
+      const float vt = p_vt[u];
+      s[0] += plv[u]; s[1] += entv[u]; s[2] += vlv[u]; s[3] += advn[u]; s[4] += vv[u]; s[5] += vt;
+      s[6] += static_cast<double>(vv[u] - vt) * (vv[u] - vt); s[7] += static_cast<double>(vv[u]) * vv[u];
+    }
+    // ---- heads dgrad (this lane's 8 k) and weight-gradient partial ----
+    float d8[kAhead][8];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d8[u][i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const float gj = lane_value(g[u], j);  // uniform
+        const float h[8] = {hu[u].x, hu[u].y, hu[u].z, hu[u].w, hw[u].x, hw[u].y, hw[u].z, hw[u].w};
+        d8[u][0] = fmaf(gj, wu[j].x, d8[u][0]); d8[u][1] = fmaf(gj, wu[j].y, d8[u][1]);
+        d8[u][2] = fmaf(gj, wu[j].z, d8[u][2]); d8[u][3] = fmaf(gj, wu[j].w, d8[u][3]);
+        d8[u][4] = fmaf(gj, ww[j].x, d8[u][4]); d8[u][5] = fmaf(gj, ww[j].y, d8[u][5]);
+        d8[u][6] = fmaf(gj, ww[j].z, d8[u][6]); d8[u][7] = fmaf(gj, ww[j].w, d8[u][7]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(gj, h[i], acc[j][i]);
+      }
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      if (!ok[u]) continue;
+      float *drow = a.dhid + static_cast<long long>(r0 + kHlWaves * u) * 512 + lane * 8;
+      *reinterpret_cast<float4 *>(drow) = make_float4(d8[u][0], d8[u][1], d8[u][2], d8[u][3]);
+      *reinterpret_cast<float4 *>(drow + 4) = make_float4(d8[u][4], d8[u][5], d8[u][6], d8[u][7]);
+    }
+  }
+  // ---- the waves' partials meet in LDS, summed in wave order ----
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float *dst = wsum + (wave * 8 + j) * 512 + lane * 8;
+    *reinterpret_cast<float4 *>(dst) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
+  }
+  if (lane < 32) bsum[wave * 32 + col] = bacc;
+  if (lane < 8) {
+    double mine = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine = lane == i ? s[i] : mine;
+    lsum[wave * 8 + lane] = mine;
+  }
+  __syncthreads();
+  float *slab = a.slab + static_cast<long long>(blockIdx.x) * kHeadLd * 512;
+  for (int i = threadIdx.x; i < 8 * 512 / 4; i += 64 * kHlWaves) {  // rows 0..7 (A + 1 <= 8); the rest is never read
+    float4 t = reinterpret_cast<const float4 *>(wsum)[i];
+#pragma unroll
+    for (int w = 1; w < kHlWaves; ++w) {
+      const float4 p = reinterpret_cast<const float4 *>(wsum + w * 4096)[i];
+      t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+    }
+    reinterpret_cast<float4 *>(slab)[i] = t;
+  }
+  if (threadIdx.x < 32) {
+    float t = bsum[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kHlWaves; ++w) t += bsum[w * 32 + threadIdx.x];
+    a.bias_slab[static_cast<long long>(blockIdx.x) * kHeadLd + threadIdx.x] = t;
+  }
+  if (threadIdx.x < 8) {  // write-through: the last workgroup reads every workgroup's partials
+    double tot = lsum[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kHlWaves; ++w) tot += lsum[w * 8 + threadIdx.x];
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.partials + blockIdx.x * 8 + threadIdx.x),
+                       __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket != gridDim.x - 1) return;
+  // ---- last workgroup: loss_reduce_kernel over the partials (sc1 loads) ----
+  double t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < static_cast<int>(gridDim.x); i += 64 * kHlWaves)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      t8[j] += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.partials + i * 8 + j),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    t8[j] = wave_sum_d(t8[j]);
+    if (lane == 0) lsum[wave * 8 + j] = t8[j];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[8];
+    for (int j = 0; j < 8; ++j) {
+      t[j] = lsum[j];
+      for (int w = 1; w < kHlWaves; ++w) t[j] += lsum[w * 8 + j];
+    }
+    const double count = a.B;
+    const float policy = static_cast<float>(t[0] / count), ent = static_cast<float>(t[1] / count);
+    const float value = static_cast<float>(t[2] / count);
+    float *out = a.loss_out;
+    out[0] = (policy - a.entropy_coef * ent) + a.value_loss_coef * value;
+    out[1] = policy; out[2] = ent; out[3] = value;
+    out[4] = static_cast<float>(t[3] / count);
+    out[5] = static_cast<float>(t[4] / count);
+    out[6] = static_cast<float>(t[5] / count);
+    const double mean_v = t[4] / count;
+    const double var_v = count > 1 ? (t[7] - count * mean_v * mean_v) / (count - 1) : 0.0;
+    out[7] = static_cast<float>(1.0 - (t[6] / count) / var_v);
+    __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
+}
+
 // the categorical loss_reduce_kernel with a row stride of 40 doubles
 __global__ __launch_bounds__(256) void loss_reduce40_kernel(const double *partials, int nblocks,
                                                             double count, float value_loss_coef,
@@ -611,6 +922,40 @@ extern "C" int dx_categorical_loss_f32(const float *head_out, const int64_t *act
 }
 
 namespace dx {
+// DX_ENOSUP: more than 7 actions (the A + 1 weight rows live in registers): the caller keeps the
+// separate heads / loss launches
+int launch_heads_loss_fused(const float *hid, const float *Wh, const float *bh, const int64_t *actions,
+                            const float *old_log_prob, const float *advantages, const float *old_values,
+                            const float *value_targets, const double *stats, float norm_eps, float *adv_norm_out,
+                            float *head, float *dhead, float *dhid, float *slab, float *bias_slab, int nslab,
+                            int rows_per_slab, int B, int A, int mode, float cliprange, float value_loss_coef,
+                            float entropy_coef, long long global_batch, double *partials, int partials_capacity,
+                            unsigned *counter, float *loss_out, hipStream_t stream) {
+  if (A + 1 > 8) return DX_ENOSUP;
+  DX_REQUIRE(B >= 1 && A >= 1 && nslab >= 1 && rows_per_slab >= 1 && static_cast<long long>(nslab) * rows_per_slab >= B,
+             "heads_loss: bad shape B=%d A=%d slabs=%d x %d rows", B, A, nslab, rows_per_slab);
+  DX_REQUIRE(mode == 0 || mode == 1, "heads_loss: mode must be 0 (PPO) or 1 (A2C)");
+  DX_REQUIRE(hid && Wh && bh && actions && advantages && value_targets && head && dhead && dhid && slab && bias_slab &&
+                 partials && counter && loss_out, "heads_loss: null pointer");
+  DX_REQUIRE(mode == 1 || (old_log_prob && old_values), "heads_loss: PPO needs old_log_prob / old_values");
+  DX_REQUIRE(partials_capacity >= 8 * nslab, "heads_loss: partials needs %d doubles", 8 * nslab);
+  if (global_batch <= 0) global_batch = B;
+  const HeadsLossArgs a{hid, Wh, bh, actions, old_log_prob, advantages, old_values, value_targets, stats, norm_eps,
+                        adv_norm_out, head, dhead, dhid, slab, bias_slab, partials, counter, loss_out, B, A,
+                        rows_per_slab, mode, cliprange, value_loss_coef, entropy_coef,
+                        1.0f / static_cast<float>(global_batch)};
+  constexpr int lds = (kHlWaves * 8 * 512 + kHlWaves * 32) * 4 + kHlWaves * 8 * 8;
+  static bool configured = false;
+  if (!configured) {
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(heads_loss_fused_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL(heads_loss_fused_kernel, dim3(nslab), dim3(64 * kHlWaves), lds, stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
 int launch_heads_act_fused(const float *hid_slabs, int nslab, long long slab_stride, const float *Wh,
                            const float *bh, int B, int A, const float *uniforms, uint64_t seed,
                            uint64_t counter, int64_t *actions, float *log_prob, float *values,

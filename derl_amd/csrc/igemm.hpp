@@ -205,6 +205,14 @@ int launch_conv0_fwd_b16(const Conv0Args &a, hipStream_t stream);
 int launch_conv0_wgrad_b16(const Conv0Args &a, int nblocks, hipStream_t stream);
 // rollout-sized batches: 32x32 tile per workgroup, pre-split weight planes Wb [3][32][256] bf16
 int launch_conv0_lat_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t stream);
+// heads forward + categorical loss + heads dgrad / wgrad partials + loss scalars in one launch (heads.hip)
+int launch_heads_loss_fused(const float *hid, const float *Wh, const float *bh, const int64_t *actions,
+                            const float *old_log_prob, const float *advantages, const float *old_values,
+                            const float *value_targets, const double *stats, float norm_eps, float *adv_norm_out,
+                            float *head, float *dhead, float *dhid, float *slab, float *bias_slab, int nslab,
+                            int rows_per_slab, int B, int A, int mode, float cliprange, float value_loss_coef,
+                            float entropy_coef, long long global_batch, double *partials, int partials_capacity,
+                            unsigned *counter, float *loss_out, hipStream_t stream);
 int launch_heads_act_fused(const float *hid_slabs, int nslab, long long slab_stride, const float *Wh,
                            const float *bh, int B, int A, const float *uniforms, uint64_t seed,
                            uint64_t counter, int64_t *actions, float *log_prob, float *values,

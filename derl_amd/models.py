@@ -219,29 +219,44 @@ def _cnn_loss_forward_backward(model, policy, data, mode, cliprange, value_loss_
   if isinstance(observations, GatheredRows):
     observations, sample_idx = observations.base, observations.index
   observations = model.prepare(observations)
-  head = model.head(observations, sample_idx)
-  eng._ensure_backward()
-  batch = head.shape[0]
-  dhead = eng.dhead[:batch * 32].view(batch, 32)
   if actions.dtype != torch.int64:
     actions = actions.long()
+  fused = eng.fused_heads()
+  if fused:
+    # conv stack + linear layer, then heads + loss + the heads' backward in ONE launch
+    # (dx_cnn_heads_loss_f32): the same kernels the native epoch enqueues
+    batch = sample_idx.numel() if sample_idx is not None else observations.shape[0]
+    model.reserve(batch)
+    eng._ensure_backward()
+    eng.forward_trunk(observations, sample_idx)
+  else:
+    head = model.head(observations, sample_idx)
+    eng._ensure_backward()
+    batch = head.shape[0]
+    dhead = eng.dhead[:batch * 32].view(batch, 32)
   need = 8 * ((batch + 7) // 8)
   if model._loss_partials is None or model._loss_partials.numel() < need:
     model._loss_partials = torch.empty(need, dtype=torch.float64, device=eng.device)
-  terms = ops.categorical_loss(head, actions, old_log_prob, advantages, old_values, value_targets,
-                               eng.num_actions, mode, cliprange, value_loss_coef, entropy_coef,
-                               dhead, global_batch, model._loss_partials)
+  if fused:
+    terms = torch.empty(8, dtype=torch.float32, device=eng.device)
+    eng.heads_loss(batch, actions, old_log_prob, advantages, old_values, value_targets, mode, cliprange,
+                   value_loss_coef, entropy_coef, global_batch, model._loss_partials, terms)
+  else:
+    terms = ops.categorical_loss(head, actions, old_log_prob, advantages, old_values, value_targets,
+                                 eng.num_actions, mode, cliprange, value_loss_coef, entropy_coef,
+                                 dhead, global_batch, model._loss_partials)
 
   def backward_fn(grad_output, on_part=None):
     """``on_part(k)`` is called when half k of the gradient buffer is final (see
     _FlatOptimizer.reduce_part): the tail's all-reduce overlaps the conv layers' backward."""
     del grad_output
     if on_part is None:
-      eng.backward(observations, sample_idx)
+      eng.backward(observations, sample_idx, part=3 if fused else None)
       return
-    for part in (0, 1):
-      eng.backward(observations, sample_idx, part=part)
-      on_part(part)
+    eng.backward(observations, sample_idx, part=2 if fused else 0)
+    on_part(0)
+    eng.backward(observations, sample_idx, part=1)
+    on_part(1)
 
   return terms, backward_fn
 

@@ -249,10 +249,30 @@ int dx_cnn_forward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
                    const int32_t *sample_idx, int B, void *stream);
 int dx_cnn_backward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
                     const int32_t *sample_idx, int B, void *stream);
+/* The forward of a training minibatch without the heads (conv stack + linear layer -> ctx->hid), and
+ * the heads with the loss in ONE launch: ctx->head = ctx->hid Wh^T + bh (derl/models.py:198-214), the
+ * categorical PPO / A2C loss of derl/alg/ppo.py:24-108 / derl/alg/a2c.py:19-79 (loss_out[8] as
+ * dx_categorical_loss_f32), its gradient w.r.t. the head outputs (ctx->dhead), ctx->dhid = dhead Wh
+ * and the heads' weight / bias gradient slabs -- what dx_cnn_forward's last stage,
+ * dx_categorical_loss_f32 and dx_cnn_backward's first two stages do in five launches.  Continue with
+ * dx_cnn_backward_part(part = 2 [then 1], or 3).  norm_stats != NULL: `advantages` are raw and
+ * normalised here with {sum, sumsq, n} (derl/runners/trajectory_transforms.py:89-92), written to
+ * adv_normalized_out if given.  `counter`: one word, zero before the first call (the launch leaves
+ * it zero).  `partials`: >= 8 * ceil(B / 64) doubles.  DX_ENOSUP for more than 7 actions. */
+int dx_cnn_forward_trunk(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
+                         const int32_t *sample_idx, int B, void *stream);
+int dx_cnn_heads_loss_f32(const dx_cnn_ctx *ctx, const int64_t *actions, const float *old_log_prob,
+                          const float *advantages, const float *old_values,
+                          const float *value_targets, const double *norm_stats, float norm_eps,
+                          float *adv_normalized_out, int B, int mode, float cliprange,
+                          float value_loss_coef, float entropy_coef, long long global_batch,
+                          double *partials, int partials_capacity, unsigned *counter,
+                          float *loss_out, void *stream);
 /* The same backward in two calls, for overlapping the gradient all-reduce with it (the one
  * exchange step of the path): part 0 = heads + linear layer, after which
  * grads[off_w[3] .. param_count) -- 95 % of the bytes -- are final; part 1 = the conv layers,
- * grads[0 .. off_w[3]).  Part 0 first. */
+ * grads[0 .. off_w[3]).  Part 0 first.  After dx_cnn_heads_loss_f32: part 2 = the linear layer only
+ * (in part 0's place), part 3 = linear layer + conv layers with one finalisation. */
 int dx_cnn_backward_part(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
                          const int32_t *sample_idx, int B, int part, void *stream);
 /* Rollout step of the policy -- replaces derl/policies.py:61-80 for one batch of observations:
@@ -316,6 +336,9 @@ typedef struct dx_cnn_epoch {
   int mirrors_current;         /* 1: the packed mirrors match ctx->params (no pack before the
                                   first minibatch; every update is followed by one)          */
   int reserved0;
+  unsigned *loss_counter;      /* one zeroed word: heads + loss + heads' backward run as ONE launch
+                                  (dx_cnn_heads_loss_f32) where num_actions <= 7; NULL: separate
+                                  heads / loss launches                                        */
   double max_grad_norm;        /* <= 0: no clipping                                         */
   double lr, beta1, beta2, opt_eps;
   long long first_step;        /* Adam's step number of minibatch 0 (1-based)               */

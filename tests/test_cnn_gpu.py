@@ -346,3 +346,53 @@ def test_baseline_minibatches_take_the_fast_kernel_families():
   ragged = routes(8192 - 64)  # 63.5 groups of 128 images: the dgrad tiles (one pixel x 128 images) do not exist
   assert all(ragged[name] != "ntp" for name in ("fc_dgrad", "conv2_dgrad", "conv1_dgrad")), ragged
   # (the forward stages tile output PIXELS and still find whole 64-row tiles: they stay on the ring)
+
+
+@pytest.mark.parametrize("batch,A,mode", [(5, 4, 0), (64, 6, 0), (1000, 7, 1), (2048, 4, 0)])
+def test_fused_heads_and_loss_launch_matches_the_separate_launches(batch, A, mode):
+  """dx_cnn_forward_trunk + dx_cnn_heads_loss_f32 + dx_cnn_backward_part(3) (heads forward, loss,
+  loss reduction and the heads' dgrad / wgrad in ONE launch) against dx_cnn_forward +
+  dx_categorical_loss_f32 + dx_cnn_backward on the same minibatch: head outputs, the eight loss
+  scalars, dL/dhead, dL/dhid and EVERY gradient of the network (the heads' own gradients come from
+  the fused launch's slabs, the rest flows through its dhid)."""
+  from derl_amd import ops
+  weights = gi.nature_cnn_weights(A, 60 + A)
+  eng = make_engine(A, weights, max_batch=max(batch, 64))
+  rs = np.random.RandomState(batch + A)
+  obs = torch.from_numpy(gi.frames(batch, 17 + batch)).to(DEV)
+  actions = torch.from_numpy(rs.randint(0, A, batch)).to(DEV)
+  old_lp = torch.from_numpy((-np.log(A) + 0.3 * rs.standard_normal(batch)).astype(np.float32)).to(DEV)
+  adv = torch.from_numpy(rs.standard_normal(batch).astype(np.float32)).to(DEV)
+  old_v = torch.from_numpy((0.2 * rs.standard_normal(batch)).astype(np.float32)).to(DEV)
+  vt = torch.from_numpy(rs.standard_normal(batch).astype(np.float32)).to(DEV)
+  partials = torch.empty(8 * ((batch + 7) // 8), dtype=torch.float64, device=DEV)
+  clip = 0.1 if mode == 0 else None
+  # separate launches
+  head_a = eng.forward(obs).clone()
+  eng._ensure_backward()
+  dhead = eng.dhead[:batch * 32].view(batch, 32)
+  terms_a = ops.categorical_loss(head_a, actions, old_lp if mode == 0 else None, adv, old_v if mode == 0 else None,
+                                 vt, A, mode, clip, 0.25, 0.01, dhead, batch, partials).clone()
+  dhead_a = dhead.clone()
+  eng.backward(obs)
+  grads_a, dhid_a = eng.grads.clone(), eng.dhid[:batch * 512].clone()
+  # one launch
+  eng.grads.zero_()
+  eng.forward_trunk(obs)
+  terms_b = torch.empty(8, dtype=torch.float32, device=DEV)
+  head_b = eng.heads_loss(batch, actions, old_lp if mode == 0 else None, adv, old_v if mode == 0 else None, vt,
+                          mode, clip, 0.25, 0.01, batch, partials, terms_b).clone()
+  dhead_b, dhid_b = eng.dhead[:batch * 32].view(batch, 32).clone(), eng.dhid[:batch * 512].clone()
+  eng.backward(obs, part=3)
+  grads_b = eng.grads.clone()
+  nt.assert_allclose(head_b[:, :A + 1].cpu().numpy(), head_a[:, :A + 1].cpu().numpy(), rtol=1e-5, atol=2e-6)
+  assert float(head_b[:, A + 1:].abs().max()) == 0.0
+  nt.assert_allclose(terms_b.cpu().numpy(), terms_a.cpu().numpy(), rtol=2e-5, atol=1e-6)
+  scale = float(dhead_a.abs().max())
+  nt.assert_allclose(dhead_b.cpu().numpy(), dhead_a.cpu().numpy(), rtol=1e-4, atol=1e-6 * scale)
+  nt.assert_allclose(dhid_b.cpu().numpy(), dhid_a.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(dhid_a.abs().max()))
+  va, vb = eng.named_views(grads_a), eng.named_views(grads_b)
+  for key in va:
+    ref = va[key].cpu().numpy()
+    nt.assert_allclose(vb[key].cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max() + 1e-9, err_msg=key)
+  assert int(eng._loss_counter()[0]) == 0  # the last workgroup left the ticket word ready for the next launch
