@@ -270,8 +270,8 @@ class CnnEngine:
     if stats_ready is not None and (stats_ready.dtype != torch.float64 or not stats_ready.is_contiguous()
                                     or tuple(stats_ready.shape) != (updates, 3)):
       raise _lib.NativeError("native epoch: statistics must be a contiguous (minibatches, 3) float64 tensor")
-    if getattr(self, "_epoch_scratch", None) is None:
-      self._epoch_scratch = torch.empty(3, dtype=torch.float64, device=dev)
+    if getattr(self, "_epoch_scratch", None) is None or self._epoch_scratch.numel() < 3 * updates:
+      self._epoch_scratch = torch.empty(3 * updates, dtype=torch.float64, device=dev)
     capacity = 8 * ((mbsize + 7) // 8)
     if getattr(self, "_epoch_partials", None) is None or self._epoch_partials.numel() < capacity:
       self._epoch_partials = torch.empty(capacity, dtype=torch.float64, device=dev)

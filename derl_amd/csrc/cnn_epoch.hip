@@ -47,11 +47,22 @@ extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void
   DX_REQUIRE(e->loss_partials_capacity >= 8 * ((e->mbsize + 7) / 8), "dx_cnn_ppo_epoch: loss_partials too small");
   hipStream_t s = as_stream(stream);
   const long long tail = c->off_w[3];  // grads[tail ..) = linear layer + heads
+  // heads + loss + heads' backward in one launch where the action count allows (<= 7), like the
+  // per-update path (models._cnn_loss_forward_backward): the same kernels on both paths
+  const bool fused_heads = e->loss_counter != nullptr && c->num_actions + 1 <= 8;
+  // with the fused launch the normalisation happens inside it: the statistics of EVERY minibatch of
+  // the epoch come from one launch (bit-identical to the per-minibatch kernel's) instead of one
+  // normalisation launch per update
+  const double *stats_all = e->stats_ready;
+  if (e->normalize && fused_heads && stats_all == nullptr) {
+    if (int rc = dx_adv_stats_segments_f32(e->advantages, nullptr, e->samples, e->mbsize, e->stats, stream)) return rc;
+    stats_all = e->stats;
+  }
   int k = 0;
   for (long long start = 0; start < e->samples; start += e->mbsize, ++k) {
     const int B = static_cast<int>(e->samples - start < e->mbsize ? e->samples - start : e->mbsize);
     const float *adv = e->advantages + start;
-    if (e->normalize) {  // what NormalizeAdvantages launches per minibatch; kept for the caller
+    if (e->normalize && !fused_heads) {  // what NormalizeAdvantages launches per minibatch; kept for the caller
       float *norm = e->adv_normalized + start;
       // sharded: the GLOBAL {sum, sumsq, n} of this minibatch, summed over the ranks beforehand
       double *stats = e->stats_ready ? const_cast<double *>(e->stats_ready) + 3LL * k : e->stats;
@@ -69,13 +80,12 @@ extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void
             start * c->in_h * c->in_w * c->in_c * (e->obs_is_u8 ? 1 : 4);
     const float *olp = e->old_log_prob ? e->old_log_prob + start : nullptr;
     const float *ov = e->old_values ? e->old_values + start : nullptr;
-    // heads + loss + heads' backward in one launch where the action count allows (<= 7), like the
-    // per-update path (models._cnn_loss_forward_backward): the same kernels on both paths
-    const bool fused_heads = e->loss_counter != nullptr && c->num_actions + 1 <= 8;
     if (fused_heads) {
       if (int rc = dx_cnn_forward_trunk(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
-      if (int rc = dx_cnn_heads_loss_f32(c, e->actions + start, olp, adv, ov, e->value_targets + start, nullptr, 0.f,
-                                         nullptr, B, e->mode, e->cliprange, e->value_loss_coef, e->entropy_coef,
+      const double *st = e->normalize ? stats_all + 3LL * k : nullptr;
+      if (int rc = dx_cnn_heads_loss_f32(c, e->actions + start, olp, e->advantages + start, ov, e->value_targets + start,
+                                         st, e->norm_eps, e->normalize ? e->adv_normalized + start : nullptr, B, e->mode,
+                                         e->cliprange, e->value_loss_coef, e->entropy_coef,
                                          static_cast<long long>(B) * e->world, e->loss_partials,
                                          e->loss_partials_capacity, e->loss_counter, e->loss_out + 8LL * k, stream))
         return rc;

@@ -320,7 +320,7 @@ typedef struct dx_cnn_epoch {
   float norm_eps;
   const double *stats_ready;   /* (minibatches, 3) GLOBAL {sum, sumsq, n} per minibatch (sharded
                                   runs: summed over the ranks beforehand) or NULL: local      */
-  double *stats;               /* (3) scratch when stats_ready == NULL                      */
+  double *stats;               /* (minibatches, 3) scratch when stats_ready == NULL         */
   float *adv_normalized;       /* (samples): every minibatch's normalised advantages        */
   float cliprange, value_loss_coef, entropy_coef;
   int world;                   /* ranks: gradients are scaled by 1 / (B * world)            */
