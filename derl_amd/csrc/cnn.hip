@@ -497,7 +497,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
         d.in_h = c->in_h; d.in_w = c->in_w; d.h0 = c->h0; d.w0 = c->w0;
         d.M = static_cast<int>(M0); d.ntiles = static_cast<int>((M0 + 255) / 256);
         d.Wp = pk + c->pk_c0f; d.bias = w + c->off_b[0]; d.out = c->y0;
-        return conv0_f32() ? took("conv0_f32", launch_conv0_fwd(d, s)) : took("conv0_b16", launch_conv0_fwd_b16(d, s));
+        return conv0_f32() ? took("conv0_f32", launch_conv0_fwd(d, s)) : took("conv0_b16", launch_conv0_fwd_b16(d, planes(c, c->pb_c0f), s));
       }
       return took("igemm_nt", launch_nt(a, obs_is_u8 != 0, EPI_BIAS_RELU, stage, s));
     case ST_CONV1_FWD:

@@ -23,7 +23,31 @@ struct Seg {       // the (at most two) images a tile touches
   int bytes_a, bytes_b;
 };
 
-__device__ __forceinline__ Seg tile_segments(const Conv0Args &a, int m0) {
+// The (at most two) images a tile touches, through the minibatch's gather table.  The table is
+// read through the CONSTANT address space (never written by these kernels): a scalar load the
+// compiler waits for with lgkmcnt where the value is first used.  (As a vector load it is waited
+// for with vmcnt(0), which also drains every store of the previous tile; as a scalar load waited
+// for on the spot it costs a full memory round trip per tile -- 1,800 of the forward's 12,000
+// cycles per tile in round 2 -- so the kernels fetch a tile's pair one tile AHEAD.)
+struct TileImages { int img_a, raw_a, raw_b; };
+
+__device__ __forceinline__ TileImages tile_images(const Conv0Args &a, int m0) {
+  typedef const __attribute__((address_space(4))) int32_t *ConstTable;
+  const int P = a.h0 * a.w0;
+  const int img_a = __builtin_amdgcn_readfirstlane(m0 / P);
+  const bool gather = a.idx != nullptr;
+  // no branch around the loads (a join would make the compiler wait for them on the spot): without
+  // a table they read two words of the frame buffer that tile_segments ignores
+  ConstTable tab = gather ? (ConstTable)(a.idx) + img_a : (ConstTable)(a.obs);
+  const int last = (a.M - 1) / P;  // (the entry behind the last image is not touched)
+  TileImages t;
+  t.img_a = img_a;
+  t.raw_a = tab[0];
+  t.raw_b = tab[gather && img_a < last ? 1 : 0];
+  return t;
+}
+
+__device__ __forceinline__ Seg tile_segments(const Conv0Args &a, int m0, const TileImages &im) {
   Seg s;
   const int P = a.h0 * a.w0;
   const int rowB = a.in_w * 4;
@@ -35,20 +59,7 @@ __device__ __forceinline__ Seg tile_segments(const Conv0Args &a, int m0) {
   s.cnt_b = left - s.cnt_a;
   s.oya0 = s.pa / a.w0;
   const int oya1 = (s.pa + s.cnt_a - 1) / a.w0;
-  // The image gather is read with SCALAR loads (the table is never written by these kernels).  As a
-  // vector load the compiler waits for it with vmcnt(0), which also waits for every store the
-  // workgroup still has in flight (the previous tile's output): one full drain per tile.
-  long long ia = img_a, ib = img_a + 1;
-  if (a.idx) {
-    const int32_t *pa = a.idx + __builtin_amdgcn_readfirstlane(img_a);
-    const int32_t *pb = s.cnt_b > 0 ? pa + 1 : pa;  // (the entry behind the last image is not touched)
-    int va, vb;
-    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(va), "=&s"(vb)
-                 : "s"(pa), "s"(pb)
-                 : "memory");
-    ia = va; ib = vb;
-  }
+  const long long ia = a.idx ? im.raw_a : im.img_a, ib = a.idx ? im.raw_b : im.img_a + 1;
   s.src_a = ia * imgB + static_cast<long long>(4 * s.oya0) * rowB;
   s.bytes_a = (4 * (oya1 - s.oya0) + 8) * rowB;
   s.src_b = 0;
@@ -58,6 +69,10 @@ __device__ __forceinline__ Seg tile_segments(const Conv0Args &a, int m0) {
     s.bytes_b = (4 * ((s.cnt_b - 1) / a.w0) + 8) * rowB;
   }
   return s;
+}
+
+__device__ __forceinline__ Seg tile_segments(const Conv0Args &a, int m0) {
+  return tile_segments(a, m0, tile_images(a, m0));
 }
 
 // byte offset inside the LDS patch of input pixel (4*oy, 4*ox) for tile pixel p (0 if p is padding)
@@ -82,24 +97,27 @@ __device__ __forceinline__ int pixel_base(const Conv0Args &a, const Seg &s, int 
 //   patch_store: registers -> LDS after the barrier that retires the previous tile's reads
 constexpr int kPatchRegs = 6;  // 6 * 256 lanes * 16 B = 24 KB >= the largest patch (launch-checked)
 
-__device__ __forceinline__ void patch_load(const Conv0Args &a, const Seg &s, u32x4 (&v)[kPatchRegs]) {
+// NT = threads of the workgroup: 256 (6 registers per lane) or 512 (3)
+template <int NT = 256>
+__device__ __forceinline__ void patch_load(const Conv0Args &a, const Seg &s, u32x4 (&v)[kPatchRegs * 256 / NT]) {
   const u32x4 *sa = reinterpret_cast<const u32x4 *>(a.obs + s.src_a);
   const u32x4 *sb = reinterpret_cast<const u32x4 *>(a.obs + s.src_b);
   const int na = s.bytes_a / 16, n = na + s.bytes_b / 16;
 #pragma unroll
-  for (int u = 0; u < kPatchRegs; ++u) {
-    const int i = u * 256 + threadIdx.x;
+  for (int u = 0; u < kPatchRegs * 256 / NT; ++u) {
+    const int i = u * NT + threadIdx.x;
     const int ic = i < n ? i : 0;
     v[u] = *(ic < na ? sa + ic : sb + (ic - na));
   }
 }
 
-__device__ __forceinline__ void patch_store(const Seg &s, const u32x4 (&v)[kPatchRegs], uint8_t *patch) {
+template <int NT = 256>
+__device__ __forceinline__ void patch_store(const Seg &s, const u32x4 (&v)[kPatchRegs * 256 / NT], uint8_t *patch) {
   u32x4 *dst = reinterpret_cast<u32x4 *>(patch);
   const int n = (s.bytes_a + s.bytes_b) / 16;
 #pragma unroll
-  for (int u = 0; u < kPatchRegs; ++u) {
-    const int i = u * 256 + threadIdx.x;
+  for (int u = 0; u < kPatchRegs * 256 / NT; ++u) {
+    const int i = u * NT + threadIdx.x;
     if (i < n) dst[i] = v[u];
   }
 }

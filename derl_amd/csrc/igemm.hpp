@@ -201,7 +201,7 @@ int launch_conv0_fwd(const Conv0Args &a, hipStream_t stream);
 int launch_conv0_wgrad(const Conv0Args &a, int nblocks, hipStream_t stream);
 // the same two kernels on the bf16 matrix cores with an exact 3-term weight / gradient split
 // (conv0_b16.hip); the default.  DX_CONV0_F32=1 selects the fp32-MFMA kernels above.
-int launch_conv0_fwd_b16(const Conv0Args &a, hipStream_t stream);
+int launch_conv0_fwd_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t stream);
 int launch_conv0_wgrad_b16(const Conv0Args &a, int nblocks, hipStream_t stream);
 // rollout-sized batches: 32x32 tile per workgroup, pre-split weight planes Wb [3][32][256] bf16
 int launch_conv0_lat_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t stream);

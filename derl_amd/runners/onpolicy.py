@@ -234,13 +234,18 @@ class IterateWithMinibatches(RunnerWrapper):
       dict.__setitem__(out, key, val)
     return out
 
-  def _draw_host(self, sample_size, pinned=False):
+  def _draw_host(self, sample_size, pinned=False, state=None):
     """The composed permutations of all epochs as an (epochs, samples) int32 array: the reference's
     per-epoch ``np.random.permutation`` draws (nothing else consumes np.random between them, so the
     stream is identical), made by the native library from NumPy's own generator state
     (dx_host_compose_permutations: bit-for-bit the NumPy result, and the call does not hold the
     GIL, so a worker thread can really run beside the training loop).  ``pinned``: into the next
-    pinned staging buffer (a torch tensor; its previous upload is waited for first)."""
+    pinned staging buffer (a torch tensor; its previous upload is waited for first).
+
+    ``state`` = None: drawn from (and advancing) the global ``np.random`` generator.  Otherwise a
+    ``np.random.get_state()`` snapshot to draw from WITHOUT touching the global generator (a draw
+    made ahead on the worker thread): the generator state after the draw is returned as the fourth
+    element and ``run`` installs it only if the global generator still is at the snapshot."""
     shape = (self.num_epochs, sample_size)
     if pinned:
       turn = self._pinned_turn
@@ -258,28 +263,42 @@ class IterateWithMinibatches(RunnerWrapper):
       lib = _lib.load()
     except _lib.NativeError:
       lib = None  # host-only use without the built library: NumPy's own calls (same stream, same result)
+    after = None
     if lib is not None:
-      name, key, pos, has_gauss, cached = np.random.get_state()
+      name, key, pos, has_gauss, cached = np.random.get_state() if state is None else state
       key = np.ascontiguousarray(key, dtype=np.uint32).copy()
       position = ctypes.c_int(int(pos))
       _lib.check(lib.dx_host_compose_permutations(
           key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(position), int(sample_size), int(self.num_epochs),
           int(bool(self.shuffle_before_epoch)), out.ctypes.data_as(ctypes.c_void_p)), "dx_host_compose_permutations")
-      np.random.set_state((name, key, position.value, has_gauss, cached))
+      after = (name, key, position.value, has_gauss, cached)
+      if state is None:
+        np.random.set_state(after)
     else:
+      source = np.random
+      if state is not None:
+        source = np.random.RandomState()
+        source.set_state(state)
       order = np.arange(sample_size)
       for epoch in range(self.num_epochs):
         if self.shuffle_before_epoch:
-          order = order[np.random.permutation(sample_size)]
+          order = order[source.permutation(sample_size)]
         out[epoch] = order
-    return out, staging, turn
+      if state is not None:
+        after = source.get_state()
+    return out, staging, turn, after
+
+  @staticmethod
+  def _same_generator_state(a, b):
+    return (a[0] == b[0] and int(a[2]) == int(b[2]) and int(a[3]) == int(b[3]) and float(a[4]) == float(b[4])
+            and np.array_equal(a[1], b[1]))
 
   def _draw_orders(self, sample_size, device, drawn=None):
     """``_draw_host`` (unless the permutations were drawn ahead) and, for device data, their upload
     with ONE pinned non-blocking copy: a pageable H2D copy per epoch would drain the stream."""
     if drawn is None:
       drawn = self._draw_host(sample_size, pinned=device is not None)
-    orders, staging, turn = drawn
+    orders, staging, turn = drawn[:3]
     orders_dev = None
     if device is not None:
       if staging is None:  # drawn without a staging buffer (cannot happen on the prefetch path)
@@ -307,13 +326,19 @@ class IterateWithMinibatches(RunnerWrapper):
 
   def run(self, obs=None):
     inner = self.runner.run(obs=obs)
-    ahead = None  # (sample_size, future of the NEXT rollout's permutations)
+    # (what it was drawn for, the np.random snapshot it was drawn from, future of the NEXT rollout's
+    # permutations).  The worker never touches the global generator: a draw made ahead counts only
+    # if np.random still is at that snapshot when the rollout it was made for arrives (then the
+    # generator is moved past the draw, as if it had happened now); if anything else drew from or
+    # reseeded np.random meanwhile, the draw is dropped and made now -- the reference's order
+    # (onpolicy.py:44-62: the permutations are drawn after the rollout).
+    ahead = None
     while True:
       try:
         interactions = next(inner)
       except StopIteration:
         if ahead is not None:
-          ahead[1].result()  # never leave a draw running behind the caller's back
+          ahead[2].result()  # never leave a draw running behind the caller's back (its result is dropped)
         return
       sample_size = interactions["observations"].shape[0]
       device = None
@@ -323,18 +348,22 @@ class IterateWithMinibatches(RunnerWrapper):
           break
       drawn = None
       if ahead is not None:
-        drawn_for, future = ahead
+        drawn_for, snapshot, future = ahead
         drawn = future.result()
         ahead = None
-        if drawn_for != (sample_size, device is not None):  # cannot happen with a fixed horizon
+        if (drawn_for != (sample_size, device is not None) or drawn[3] is None
+            or not self._same_generator_state(np.random.get_state(), snapshot)):
           drawn = None
+        else:
+          np.random.set_state(drawn[3])
       _, _, orders, orders_dev = self._draw_orders(sample_size, device, drawn)
       if self._prefetch_allowed():
         if self._worker is None:
           from concurrent.futures import ThreadPoolExecutor  # pylint: disable=import-outside-toplevel
           self._worker = ThreadPoolExecutor(1)
-        ahead = ((sample_size, device is not None),
-                 self._worker.submit(self._draw_host, sample_size, device is not None))
+        snapshot = np.random.get_state()
+        ahead = ((sample_size, device is not None), snapshot,
+                 self._worker.submit(self._draw_host, sample_size, device is not None, snapshot))
       mbsize = sample_size // self.num_minibatches
       extras = None
       if self.prepare is not None and orders_dev is not None:

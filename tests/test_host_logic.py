@@ -208,3 +208,75 @@ def test_native_permutation_composer_is_numpy_bit_for_bit():
     tail_got = np.random.randint(0, 1 << 30, 8)
     nt.assert_array_equal(got, want, err_msg=f"seed {seed} n {n}")
     nt.assert_array_equal(tail_got, tail_want, err_msg="generator state after the draws")
+
+
+class _ResidentRunner:
+  """A device-resident runner as far as IterateWithMinibatches' prefetch rule is concerned
+  (`_device_resident`, `is_exhausted`, `env.host_rng_free`), yielding host arrays."""
+  class _Env:
+    host_rng_free = True
+
+  def __init__(self, rollouts, samples, between=None):
+    self.env, self.unwrapped = self._Env(), self
+    self.rollouts, self.samples, self.between = rollouts, samples, between
+    self.produced = 0
+
+  def _device_resident(self):
+    return True
+
+  def is_exhausted(self):
+    return self.produced >= self.rollouts
+
+  def run(self, obs=None):
+    while self.produced < self.rollouts:
+      if self.between is not None:
+        self.between(self.produced)
+      self.produced += 1
+      base = 1000 * self.produced
+      yield {"observations": np.arange(base, base + self.samples, dtype=np.int64)}
+
+
+def test_permutations_drawn_ahead_keep_the_reference_stream_and_never_touch_a_moved_generator():
+  """IterateWithMinibatches draws the NEXT rollout's permutations on a worker thread from a
+  SNAPSHOT of np.random (derl/runners/onpolicy.py:44-62 draws them after the rollout): the result
+  counts only if the global generator still is at that snapshot when the rollout arrives.  (a) the
+  minibatches equal the reference's order for an undisturbed stream, and np.random ends where the
+  reference's would; (b) a reseed (or any draw) between two rollouts drops the draw made ahead --
+  the old worker can no longer install a stale state behind a new seed (the race that made a
+  native-vs-per-update comparison differ once in ~40 runs)."""
+  from derl_amd.runners.onpolicy import IterateWithMinibatches
+
+  def reference(rollouts, samples, epochs, nmb, between=None):
+    out = []
+    for r in range(rollouts):
+      if between is not None:
+        between(r)
+      obs = np.arange(1000 * (r + 1), 1000 * (r + 1) + samples)
+      order = np.arange(samples)
+      for _ in range(epochs):
+        order = order[np.random.permutation(samples)]
+        out.extend(obs[order[k:k + samples // nmb]] for k in range(0, samples, samples // nmb))
+    return out
+
+  def ours(rollouts, samples, epochs, nmb, between=None):
+    it = IterateWithMinibatches(_ResidentRunner(rollouts, samples, between), num_epochs=epochs, num_minibatches=nmb)
+    assert it._prefetch_allowed()
+    return [np.asarray(mb["observations"]) for mb in it.run()]
+
+  def reseed(r):
+    if r == 2:
+      np.random.seed(99)  # while the draw for rollout 2 made ahead is pending or done
+    if r == 3:
+      np.random.rand(5)   # any other consumer of the stream
+
+  for between in (None, reseed):
+    np.random.seed(21)
+    want = reference(5, 96, 3, 4, between)
+    tail_want = np.random.randint(0, 1 << 30, 4)
+    np.random.seed(21)
+    got = ours(5, 96, 3, 4, between)
+    tail_got = np.random.randint(0, 1 << 30, 4)
+    assert len(got) == len(want) == 5 * 3 * 4
+    for a, b in zip(got, want):
+      nt.assert_array_equal(a, b)
+    nt.assert_array_equal(tail_got, tail_want)
