@@ -624,6 +624,66 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
   }
 }
 
+// DX_FWD_LANES=1 (an experiment, off by default): the forward as two independent chains over the two
+// halves of the rows, the second on the side stream -- what pays for the rollout (two lanes) and
+// for the backward (weight gradients beside data gradients) does NOT pay here: measured per PPO
+// iteration, same box, alternating, 256 envs 41.9 -> 42.8 ms, 128 envs 24.4 -> 25.6 ms.  The two
+// chains run the SAME stage at the same time and compete for the same weights in L2 and the same
+// workgroup slots (each stage already fills 512 of them); half-sized launches only add their ramps.
+// Rows are independent in every forward stage, so the activations are those of the one-chain forward
+// (tests/test_cnn_gpu.py passes with the switch on).
+static int fc_ksplit(int B, int flat);
+static bool fwd_lanes(int B) {
+  static int mode = -2, limit = 0;
+  if (mode == -2) {
+    const char *e = getenv("DX_FWD_LANES");
+    const char *m = getenv("DX_FWD_LANE_MIN");
+    limit = m ? atoi(m) : 4096;
+    mode = e ? atoi(e) : 0;
+  }
+  return B >= 2 && B % 2 == 0 && (mode == 1 || (mode == -1 && B >= limit));
+}
+
+// forward stages first .. last on `s` (as one chain, or as two half-batch chains joined at the end)
+static int forward_stages(const dx_cnn_ctx *c, int first, int last, const void *obs, int obs_is_u8,
+                          const int32_t *sample_idx, int B, hipStream_t s) {
+  SideStream *side = fwd_lanes(B) ? side_stream() : nullptr;
+  if (side == nullptr) {
+    const Plan plan = make_plan(c, B);
+    for (int st = first; st <= last; ++st)
+      if (int rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, s)) return rc;
+    return DX_OK;
+  }
+  const int part = B / 2;
+  dx_cnn_ctx upper = *c;  // rows part .. B-1
+  upper.y0 += static_cast<long long>(part) * c->h0 * c->w0 * kC0;
+  upper.y1 += static_cast<long long>(part) * c->h1 * c->w1 * kC1;
+  upper.y2 += static_cast<long long>(part) * c->flat;
+  upper.hid += static_cast<long long>(part) * kHid;
+  upper.head += static_cast<long long>(part) * kHeadLd;
+  if (upper.hid_slabs) {  // small batches: the linear layer's split-K partials of the two halves side by side
+    upper.hid_slabs += static_cast<long long>(fc_ksplit(part, c->flat)) * part * kHid;
+    upper.hid_slab_count -= static_cast<long long>(fc_ksplit(part, c->flat)) * part * kHid;
+  }
+  const void *obs_upper = obs;
+  const int32_t *idx_upper = nullptr;
+  if (sample_idx) idx_upper = sample_idx + part;
+  else obs_upper = static_cast<const char *>(obs) + static_cast<long long>(part) * c->in_h * c->in_w * c->in_c * (obs_is_u8 ? 1 : 4);
+  const Plan plan = make_plan(c, part);
+  if (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->stream[0], side->fork, 0) != hipSuccess)
+    return fail(DX_EHIP, "forward: cannot order the side stream");
+  int rc = DX_OK;
+  for (int st = first; st <= last && rc == DX_OK; ++st) {
+    rc = run_stage(c, st, obs, obs_is_u8, sample_idx, part, plan, s);
+    if (rc == DX_OK) rc = run_stage(&upper, st, obs_upper, obs_is_u8, idx_upper, part, plan, side->stream[0]);
+  }
+  // also after a failed launch: the caller's stream never runs ahead of the side stream
+  const bool joined = hipEventRecord(side->join[0], side->stream[0]) == hipSuccess &&
+                      hipStreamWaitEvent(s, side->join[0], 0) == hipSuccess;
+  if (!joined && rc == DX_OK) rc = fail(DX_EHIP, "forward: cannot join the side stream");
+  return rc;
+}
+
 // observations (B,H,W,4) uint8 or float32 NHWC [optionally gathered by sample_idx] ->
 // ctx->head (B,32): columns 0..A-1 logits, column A value.  Keeps y0,y1,y2,hid for backward.
 int dx_cnn_forward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const int32_t *sample_idx,
@@ -631,10 +691,7 @@ int dx_cnn_forward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const in
   DX_TRACE("dx_cnn_forward");
   if (int rc = check_ctx(c, "dx_cnn_forward", B, false)) return rc;
   DX_REQUIRE(obs != nullptr, "dx_cnn_forward: null observations");
-  const Plan plan = make_plan(c, B);
-  for (int st = ST_CONV0_FWD; st <= ST_HEADS_FWD; ++st)
-    if (int rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, as_stream(stream))) return rc;
-  return DX_OK;
+  return forward_stages(c, ST_CONV0_FWD, ST_HEADS_FWD, obs, obs_is_u8, sample_idx, B, as_stream(stream));
 }
 
 // conv0 .. linear layer only (ctx->hid): the forward of an update whose heads run inside
@@ -644,10 +701,7 @@ int dx_cnn_forward_trunk(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, co
   DX_TRACE("dx_cnn_forward_trunk");
   if (int rc = check_ctx(c, "dx_cnn_forward_trunk", B, false)) return rc;
   DX_REQUIRE(obs != nullptr, "dx_cnn_forward_trunk: null observations");
-  const Plan plan = make_plan(c, B);
-  for (int st = ST_CONV0_FWD; st <= ST_FC_FWD; ++st)
-    if (int rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, as_stream(stream))) return rc;
-  return DX_OK;
+  return forward_stages(c, ST_CONV0_FWD, ST_FC_FWD, obs, obs_is_u8, sample_idx, B, as_stream(stream));
 }
 
 // ctx->hid (B,512) -> ctx->head, the loss scalars, ctx->dhead, ctx->dhid and the heads' weight /
