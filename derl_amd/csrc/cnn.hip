@@ -424,13 +424,17 @@ static int finalize_grads(const dx_cnn_ctx *c, const Plan &plan, int which, hipS
     j[n++] = PermuteJob{c->slabs + plan.s[layer].b_off, g + off_dst, total, 1, 1, 1, 1, 0, 0, 0, off,
                         plan.s[layer].bsplit, N, 0};
   };
-  if (which & 1) {
-    // conv: iterate the slab [oc][kh][kw][ic] in its own order (coalesced slab reads) and
-    // scatter into the canonical (oc, ic, kh, kw) layout
+  // which: 1 = the three conv layers (= 4 | 8), 2 = linear layer + heads, 4 = conv0 only, 8 = conv1 + conv2
+  if (which & 1) which |= 4 | 8;
+  // conv: iterate the slab [oc][kh][kw][ic] in its own order (coalesced slab reads) and
+  // scatter into the canonical (oc, ic, kh, kw) layout
+  if (which & 4) {
     addw(L_C0, c->off_w[0], kC0 * 64LL * IC0, 8, 8, IC0, IC0 * 64LL, 8, 1, 64, 0, kC0, 64 * IC0, 1);
+    addb(L_C0, c->off_b[0], kC0, 0, kC0);
+  }
+  if (which & 8) {
     addw(L_C1, c->off_w[1], kC1 * 16LL * kC0, 4, 4, kC0, kC0 * 16LL, 4, 1, 16, 0, kC1, 16 * kC0, 1);
     addw(L_C2, c->off_w[2], kC2 * 9LL * kC1, 3, 3, kC1, kC1 * 9LL, 3, 1, 9, 0, kC2, 9 * kC1, 1);
-    addb(L_C0, c->off_b[0], kC0, 0, kC0);
     addb(L_C1, c->off_b[1], kC1, 0, kC1);
     addb(L_C2, c->off_b[2], kC2, 0, kC2);
   }
@@ -745,9 +749,12 @@ static bool bwd_overlap(int B) {
   return mode == 1 || (mode == -1 && B >= limit);
 }
 
-// stages first .. last of the backward (no finalisation) on `s`, the overlapped ones on the side stream
+// Stages first .. last of the backward on `s`, the overlapped ones on the side stream, then the
+// finalisation `which` (finalize_grads).  With the side stream and the whole gradient to finalise
+// (which == 3) the slabs of everything but conv0 are reduced ON the side stream, under the first
+// conv layer's weight gradient (the last stage of the chain), and only conv0's own slabs after it.
 static int backward_stages(const dx_cnn_ctx *c, int first, int last, const void *obs, int obs_is_u8,
-                           const int32_t *sample_idx, int B, const Plan &plan, hipStream_t s) {
+                           const int32_t *sample_idx, int B, const Plan &plan, int which, hipStream_t s) {
   SideStream *side = bwd_overlap(B) ? side_stream() : nullptr;
   bool forked = false;
   int rc = DX_OK;
@@ -760,13 +767,21 @@ static int backward_stages(const dx_cnn_ctx *c, int first, int last, const void 
       }
       forked = true;
     }
+    // the heads' slabs (heads stages or dx_cnn_heads_loss_f32, on `s`) are ordered before the side
+    // stream's finalisation by the fork of the linear layer's weight gradient
     rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, aside ? side->stream[0] : s);
+    static const bool side_finalize = [] { const char *e = getenv("DX_BWD_SIDE_FINALIZE"); return !(e && atoi(e) == 0); }();
+    if (rc == DX_OK && aside && side_finalize && st == ST_CONV1_WGRAD && which == 3 && last == ST_CONV0_WGRAD) {
+      rc = finalize_grads(c, plan, 2 | 8, side->stream[0]);
+      which = 4;
+    }
   }
   if (forked) {  // also after a failed launch: the caller's stream never runs ahead of the side stream
     const bool joined = hipEventRecord(side->join[0], side->stream[0]) == hipSuccess &&
                         hipStreamWaitEvent(s, side->join[0], 0) == hipSuccess;
     if (!joined && rc == DX_OK) rc = fail(DX_EHIP, "backward: cannot join the side stream");
   }
+  if (rc == DX_OK && which != 0) rc = finalize_grads(c, plan, which, s);
   return rc;
 }
 
@@ -778,8 +793,8 @@ int dx_cnn_backward(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, const i
   if (int rc = check_ctx(c, "dx_cnn_backward", B, true)) return rc;
   DX_REQUIRE(obs != nullptr, "dx_cnn_backward: null observations");
   const Plan plan = make_plan(c, B);
-  if (int rc = backward_stages(c, ST_HEADS_WGRAD, ST_CONV0_WGRAD, obs, obs_is_u8, sample_idx, B, plan, as_stream(stream))) return rc;
-  return run_stage(c, ST_FINALIZE, obs, obs_is_u8, sample_idx, B, plan, as_stream(stream));
+  g_route[ST_FINALIZE] = "finalize";
+  return backward_stages(c, ST_HEADS_WGRAD, ST_CONV0_WGRAD, obs, obs_is_u8, sample_idx, B, plan, 3, as_stream(stream));
 }
 
 // The same backward in two calls so that a data-parallel caller can start the all-reduce of the
@@ -799,8 +814,7 @@ int dx_cnn_backward_part(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, co
   // parts 2 / 3: the heads' dgrad and weight-gradient slabs already exist (dx_cnn_heads_loss_f32)
   const int first = part == 0 ? ST_HEADS_WGRAD : part == 1 ? ST_CONV2_WGRAD : ST_FC_WGRAD;
   const int last = (part == 0 || part == 2) ? ST_FC_DGRAD : ST_CONV0_WGRAD;
-  if (int rc = backward_stages(c, first, last, obs, obs_is_u8, sample_idx, B, plan, s)) return rc;
-  return finalize_grads(c, plan, part == 1 ? 1 : part == 3 ? 3 : 2, s);
+  return backward_stages(c, first, last, obs, obs_is_u8, sample_idx, B, plan, part == 1 ? 1 : part == 3 ? 3 : 2, s);
 }
 
 // split of the 3136-deep linear layer over K for small batches (98 K-steps = 2 x 7 x 7)
