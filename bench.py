@@ -310,6 +310,12 @@ def main():
         "bound": "mfma", "kernel": f"{dominant} (minibatch {mb})",
         "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(tf / peak, 4), "traffic": pmc_traffic(dominant, mb),
+        "timing": "HIP events around each stage launched alone (the stage table below).  In the training loop "
+                  "the weight-gradient stages of the linear layer / conv2 / conv1 run on a side stream beside "
+                  "the data-gradient chain (DX_BWD_OVERLAP, minibatches >= 2048), so rocprofv3's per-kernel "
+                  "averages of the default command contain launches that shared the chip; the same command "
+                  "with DX_BWD_OVERLAP=0 gives the stand-alone averages "
+                  "(profiles/r03_b_bench_kernel_stats.csv / r03_b_bench_kernel_stats_serial.csv)",
         "network_fwd_bwd": {"us": round(total_us, 1),
                             "achieved": round(total_flops / (total_us * 1e-6) / 1e12, 2),
                             "frac": round(total_flops / (total_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},

@@ -287,7 +287,9 @@ def test_backward_in_two_parts_equals_whole_backward():
 
 
 @pytest.mark.parametrize("switch", ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_TN_SWIZZLE=0", "DX_LAT_MAX_TILES=0", "DX_WGRAD_DIRECT=0",
-                                    "DX_WGRAD_DIRECT_MIN_B=1", "DX_NT_DMA=0", "DX_NTP=0"])
+                                    "DX_WGRAD_DIRECT_MIN_B=1", "DX_NT_DMA=0", "DX_NTP=0",
+                                    "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
+                                    "DX_BWD_OVERLAP=0 DX_C0_WAVES=4 DX_C0_GROUP4=0"])  # and their serial / round-2 twins
 def test_diagnostic_switches_keep_parity(switch):
   """Every alternative kernel route behind an environment switch (diagnostic switches)
   passes the same golden / oracle comparisons: the switches are read once per process, so a subset
