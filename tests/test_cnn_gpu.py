@@ -286,6 +286,53 @@ def test_backward_in_two_parts_equals_whole_backward():
   assert torch.equal(eng.grads, whole)
 
 
+_STREAMS_PROBE = """
+import hashlib, sys, torch
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/tests/golden")
+import inputs as gi
+from derl_amd.cnn_engine import CnnEngine
+dev = torch.device("cuda")
+torch.manual_seed(5)
+eng = CnnEngine(4, max_batch=2304, device=dev)
+eng.load_state_dict(gi.nature_cnn_weights(4, 3))
+obs = torch.randint(0, 256, (2304, 84, 84, 4), dtype=torch.uint8, device=dev)
+idx = torch.randperm(2304, device=dev).to(torch.int32)
+digest = hashlib.sha256()
+for rep in range(3):  # repeated: a race between the two streams would not hit the same way every time
+  eng.forward(obs, idx)
+  eng._ensure_backward()
+  torch.manual_seed(7)
+  eng.dhead[:2304 * 32].normal_()
+  grads = eng.backward(obs, idx)
+  torch.cuda.synchronize()
+  digest.update(grads.cpu().numpy().tobytes())
+  digest.update(eng.head[:2304 * 32].cpu().numpy().tobytes())
+print("DIGEST", digest.hexdigest())
+"""
+
+
+def test_side_stream_routes_are_bit_identical_to_the_serial_ones():
+  """The backward with its weight-gradient stages (and most of the slab reduction) on the side stream
+  (DX_BWD_OVERLAP) and the forward as two half-batch chains (DX_FWD_LANES) launch the SAME kernels
+  as the serial order on other streams: gradients and outputs must be bit-identical -- a difference
+  would be a missing dependency between the streams (a race), not rounding.  The switches are read
+  once per process: one child process per setting, 2,304 gathered samples, three repetitions each."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  digests = {}
+  for setting in ("DX_BWD_OVERLAP=0 DX_FWD_LANES=0", "DX_BWD_OVERLAP=1 DX_FWD_LANES=0", "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",
+                  "DX_BWD_OVERLAP=1 DX_BWD_SIDE_FINALIZE=0"):
+    env = dict(os.environ)
+    env.update(item.split("=") for item in setting.split())
+    out = subprocess.run([sys.executable, "-c", _STREAMS_PROBE.format(root=root)], env=env, capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    digests[setting] = [line for line in out.stdout.splitlines() if line.startswith("DIGEST")][-1]
+  assert len(set(digests.values())) == 1, digests
+
+
 @pytest.mark.parametrize("switch", ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_TN_SWIZZLE=0", "DX_LAT_MAX_TILES=0", "DX_WGRAD_DIRECT=0",
                                     "DX_WGRAD_DIRECT_MIN_B=1", "DX_NT_DMA=0", "DX_NTP=0",
                                     "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
