@@ -196,7 +196,7 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
     int N, K, bkn;
     layer_nk(c, l, &N, &K, &bkn);
     // capacity (offsets) from max_batch, split from the actual batch
-    const int min_rows = l == L_HD ? 64 : 256;
+    const int min_rows = l == L_HD ? 32 : 256;  // heads: one 4-row batch per wave of the fused heads + loss launch (8 waves)
     long long ms_cap = msplit_bound(layer_rows(c, l, c->max_batch), bkn, min_rows);
     pick_msplit(layer_rows(c, l, B), bkn, min_rows, &p.s[l].msplit, &p.s[l].mper);
     p.s[l].direct = 0;

@@ -12,3 +12,4 @@ for r in rows:
   if any(k in n for k in ("heads_loss","finalize","adam","pack_fused","transpose","split_planes","colsum","sumsq","adv_norm","permute_reduce","categorical_loss","loss_reduce","igemm_tn_kernel<5","igemm_nt_kernel<6","igemm_nt_lat_kernel<4")):
     print(f"{n[:70]:70s} calls {int(r['Calls']):5d} avg {float(r['AverageNs'])/1e3:8.1f} us")
 PY
+rm -f $R/gpurun_out/${TAG}_prof/*kernel_trace.csv
