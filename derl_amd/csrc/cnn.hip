@@ -306,11 +306,10 @@ static uint16_t *planes(const dx_cnn_ctx *c, long long off) {
   return reinterpret_cast<uint16_t *>(c->packed + off);
 }
 
-// canonical parameters -> packed mirrors (call after every parameter change)
-int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
-  DX_TRACE("dx_cnn_pack");
-  if (int rc = check_ctx(c, "dx_cnn_pack", 1, false)) return rc;
-  hipStream_t s = as_stream(stream);
+// canonical parameters -> packed mirrors.  part 1 = what the FIRST conv layer's forward reads (its
+// forward mirror and the bf16 planes of it), part 2 = every other mirror, 3 = both.  The split lets
+// dx_cnn_ppo_epoch start the next minibatch's first layer while the rest is still being packed.
+static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s) {
   const int A = c->num_actions, IC0 = c->in_c, P = c->h2 * c->w2, flat = c->flat;
   const float *w = c->params;
   float *pk = c->packed;
@@ -322,10 +321,19 @@ int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
                  long long s1, long long s2, long long s3, long long off) {
     j[n++] = PermuteJob{src, dst, total, D1, D2, D3, s0, s1, s2, s3, off, 1, 0, 0};
   };
+  const long long wsz0 = kC0 * 64LL * IC0, wsz1 = kC1 * 16LL * kC0, wsz2 = kC2 * 9LL * kC1,
+                  wsz3 = static_cast<long long>(kHid) * flat;
   // conv forward: dst [oc][kh][kw][ic] <- OIHW
-  add(w + c->off_w[0], pk + c->pk_c0f, kC0 * 64LL * IC0, 8, 8, IC0, IC0 * 64LL, 8, 1, 64, 0);
-  add(w + c->off_w[1], pk + c->pk_c1f, kC1 * 16LL * kC0, 4, 4, kC0, kC0 * 16LL, 4, 1, 16, 0);
-  add(w + c->off_w[2], pk + c->pk_c2f, kC2 * 9LL * kC1, 3, 3, kC1, kC1 * 9LL, 3, 1, 9, 0);
+  if (part & 1) add(w + c->off_w[0], pk + c->pk_c0f, wsz0, 8, 8, IC0, IC0 * 64LL, 8, 1, 64, 0);
+  if (part == 1) {  // one-slab "reduction" = the plain permutation, then the planes of the mirror
+    if (int rc = launch_permute_reduce(j, n, s)) return rc;
+    const float *src[1] = {pk + c->pk_c0f};
+    uint16_t *dst[1] = {planes(c, c->pb_c0f)};
+    const long long cnt[1] = {wsz0};
+    return launch_split_planes(src, dst, cnt, 1, s);
+  }
+  add(w + c->off_w[1], pk + c->pk_c1f, wsz1, 4, 4, kC0, kC0 * 16LL, 4, 1, 16, 0);
+  add(w + c->off_w[2], pk + c->pk_c2f, wsz2, 3, 3, kC1, kC1 * 9LL, 3, 1, 9, 0);
   // linear layer: launch_fc_pack below (dst [n][p][c] <- [n][c*P + p], and its transpose)
   // heads: rows 0..A-1 policy logits, row A value
   add(w + c->off_w[4], pk + c->pk_hdf, static_cast<long long>(A) * kHid, 1, 1, kHid, kHid, 0, 0, 1, 0);
@@ -346,14 +354,20 @@ int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
   if (int rc = launch_pack_fused(j, n, w + c->off_w[3], pk + c->pk_fcf, pk + c->pk_fcd, kHid, P, kC2, s)) return rc;
   // bf16 planes (second launch: reads the mirrors packed above): conv0 for the rollout kernel,
   // the other NT mirrors only for the opt-in bf16-split GEMMs
-  const long long wsz0 = kC0 * 64LL * IC0, wsz1 = kC1 * 16LL * kC0, wsz2 = kC2 * 9LL * kC1,
-                  wsz3 = static_cast<long long>(kHid) * flat;
   const float *src[7] = {pk + c->pk_c0f, pk + c->pk_c1f, pk + c->pk_c2f, pk + c->pk_fcf, pk + c->pk_c1d[0],
                          pk + c->pk_c2d, pk + c->pk_fcd};
   uint16_t *dst[7] = {planes(c, c->pb_c0f), planes(c, c->pb_c1f), planes(c, c->pb_c2f), planes(c, c->pb_fcf),
                       planes(c, c->pb_c1d), planes(c, c->pb_c2d), planes(c, c->pb_fcd)};
   const long long cnt[7] = {wsz0, wsz1, wsz2, wsz3, wsz1, wsz2, wsz3};
-  return launch_split_planes(src, dst, cnt, use_b3() ? 7 : 1, s);
+  const int first = (part & 1) ? 0 : 1, count = (use_b3() ? 7 : 1) - first;
+  return count > 0 ? launch_split_planes(src + first, dst + first, cnt + first, count, s) : DX_OK;
+}
+
+// canonical parameters -> packed mirrors (call after every parameter change)
+int dx_cnn_pack(const dx_cnn_ctx *c, void *stream) {
+  DX_TRACE("dx_cnn_pack");
+  if (int rc = check_ctx(c, "dx_cnn_pack", 1, false)) return rc;
+  return pack_part(c, 3, as_stream(stream));
 }
 
 static Gather conv_gather(const void *src, const int32_t *idx, int H, int W, int C, int OH, int OW,
@@ -950,3 +964,39 @@ int dx_cnn_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is_u8,
 }
 
 }  // extern "C"
+
+// ---- for dx_cnn_ppo_epoch (cnn_epoch.hip): pieces of the calls above, and the side stream ----
+namespace dx {
+
+// forward stages first .. last (ST_CONV0_FWD .. ST_HEADS_FWD) of a minibatch already checked by the caller
+int cnn_forward_range(const dx_cnn_ctx *c, int first, int last, const void *obs, int obs_is_u8,
+                      const int32_t *sample_idx, int B, hipStream_t s) {
+  return forward_stages(c, first, last, obs, obs_is_u8, sample_idx, B, s);
+}
+
+int cnn_pack_part(const dx_cnn_ctx *c, int part, hipStream_t s) { return pack_part(c, part, s); }
+
+// the library's side stream, ordered after everything enqueued on `s` so far (NULL: unavailable)
+hipStream_t cnn_side_begin(hipStream_t s) {
+  SideStream *side = side_stream();
+  if (side == nullptr) return nullptr;
+  if (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->stream[0], side->fork, 0) != hipSuccess) {
+    fail(DX_EHIP, "cnn_side_begin: cannot order the side stream");
+    return nullptr;
+  }
+  return side->stream[0];
+}
+
+// `s` ordered after everything enqueued on the side stream
+int cnn_side_end(hipStream_t s) {
+  SideStream *side = side_stream();
+  if (side == nullptr) return DX_EHIP;
+  if (hipEventRecord(side->join[0], side->stream[0]) != hipSuccess || hipStreamWaitEvent(s, side->join[0], 0) != hipSuccess) {
+    (void)hipStreamSynchronize(side->stream[0]);
+    return fail(DX_EHIP, "cnn_side_end: cannot join the side stream");
+  }
+  return DX_OK;
+}
+
+}  // namespace dx
+

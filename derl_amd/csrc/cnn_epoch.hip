@@ -11,18 +11,37 @@
 // interpreter between them -- at the 8-GPU shard size of BASELINE config 2 (32 envs per GPU) the
 // interpreter took as long as the kernels -- and the exchange step now sits INSIDE the call
 // (dx_allreduce_grads between the two halves of the backward).
+#include <cstdlib>
+
 #include "common.hpp"
+#include "igemm.hpp"
 
 namespace dx {
 bool comm_active();
 int comm_allreduce_async(float *buf, long long count, hipStream_t stream);
 int comm_wait(hipStream_t stream);
+// cnn.hip: pieces of dx_cnn_forward / dx_cnn_pack and the library's side stream
+int cnn_forward_range(const dx_cnn_ctx *c, int first, int last, const void *obs, int obs_is_u8,
+                      const int32_t *sample_idx, int B, hipStream_t s);
+int cnn_pack_part(const dx_cnn_ctx *c, int part, hipStream_t s);
+hipStream_t cnn_side_begin(hipStream_t s);
+int cnn_side_end(hipStream_t s);
 }  // namespace dx
 
 using namespace dx;
 
+static int epoch_body(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream, bool &tail_on_side);
+
 extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream) {
   DX_TRACE("dx_cnn_ppo_epoch");
+  bool tail_on_side = false;  // part of an update's tail is still on the library's side stream
+  const int rc = epoch_body(c, e, stream, tail_on_side);
+  // only after a failed launch: the caller's stream never runs ahead of the side stream
+  if (tail_on_side) (void)cnn_side_end(as_stream(stream));
+  return rc;
+}
+
+static int epoch_body(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream, bool &tail_on_side) {
   DX_REQUIRE(c != nullptr && e != nullptr, "dx_cnn_ppo_epoch: null argument");
   DX_REQUIRE(e->struct_bytes == static_cast<int>(sizeof(dx_cnn_epoch)),
              "dx_cnn_ppo_epoch: struct size mismatch (caller %d, library %d)", e->struct_bytes,
@@ -58,6 +77,13 @@ extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void
     if (int rc = dx_adv_stats_segments_f32(e->advantages, nullptr, e->samples, e->mbsize, e->stats, stream)) return rc;
     stats_all = e->stats;
   }
+  // DX_EPOCH_TAIL_OVERLAP=1 (an experiment, off by default): step and re-pack the first conv layer
+  // first and leave the rest of an update's tail to the side stream, beside the next minibatch's
+  // first layer.  Measured SLOWER (same box, alternating): 256 envs 43.5 -> 44.1 ms per iteration,
+  // 32 envs 11.33 -> 12.17 ms -- a dependency between two HIP streams costs tens of microseconds on
+  // this stack, more than the ~35 us of small launches it hides (the backward's side stream pays the
+  // same price and wins only because it hides whole GEMM stages).
+  static const bool tail_overlap = [] { const char *v = getenv("DX_EPOCH_TAIL_OVERLAP"); return v && atoi(v) != 0; }();
   int k = 0;
   for (long long start = 0; start < e->samples; start += e->mbsize, ++k) {
     const int B = static_cast<int>(e->samples - start < e->mbsize ? e->samples - start : e->mbsize);
@@ -80,8 +106,19 @@ extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void
             start * c->in_h * c->in_w * c->in_c * (e->obs_is_u8 ? 1 : 4);
     const float *olp = e->old_log_prob ? e->old_log_prob + start : nullptr;
     const float *ov = e->old_values ? e->old_values + start : nullptr;
-    if (fused_heads) {
+    if (tail_on_side) {
+      // the previous update left everything but the first conv layer's parameters and mirrors to the
+      // side stream: this minibatch's first layer runs beside that, the rest of the forward after it
+      if (int rc = cnn_forward_range(c, ST_CONV0_FWD, ST_CONV0_FWD, obs, e->obs_is_u8, idx, B, s)) return rc;
+      tail_on_side = false;
+      if (int rc = cnn_side_end(s)) return rc;
+      if (int rc = cnn_forward_range(c, ST_CONV1_FWD, fused_heads ? ST_FC_FWD : ST_HEADS_FWD, obs, e->obs_is_u8, idx, B, s)) return rc;
+    } else if (fused_heads) {
       if (int rc = dx_cnn_forward_trunk(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
+    } else {
+      if (int rc = dx_cnn_forward(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
+    }
+    if (fused_heads) {
       const double *st = e->normalize ? stats_all + 3LL * k : nullptr;
       if (int rc = dx_cnn_heads_loss_f32(c, e->actions + start, olp, e->advantages + start, ov, e->value_targets + start,
                                          st, e->norm_eps, e->normalize ? e->adv_normalized + start : nullptr, B, e->mode,
@@ -90,7 +127,6 @@ extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void
                                          e->loss_partials_capacity, e->loss_counter, e->loss_out + 8LL * k, stream))
         return rc;
     } else {
-      if (int rc = dx_cnn_forward(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
       if (int rc = dx_categorical_loss_f32(c->head, e->actions + start, olp, adv, ov, e->value_targets + start, B,
                                            c->num_actions, e->mode, e->cliprange, e->value_loss_coef, e->entropy_coef,
                                            static_cast<long long>(B) * e->world, c->dhead, e->loss_partials,
@@ -110,6 +146,29 @@ extern "C" int dx_cnn_ppo_epoch(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void
     }
     if (int rc = dx_grad_sumsq_f32(c->grads, c->param_count, e->sumsq_partials, e->npartials, stream)) return rc;
     float *norm_out = e->grad_norm_out ? e->grad_norm_out + static_cast<long long>(e->grad_norm_stride) * k : nullptr;
+    const bool more = start + e->mbsize < e->samples;
+    if (e->optimizer == 0 && more && tail_overlap) {
+      // Another minibatch follows: the first conv layer's parameters (weight + bias: the head of the
+      // parameter vector) are stepped and re-packed FIRST, on this stream; the other 99.5 % of the
+      // parameters and their mirrors follow on the side stream, beside the next minibatch's first
+      // layer.  The same element-wise kernels over two ranges: the parameters are bit-identical to the
+      // one-launch step's.
+      const long long head_n = c->off_b[0] + 32;  // conv0 weight + bias (multiple of 4 floats)
+      if (int rc = dx_clip_adam_step_f32(c->params, c->grads, e->state0, e->state1, head_n, e->sumsq_partials,
+                                         e->npartials, e->max_grad_norm, e->lr, e->beta1, e->beta2, e->opt_eps,
+                                         e->first_step + k, norm_out, stream))
+        return rc;
+      if (int rc = cnn_pack_part(c, 1, s)) return rc;
+      hipStream_t side = cnn_side_begin(s);
+      if (side == nullptr) return DX_EHIP;
+      tail_on_side = true;
+      int rc = dx_clip_adam_step_f32(c->params + head_n, c->grads + head_n, e->state0 + head_n, e->state1 + head_n,
+                                     c->param_count - head_n, e->sumsq_partials, e->npartials, e->max_grad_norm, e->lr,
+                                     e->beta1, e->beta2, e->opt_eps, e->first_step + k, nullptr, side);
+      if (rc == DX_OK) rc = cnn_pack_part(c, 2, side);
+      if (rc != DX_OK) return rc;
+      continue;
+    }
     if (e->optimizer == 0) {
       if (int rc = dx_clip_adam_step_f32(c->params, c->grads, e->state0, e->state1, c->param_count, e->sumsq_partials,
                                          e->npartials, e->max_grad_norm, e->lr, e->beta1, e->beta2, e->opt_eps,
