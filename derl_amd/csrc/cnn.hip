@@ -773,7 +773,10 @@ static int backward_stages(const dx_cnn_ctx *c, int first, int last, const void 
   bool forked = false;
   int rc = DX_OK;
   for (int st = first; st <= last && rc == DX_OK; ++st) {
-    const bool aside = side != nullptr && (st == ST_FC_WGRAD || st == ST_CONV2_WGRAD || st == ST_CONV1_WGRAD);
+    // DX_BWD_OVERLAP_MASK: which weight-gradient stages go aside (1 = linear layer, 2 = conv2, 4 = conv1)
+    static const int aside_mask = [] { const char *e = getenv("DX_BWD_OVERLAP_MASK"); return e ? atoi(e) : 7; }();
+    const bool aside = side != nullptr && ((st == ST_FC_WGRAD && (aside_mask & 1)) || (st == ST_CONV2_WGRAD && (aside_mask & 2)) ||
+                                            (st == ST_CONV1_WGRAD && (aside_mask & 4)));
     if (aside) {  // everything enqueued on `s` so far (this layer's output gradient) comes first
       if (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->stream[0], side->fork, 0) != hipSuccess) {
         rc = fail(DX_EHIP, "backward: cannot order the side stream");
