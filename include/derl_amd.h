@@ -16,7 +16,12 @@
  *  - every function returns 0 on success, a negative DX_E* code on failure and never
  *    throws; dx_last_error() returns a thread-local message for the last failure;
  *  - shapes are validated on the host before any launch (a bad shape never reaches a
- *    kernel).
+ *    kernel);
+ *  - the dx_cnn_* calls of ONE device must come from one host thread at a time: the native
+ *    rollout, the backward of minibatches >= 2,048 samples and dx_cnn_ppo_epoch put part of
+ *    their launches on side streams the library owns per device (created on first use, ordered
+ *    against `stream` with events and always joined before the call's later launches on
+ *    `stream`; one process per GPU -- the launcher contract -- satisfies this).
  */
 #ifndef DERL_AMD_H
 #define DERL_AMD_H
