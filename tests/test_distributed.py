@@ -40,12 +40,15 @@ def test_two_rank_data_parallel_ppo_learns_and_replicas_stay_identical():
 
 
 @pytest.mark.gpu
-def test_rccl_communicator_behind_the_c_abi_runs_the_data_path_at_world_size_1():
+@pytest.mark.parametrize("overlap", ["-1", "1"])
+def test_rccl_communicator_behind_the_c_abi_runs_the_data_path_at_world_size_1(overlap):
   """dx_comm_init / dx_allreduce_grads / dx_allreduce_sum_f64 / dx_comm_broadcast_f32 on a real
   RCCL communicator (one rank: all this box has), bootstrapped over torch.distributed's nccl
-  backend, with the sharded code path forced: see dist_worker.rccl_one_rank."""
+  backend, with the sharded code path forced: see dist_worker.rccl_one_rank.  Second case: the
+  backward's side stream forced on at the test's small minibatches (at 2-4 GPUs a shard's
+  minibatch is >= 2,048 samples and the all-reduces sit between two overlapped halves)."""
   env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29516", RANK="0", WORLD_SIZE="1",
-             LOCAL_RANK="0", DERL_AMD_FORCE_COLLECTIVES="1", OMP_NUM_THREADS="2")
+             LOCAL_RANK="0", DERL_AMD_FORCE_COLLECTIVES="1", OMP_NUM_THREADS="2", DX_BWD_OVERLAP=overlap)
   out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "rccl_one_rank"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
