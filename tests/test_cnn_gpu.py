@@ -193,6 +193,54 @@ def test_backward_ragged_batches_with_gather(batch):
     nt.assert_allclose(grads[k].cpu().numpy(), og, rtol=1e-4, atol=1e-5 + 1e-5 * scale, err_msg=k)
 
 
+@pytest.mark.parametrize("shape,batch", [((80, 96), 40), ((80, 96), 640), ((64, 64), 40), ((64, 64), 640)])
+def test_other_frame_geometries_match_the_oracle(shape, batch):
+  """The reference's NatureCNN takes any frame size (models.py:94-124 derives the linear layer's width
+  from the conv stack).  80x96 frames -> 19x23, 8x10, 6x8 feature maps (an output width that is not
+  a multiple of 4: the first layer's per-pixel offset table; dedicated weight-gradient kernels that
+  do not cover the shape), 64x64 -> 15x15, 6x6, 4x4 (fewer than 256 first-layer pixels per image: no
+  direct first-layer kernel at all).  Batch 40 takes the small-batch kernels, 640 = five groups of
+  128 images the persistent ring kernels.  Forward layer by layer against torch-CPU float32,
+  gradients against float64 autograd on the ReLU branch the engine took."""
+  H, W = shape
+  rs = np.random.RandomState(H * 1000 + batch)
+  A = 5
+  dims = [((H - 8) // 4 + 1, (W - 8) // 4 + 1)]
+  dims.append(((dims[0][0] - 4) // 2 + 1, (dims[0][1] - 4) // 2 + 1))
+  dims.append((dims[1][0] - 2, dims[1][1] - 2))
+  flat = dims[2][0] * dims[2][1] * 64
+  weights = {}
+  for name, wshape in [("base.conv-0", (32, 4, 8, 8)), ("base.conv-1", (64, 32, 4, 4)), ("base.conv-2", (64, 64, 3, 3)),
+                       ("base.linear", (512, flat)), ("output_layers.0", (A, 512)), ("output_layers.1", (1, 512))]:
+    fan_in = int(np.prod(wshape[1:]))
+    weights[f"{name}.weight"] = (rs.standard_normal(wshape) * 1.4 / np.sqrt(fan_in)).astype(np.float32)
+    weights[f"{name}.bias"] = (rs.standard_normal(wshape[0]) * 0.05).astype(np.float32)
+  base = rs.randint(0, 256, size=(batch + 3, H, W, 4)).astype(np.int32)
+  pool = np.where(rs.uniform(size=(batch + 3, H, W, 1)) < 0.35, base, base // 8).astype(np.uint8)
+  idx = rs.permutation(batch + 3)[:batch].astype(np.int32)
+  from derl_amd.cnn_engine import CnnEngine
+  eng = CnnEngine(A, input_shape=(H, W, 4), max_batch=max(256, batch), device=DEV)
+  eng.load_state_dict(weights)
+  data = dict(observations=pool, actions=rs.randint(0, A, batch).astype(np.int64),
+              log_prob=(rs.standard_normal(batch) * 0.1 - 1.7).astype(np.float32),
+              advantages=rs.standard_normal(batch).astype(np.float32),
+              values=rs.standard_normal((batch, 1)).astype(np.float32) * 0.2,
+              value_targets=rs.standard_normal((batch, 1)).astype(np.float32))
+  loss, grads = run_loss_and_backward(eng, data, 0, 0.1, 0.25, 0.01, A, torch.from_numpy(idx).to(DEV))
+  obs = pool[idx]
+  masks = []
+  for name, (h, w), c, r in zip(("y0", "y1", "y2"), dims, (32, 64, 64), oracle_activations(weights, obs)):
+    y = getattr(eng, name)[:batch * h * w * c].view(batch, h, w, c)
+    nt.assert_allclose(y.cpu().numpy(), r, rtol=1e-4, atol=2e-5, err_msg=name)
+    masks.append((y > 0).permute(0, 3, 1, 2).contiguous().cpu().numpy())
+  terms, ograds = oracle.ppo_loss_and_grads(weights, dict(data, observations=obs), "cnn", 0.1, 0.25, 0.01,
+                                            dtype=torch.float64, relu_masks=masks)
+  nt.assert_allclose(loss[0], terms["loss"], rtol=1e-4, atol=1e-5)
+  for k, og in ograds.items():
+    scale = np.abs(og).max()
+    nt.assert_allclose(grads[k].cpu().numpy(), og, rtol=1e-4, atol=1e-5 + 1e-5 * scale, err_msg=k)
+
+
 def engine_relu_masks(eng, batch):
   """The ReLU masks of the engine's last forward: kept post-activation outputs > 0 (NHWC in
   HBM), returned NCHW like the oracle's activations."""
