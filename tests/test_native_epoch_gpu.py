@@ -51,9 +51,11 @@ def make_alg(kind, native, nenvs, horizon, epochs, nmb):
     env = derl.env.make("HalfCheetah-v3", nenvs=nenvs, seed=3)
   elif kind == "cnn":
     env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=nenvs, seed=3)
+  elif kind == "cnn18":  # 18 actions: wider than the fused heads + loss launch covers (A + 1 <= 8)
+    env = derl.env.make("SeaquestNoFrameskip-v4", nenvs=nenvs, seed=3)
   else:
     env = DeviceVectorEnv(nenvs, 11, 5, seed=3)
-  kwargs = derl.PPOFactory.get_kwargs("atari" if kind == "cnn" else "mujoco")
+  kwargs = derl.PPOFactory.get_kwargs("atari" if kind.startswith("cnn") else "mujoco")
   kwargs.update(nenvs=nenvs, num_runner_steps=horizon, num_epochs=epochs, num_minibatches=nmb,
                 num_train_steps=nenvs * horizon * 4, entropy_coef=0.01)
   alg = derl.PPOFactory(**kwargs).make(env)
@@ -95,7 +97,7 @@ def run(kind, native, nenvs, horizon, epochs, nmb, rollouts, keep_host=False):
 
 
 # 33 envs x 16 steps = 528 samples in 5 minibatches of 105 + a ragged sixth of 3
-@pytest.mark.parametrize("kind", ["gaussian", "categorical", "cnn"])
+@pytest.mark.parametrize("kind", ["gaussian", "categorical", "cnn", "cnn18"])
 def test_native_epoch_equals_per_update_path_and_oracle(kind):
   nenvs, horizon, epochs, nmb, rollouts = 33, 16, 2, 5, 2
   fast = run(kind, True, nenvs, horizon, epochs, nmb, rollouts, keep_host=True)
@@ -111,7 +113,9 @@ def test_native_epoch_equals_per_update_path_and_oracle(kind):
     assert torch.equal(a, b)
   assert torch.equal(fast["params"], slow["params"])
   assert torch.equal(fast["m"], slow["m"]) and torch.equal(fast["v"], slow["v"])
-  if kind == "cnn":  # the conv path's oracle parity: the golden Trainer.step tests (same native call)
+  if kind.startswith("cnn"):  # the conv path's oracle parity: the golden Trainer.step tests (same native call)
+    if kind == "cnn18":
+      assert not fast["alg"].model.engine.fused_heads()  # forward + separate loss launch + whole backward
     return
   # the oracle on the first epoch's minibatches (incl. the ragged one), from the same start
   alg = fast["alg"]
