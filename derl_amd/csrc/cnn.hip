@@ -33,11 +33,13 @@ bool use_b3() {  // experiment build + DX_SPLIT_BF16=1: big NT stages on the bf1
 #endif
 }
 
-// DX_C0LAT_MAX_TILES: largest 32-pixel tile count of the rollout conv0 kernel.  Measured crossover
-// against the 256-pixel-tile kernel: B=64 9.4 vs 11.1 us, B=128 14.7 vs 11.7 us, B=256 25.8 vs 15.0 us.
+// DX_C0LAT_MAX_TILES: largest 32-pixel tile count of the rollout conv0 kernel.  Crossover against the
+// 256-pixel-tile kernel (eight waves per tile, pre-split planes: round 3), per PPO iteration on one
+// box: 32 envs 10.96 vs 11.03 ms, 64 envs 17.69 vs 17.32 ms -- the 32x32-tile kernel up to 500 tiles
+// (40 images).  (Round 2, four waves per tile: B=64 9.4 vs 11.1 us, B=128 14.7 vs 11.7 us.)
 int conv0_lat_max_tiles() {
   static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_C0LAT_MAX_TILES"); v = e ? atoi(e) : 1024; }
+  if (v < 0) { const char *e = getenv("DX_C0LAT_MAX_TILES"); v = e ? atoi(e) : 500; }
   return v;
 }
 
