@@ -136,7 +136,7 @@ def main():
                       "(BASELINE.md 3.1: the GPU run's shapes)")
   parser.add_argument("--cpu-iterations", type=int, default=3, help="timed CPU iterations after --cpu-warmup")
   parser.add_argument("--cpu-warmup", type=int, default=1)
-  parser.add_argument("--cpu-budget-s", type=float, default=150.0,
+  parser.add_argument("--cpu-budget-s", type=float, default=35.0,
                       help="cuts the timed CPU iterations (never below 1) to fit this many seconds")
   parser.add_argument("--no-roofline", action="store_true")
   parser.add_argument("--no-other-configs", action="store_true")
