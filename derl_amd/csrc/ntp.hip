@@ -633,10 +633,21 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
 // sum_k A[m][k] W[n][k] : 0 (mask given; N = 49 pixels x 64 channels of the conv stack) or the
 // forward out[m][n] = bias[n] + sum_k A[m][k] W[n][k] (bias given).  The tile walk is the dgrad one
 // with the column tile in the pixel's place (MODE 2).
+// DX_NTP_FC_FWD_MIN_TILES: fewest 128x64 tiles for the linear layer's FORWARD to take the ring kernel.
+// Its alternative, nt_dma.hip, has 128x128 tiles: at 2,048-2,560 rows (a 64-env shard's minibatch,
+// config 5's shard) that is 64-80 workgroups walking 98 K steps each on a 256-CU chip -- 197 us for
+// 2,560 rows where the 8,192-row minibatch takes 202 us; 128-160 ring-kernel tiles use twice the CUs.
+int ntp_fc_fwd_min_tiles() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_NTP_FC_FWD_MIN_TILES"); v = e ? atoi(e) : 128; }
+  return v;
+}
+
 int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, const float *bias, float *out, int M,
                     int N, int K, hipStream_t stream) {
+  const int min_tiles = bias != nullptr && ntp_fc_fwd_min_tiles() < ntp_min_tiles() ? ntp_fc_fwd_min_tiles() : ntp_min_tiles();
   if (!ntp_on() || N % ShapeS::BN || K % kBK || lda < K || lda % 4 || M % ShapeS::BM || M / ShapeS::BM < 8 ||
-      1LL * (M / ShapeS::BM) * (N / ShapeS::BN) < ntp_min_tiles() || (mask != nullptr) == (bias != nullptr) ||
+      1LL * (M / ShapeS::BM) * (N / ShapeS::BN) < min_tiles || (mask != nullptr) == (bias != nullptr) ||
       // 32-bit per-lane byte offsets: rows of A ((tile * BM + R) * lda * 4) and of out / mask
       4LL * M * N >= (1LL << 32) || 4LL * M * lda >= (1LL << 32))
     return DX_ENOSUP;
