@@ -542,7 +542,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       a.ksplit = ks;
       a.slab_stride = static_cast<long long>(B) * kHid;
       if (ks == 1 && ntp_fc_fwd()) {
-        if (const int rc = took("ntp", launch_ntp_rows(c->y2, flat, pk + c->pk_fcf, nullptr, w + c->off_b[3], c->hid, B, kHid, flat, s));
+        if (const int rc = took("ntp", launch_ntp_rows(c->y2, flat, pk + c->pk_fcf, nullptr, w + c->off_b[3], c->hid, B, kHid, flat, c->hid_slabs, c->hid_slabs ? c->hid_slab_count : 0, s));
             rc != DX_ENOSUP)
           return rc;
       }
@@ -572,7 +572,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       }
       return took("igemm_tn", tn(L_FC, rows_gather(c->y2, flat), c->dhid, kHid, B, kHid, flat, false));
     case ST_FC_DGRAD:
-      if (const int rc = took("ntp", launch_ntp_rows(c->dhid, kHid, pk + c->pk_fcd, c->y2, nullptr, c->dy2, B, flat, kHid, s)); rc != DX_ENOSUP)
+      if (const int rc = took("ntp", launch_ntp_rows(c->dhid, kHid, pk + c->pk_fcd, c->y2, nullptr, c->dy2, B, flat, kHid, nullptr, 0, s)); rc != DX_ENOSUP)
         return rc;
       if (nt_dma_on() && nt_dma_supported(B, flat, kHid)) {
         const NtDmaArgs d{c->dhid, pk + c->pk_fcd, nullptr, c->y2, c->dy2, B, flat, kHid, kHid, flat};

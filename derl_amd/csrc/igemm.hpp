@@ -112,8 +112,9 @@ int launch_nt_b3(const NTArgs &a, int epi, int stage, hipStream_t stream);
 // persistent LDS-DMA ring kernels for the 64-column conv stages (ntp.hip); DX_ENOSUP = not covered
 int launch_ntp_fwd(const NTArgs &a, int stage, hipStream_t stream);
 int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream);
+// ksplit_slabs (optional, ksplit_capacity floats): scratch for the forward's two K halves at small tile counts
 int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, const float *bias, float *out, int M,
-                    int N, int K, hipStream_t stream);
+                    int N, int K, float *ksplit_slabs, long long ksplit_capacity, hipStream_t stream);
 
 // plain row-major NT GEMM fed by LDS-DMA (nt_dma.hip): the linear layer's forward and dgrad
 struct NtDmaArgs {

@@ -157,7 +157,7 @@ def test_loss_and_gradients_match_reference_golden(name):
 # XCD-aware block numbering from 64 reduction slices, pixel-group dgrads with a ragged last group)
 # 2048: the persistent ring kernels with few tiles per workgroup + nt_dma for the linear layer
 # 1152 = 9 groups of 128 images: the ring kernels with one XCD holding two image groups, the others one
-@pytest.mark.parametrize("batch", [1, 5, 37, 130, 1024, 1152, 2048, 2100, 8192])  # 8192 = BASELINE minibatch
+@pytest.mark.parametrize("batch", [1, 5, 37, 130, 1024, 1152, 2048, 2100, 2560, 8192])  # 8192 = BASELINE minibatch; 2560 = config 5's shard (K-split linear forward, uneven row groups per XCD)
 def test_backward_ragged_batches_with_gather(batch):
   rs = np.random.RandomState(batch)
   A = 6
