@@ -681,9 +681,12 @@ static int forward_stages(const dx_cnn_ctx *c, int first, int last, const void *
   upper.y2 += static_cast<long long>(part) * c->flat;
   upper.hid += static_cast<long long>(part) * kHid;
   upper.head += static_cast<long long>(part) * kHeadLd;
-  if (upper.hid_slabs) {  // small batches: the linear layer's split-K partials of the two halves side by side
-    upper.hid_slabs += static_cast<long long>(fc_ksplit(part, c->flat)) * part * kHid;
-    upper.hid_slab_count -= static_cast<long long>(fc_ksplit(part, c->flat)) * part * kHid;
+  dx_cnn_ctx lower = *c;  // rows 0 .. part-1: the same buffers, but only its half of the split-K scratch
+  if (upper.hid_slabs) {  // the linear layer's split-K partials of the two halves side by side
+    const long long half = c->hid_slab_count / 2 / 4 * 4;
+    upper.hid_slabs += half;
+    upper.hid_slab_count -= half;
+    lower.hid_slab_count = half;
   }
   const void *obs_upper = obs;
   const int32_t *idx_upper = nullptr;
@@ -694,7 +697,7 @@ static int forward_stages(const dx_cnn_ctx *c, int first, int last, const void *
     return fail(DX_EHIP, "forward: cannot order the side stream");
   int rc = DX_OK;
   for (int st = first; st <= last && rc == DX_OK; ++st) {
-    rc = run_stage(c, st, obs, obs_is_u8, sample_idx, part, plan, s);
+    rc = run_stage(&lower, st, obs, obs_is_u8, sample_idx, part, plan, s);
     if (rc == DX_OK) rc = run_stage(&upper, st, obs_upper, obs_is_u8, idx_upper, part, plan, side->stream[0]);
   }
   // also after a failed launch: the caller's stream never runs ahead of the side stream

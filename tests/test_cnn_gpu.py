@@ -342,20 +342,20 @@ import inputs as gi
 from derl_amd.cnn_engine import CnnEngine
 dev = torch.device("cuda")
 torch.manual_seed(5)
-eng = CnnEngine(4, max_batch=2304, device=dev)
+eng = CnnEngine(4, max_batch=4608, device=dev)
 eng.load_state_dict(gi.nature_cnn_weights(4, 3))
-obs = torch.randint(0, 256, (2304, 84, 84, 4), dtype=torch.uint8, device=dev)
-idx = torch.randperm(2304, device=dev).to(torch.int32)
+obs = torch.randint(0, 256, (4608, 84, 84, 4), dtype=torch.uint8, device=dev)
+idx = torch.randperm(4608, device=dev).to(torch.int32)
 digest = hashlib.sha256()
 for rep in range(3):  # repeated: a race between the two streams would not hit the same way every time
   eng.forward(obs, idx)
   eng._ensure_backward()
   torch.manual_seed(7)
-  eng.dhead[:2304 * 32].normal_()
+  eng.dhead[:4608 * 32].normal_()
   grads = eng.backward(obs, idx)
   torch.cuda.synchronize()
   digest.update(grads.cpu().numpy().tobytes())
-  digest.update(eng.head[:2304 * 32].cpu().numpy().tobytes())
+  digest.update(eng.head[:4608 * 32].cpu().numpy().tobytes())
 print("DIGEST", digest.hexdigest())
 """
 
@@ -365,7 +365,8 @@ def test_side_stream_routes_are_bit_identical_to_the_serial_ones():
   (DX_BWD_OVERLAP) and the forward as two half-batch chains (DX_FWD_LANES) launch the SAME kernels
   as the serial order on other streams: gradients and outputs must be bit-identical -- a difference
   would be a missing dependency between the streams (a race), not rounding.  The switches are read
-  once per process: one child process per setting, 2,304 gathered samples, three repetitions each."""
+  once per process: one child process per setting, 4,608 gathered samples (the whole batch and its
+  halves of 2,304 rows take the same kernel routes), three repetitions each."""
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
