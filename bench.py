@@ -315,7 +315,7 @@ def main():
                   "the data-gradient chain (DX_BWD_OVERLAP, minibatches >= 2048), so rocprofv3's per-kernel "
                   "averages of the default command contain launches that shared the chip; the same command "
                   "with DX_BWD_OVERLAP=0 gives the stand-alone averages "
-                  "(profiles/r03_c_bench_kernel_stats.csv / r03_c_bench_kernel_stats_serial.csv)",
+                  "(profiles/r03_d_bench_kernel_stats.csv / r03_d_bench_kernel_stats_serial.csv)",
         "network_fwd_bwd": {"us": round(total_us, 1),
                             "achieved": round(total_flops / (total_us * 1e-6) / 1e12, 2),
                             "frac": round(total_flops / (total_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
