@@ -85,6 +85,11 @@ struct NtpArgs {
   // adds the bias); the launcher sums the parts afterwards
   int ks_shift;
   long long slab_bytes;
+  // MODE 1: an XCD walks a CONTIGUOUS eighth of the (image group, pixel) tiles instead of whole groups
+  // (group g on XCD g % 8): with a group count that is not a multiple of 8 some XCDs owned one group
+  // more than the others (config 5's shard, 20 groups: 3 against 2 -- conv1_dgrad 173 us where the
+  // balanced walk takes 145)
+  int blocked;
   int TA, TB, PA, PB;  // run grid and the element pitch of a step in ta / tb (see Cursor)
   // MODE 0: the K steps of a tile in the order they are walked (element offsets into the input
   // window and into a row of Wp).  The order is free (any permutation of the K axis); the
@@ -135,13 +140,20 @@ __device__ __forceinline__ void open_tile(Cursor &c, const NtpArgs &p) {
   } else {
     const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
     const uint32_t u = (blockIdx.x >> 3) + c.i * per;
-    uint32_t gl = fdiv(u, g.div_img);
-    c.pix = u - gl * g.OHW;
-    if (MODE == 2 && p.rows_inner) {
-      c.pix = fdiv(u, p.div_groups);
-      gl = u - c.pix * p.groups_per_xcd;
+    if ((MODE == 1 || MODE == 2) && p.blocked) {  // tile t of the group-major list, this XCD's contiguous eighth
+      const uint32_t t = xcd * static_cast<uint32_t>(p.tiles_per_xcd) + u;
+      const uint32_t gb = fdiv(t, g.div_img);
+      c.pix = t - gb * g.OHW;
+      c.tile = gb;
+    } else {
+      uint32_t gl = fdiv(u, g.div_img);
+      c.pix = u - gl * g.OHW;
+      if (MODE == 2 && p.rows_inner) {
+        c.pix = fdiv(u, p.div_groups);
+        gl = u - c.pix * p.groups_per_xcd;
+      }
+      c.tile = gl * 8 + xcd;
     }
-    c.tile = gl * 8 + xcd;
     c.valid = u < static_cast<uint32_t>(p.tiles_per_xcd) && c.tile < p.ngroups;
     if (MODE == 2) {  // plain rows: the "pixel" is the column tile (x the K part), one run of K elements
       const int kp = c.pix & ((1 << p.ks_shift) - 1);
@@ -579,7 +591,7 @@ int launch_ntp_fwd(const NTArgs &a, int stage, hipStream_t stream) {
   NtpArgs p;
   p.nt = a;
   p.nimg = p.ngroups = p.tiles_per_xcd = p.diag = p.rows_inner = 0;
-  p.ks_shift = 0; p.slab_bytes = 0;
+  p.ks_shift = 0; p.slab_bytes = 0; p.blocked = 0;
   p.groups_per_xcd = 1; p.div_groups = make_fastdiv(1);
   p.TA = g.nseg; p.TB = 1; p.PA = g.nseg > 1 ? g.seg_off[1] : 0; p.PB = 0;
   const int per_run = g.seglen / kBK, taps_per_run = g.seglen / g.C, steps_per_tap = g.C / kBK;
@@ -632,11 +644,13 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
   p.nt = a;
   p.ntiles = p.diag = p.rows_inner = 0;
   p.ks_shift = 0; p.slab_bytes = 0;
+  static const bool blocked_on = [] { const char *e = getenv("DX_NTP_BLOCKED"); return !(e && atoi(e) == 0); }();
+  p.blocked = blocked_on ? 1 : 0;
   p.groups_per_xcd = 1; p.div_groups = make_fastdiv(1);
   p.TA = TA; p.TB = TB; p.PA = g.seg_off[TB]; p.PB = g.seg_off[1];
   p.nimg = nimg;
   p.ngroups = nimg / (large ? ShapeL::BM : ShapeS::BM);
-  p.tiles_per_xcd = cdiv(p.ngroups, 8) * g.OHW;
+  p.tiles_per_xcd = p.blocked ? static_cast<int>((1LL * p.ngroups * g.OHW + 7) / 8) : cdiv(p.ngroups, 8) * g.OHW;
   return large ? launch_as<ST_CONV1_DGRAD, 1, EPI_MASK, ShapeL>(p, stream) : launch_as<ST_CONV2_DGRAD, 1, EPI_MASK, ShapeS>(p, stream);
 }
 
@@ -690,6 +704,10 @@ int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, 
   // whose row blocks (128 x 3136 floats) are the bigger operand, went 155 -> 218 MB and keeps the old walk);
   // every XCD must own the same number of row groups
   p.rows_inner = mask != nullptr && p.ngroups % 8 == 0 && rows_inner_on();
+  // a row-group count that is not a multiple of 8: contiguous eighths of the tile list (see NtpArgs::blocked)
+  static const bool blocked_on = [] { const char *e = getenv("DX_NTP_BLOCKED"); return !(e && atoi(e) == 0); }();
+  p.blocked = (blocked_on && !p.rows_inner && p.ngroups % 8 != 0) ? 1 : 0;
+  if (p.blocked) p.tiles_per_xcd = static_cast<int>((1LL * p.ngroups * gn + 7) / 8);
   p.groups_per_xcd = p.ngroups / 8 > 0 ? p.ngroups / 8 : 1;
   p.div_groups = make_fastdiv(p.groups_per_xcd);
   if (mask) return launch_as<ST_FC_DGRAD, 2, EPI_MASK, ShapeS>(p, stream);
@@ -699,7 +717,7 @@ int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, 
     g.OHW = 2 * gn; g.OW = 2 * gn; g.div_img = make_fastdiv(2 * gn); g.div_row = make_fastdiv(2 * gn);
     g.seglen = K / 2;
     p.PA = K / 2;
-    p.tiles_per_xcd = cdiv(p.ngroups, 8) * 2 * gn;
+    p.tiles_per_xcd = p.blocked ? static_cast<int>((2LL * p.ngroups * gn + 7) / 8) : cdiv(p.ngroups, 8) * 2 * gn;
     p.nt.out = ksplit_slabs;
     if (int rc = launch_as<ST_FC_FWD, 2, EPI_BIAS, ShapeF>(p, stream)) return rc;
     const PermuteJob sum{ksplit_slabs, out, 1LL * M * N, 1, 1, 1, 1, 0, 0, 0, 0, 2, 1LL * M * N, 0};
