@@ -535,17 +535,19 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     case ST_FC_FWD: {
       // small minibatches (multi-GPU shards): 49 sequential 64-deep K steps on 128 workgroups are
       // a latency chain; split K 7 ways into the rollout slabs and sum them into hid
+      // (the ring kernel first: from 1,024 rows up it covers the layer, with K in 7 / 2 parts through the
+      // same slabs while its tiles are few)
+      if (B >= 1024 && ntp_fc_fwd()) {
+        if (const int rc = took("ntp", launch_ntp_rows(c->y2, flat, pk + c->pk_fcf, nullptr, w + c->off_b[3], c->hid, B, kHid, flat, c->hid_slabs, c->hid_slabs ? c->hid_slab_count : 0, s));
+            rc != DX_ENOSUP)
+          return rc;
+      }
       const int ks = (B <= 1024 && c->hid_slabs && 7LL * B * kHid <= c->hid_slab_count && flat % (7 * 64) == 0) ? 7 : 1;
       a = nt_args(rows_gather(c->y2, flat), pk + c->pk_fcf, w + c->off_b[3], ks > 1 ? c->hid_slabs : c->hid,
                   kHid, B, kHid, flat);
       a.Wb = planes(c, c->pb_fcf); a.wb_plane = static_cast<long long>(kHid) * flat;
       a.ksplit = ks;
       a.slab_stride = static_cast<long long>(B) * kHid;
-      if (ks == 1 && ntp_fc_fwd()) {
-        if (const int rc = took("ntp", launch_ntp_rows(c->y2, flat, pk + c->pk_fcf, nullptr, w + c->off_b[3], c->hid, B, kHid, flat, c->hid_slabs, c->hid_slabs ? c->hid_slab_count : 0, s));
-            rc != DX_ENOSUP)
-          return rc;
-      }
       if (ks == 1 && nt_dma_on() && nt_dma_supported(B, kHid, flat)) {
         const NtDmaArgs d{c->y2, pk + c->pk_fcf, w + c->off_b[3], nullptr, c->hid, B, kHid, flat, flat, kHid};
         return took("nt_dma", launch_nt_dma(d, EPI_BIAS, s));

@@ -79,11 +79,12 @@ struct NtpArgs {
   // fc_dgrad fetched 484 MB for 126 MB of operands.
   int rows_inner, groups_per_xcd;
   FastDiv div_groups;
-  // MODE 2 forward with few tiles: K in 1 << ks_shift parts -- the "column tile" index carries the part
-  // in its low bits (tile walk and cursor unchanged: the part is the cursor's run `ta`, PA elements
+  // MODE 2 forward with few tiles: K in `kparts` parts (1, 2 or 7 of the linear layer's 98 steps) --
+  // the "column tile" index is column tile * kparts + part (tile walk and cursor unchanged: the part is the cursor's run `ta`, PA elements
   // apart in a row of A and of W), part kp writes its partial sums to out + kp * slab_bytes (part 0
   // adds the bias); the launcher sums the parts afterwards
-  int ks_shift;
+  int kparts;
+  FastDiv div_kparts;
   long long slab_bytes;
   // MODE 1: an XCD walks a CONTIGUOUS eighth of the (image group, pixel) tiles instead of whole groups
   // (group g on XCD g % 8): with a group count that is not a multiple of 8 some XCDs owned one group
@@ -156,7 +157,7 @@ __device__ __forceinline__ void open_tile(Cursor &c, const NtpArgs &p) {
     }
     c.valid = u < static_cast<uint32_t>(p.tiles_per_xcd) && c.tile < p.ngroups;
     if (MODE == 2) {  // plain rows: the "pixel" is the column tile (x the K part), one run of K elements
-      const int kp = c.pix & ((1 << p.ks_shift) - 1);
+      const int kp = c.pix - static_cast<int>(fdiv(c.pix, p.div_kparts)) * p.kparts;
       c.ta = kp; c.ta_hi = kp; c.tb_lo = 0; c.tb_hi = 0; c.pixoff = 0;
     } else {
       const int y = fdiv(c.pix, g.div_row), x = c.pix - y * g.OW;  // unit stride (checked on the host)
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
         4LL * (MODE == 0 ? p.step_ao[ld.q] : ld.pixoff + ld.ta * p.PA + ld.tb * p.PB + ld.q);    \
     const char *wbase_ = reinterpret_cast<const char *>(a.Wp) +                                  \
         4LL * (MODE == 0 ? p.step_ko[ld.q] : (ld.ta * p.TB + ld.tb) * g.seglen + ld.q) +         \
-        (MODE == 2 ? 4LL * (ld.pix >> p.ks_shift) * S::BN * a.K : 0LL);                          \
+        (MODE == 2 ? 4LL * fdiv(ld.pix, p.div_kparts) * S::BN * a.K : 0LL);                      \
     _Pragma("unroll") for (int q_ = 0; q_ < S::APIECES; ++q_)                                    \
         dma_piece(abase_, av[q_], dst_ + (wave + S::NLOAD * q_) * 256);                         \
     _Pragma("unroll") for (int j_ = 0; j_ < S::WPIECES; ++j_)                                    \
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
     // Tiles are never ragged (the launchers require whole tiles): a guarded store or load here is
     // a branch, and the compiler then drains vmcnt at the loop header.
     // element (t, r) of column block j: uniform part (tile, wave, t, r) + lane part (hi, l31)
-    const long long rowbytes = 4LL * (MODE == 0 ? a.ldc : (a.om.enabled ? a.om.OUT_H * a.om.OUT_W : (MODE == 2 ? g.OHW >> p.ks_shift : g.OHW)) * a.ldc);
+    const long long rowbytes = 4LL * (MODE == 0 ? a.ldc : (a.om.enabled ? a.om.OUT_H * a.om.OUT_W : (MODE == 2 ? static_cast<int>(fdiv(g.OHW, p.div_kparts)) : g.OHW)) * a.ldc);
     const long long tile0 = static_cast<long long>(tile * BM + wm * 32 * TM) * rowbytes;  // uniform
     if (kDiag && (p.diag & 16)) {  // diagnostic: no epilogue traffic
     } else if (MODE == 0) {
@@ -399,8 +400,9 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
           const int gq = nb / om.chan;
           const int py = gq / om.osx, px = gq - py * om.osx;
           pix0[j] = 4LL * (((oy * om.osy + py) * om.OUT_W + ox * om.osx + px) * a.ldc + (nb - gq * om.chan));
-        } else if (MODE == 2) {  // column tile pix >> ks_shift of K part pix & mask
-          pix0[j] = 4LL * ((pix >> p.ks_shift) * a.ldc + nb) + (pix & ((1 << p.ks_shift) - 1)) * p.slab_bytes;
+        } else if (MODE == 2) {  // column tile pix / kparts of K part pix % kparts
+          const int cp = static_cast<int>(fdiv(pix, p.div_kparts));
+          pix0[j] = 4LL * (cp * a.ldc + nb) + (pix - cp * p.kparts) * p.slab_bytes;
         } else {
           pix0[j] = 4LL * (pix * a.ldc + nb);
         }
@@ -409,7 +411,8 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
       if (EPI == EPI_BIAS) {  // plain rows forward: the bias of this column tile, no mask
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const float bj = (pix & ((1 << p.ks_shift) - 1)) ? 0.f : a.bias[(pix >> p.ks_shift) * S::BN + wn * 32 * TN + 32 * j + l31];
+          const int cpb = static_cast<int>(fdiv(pix, p.div_kparts));
+          const float bj = (pix - cpb * p.kparts) ? 0.f : a.bias[cpb * S::BN + wn * 32 * TN + 32 * j + l31];
 #pragma unroll
           for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -591,7 +594,7 @@ int launch_ntp_fwd(const NTArgs &a, int stage, hipStream_t stream) {
   NtpArgs p;
   p.nt = a;
   p.nimg = p.ngroups = p.tiles_per_xcd = p.diag = p.rows_inner = 0;
-  p.ks_shift = 0; p.slab_bytes = 0; p.blocked = 0;
+  p.kparts = 1; p.div_kparts = make_fastdiv(1); p.slab_bytes = 0; p.blocked = 0;
   p.groups_per_xcd = 1; p.div_groups = make_fastdiv(1);
   p.TA = g.nseg; p.TB = 1; p.PA = g.nseg > 1 ? g.seg_off[1] : 0; p.PB = 0;
   const int per_run = g.seglen / kBK, taps_per_run = g.seglen / g.C, steps_per_tap = g.C / kBK;
@@ -643,7 +646,7 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
   NtpArgs p;
   p.nt = a;
   p.ntiles = p.diag = p.rows_inner = 0;
-  p.ks_shift = 0; p.slab_bytes = 0;
+  p.kparts = 1; p.div_kparts = make_fastdiv(1); p.slab_bytes = 0;
   static const bool blocked_on = [] { const char *e = getenv("DX_NTP_BLOCKED"); return !(e && atoi(e) == 0); }();
   p.blocked = blocked_on ? 1 : 0;
   p.groups_per_xcd = 1; p.div_groups = make_fastdiv(1);
@@ -671,24 +674,31 @@ int ntp_fc_fwd_min_tiles() {
 int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, const float *bias, float *out, int M,
                     int N, int K, float *ksplit_slabs, long long ksplit_capacity, hipStream_t stream) {
   const int min_tiles = bias != nullptr && ntp_fc_fwd_min_tiles() < ntp_min_tiles() ? ntp_fc_fwd_min_tiles() : ntp_min_tiles();
-  // Forward with at most ONE tile per CU even after cutting K in two (<= 16 row groups of 128: up to
-  // 2,048 rows): every tile is a chain of K / 32 = 98 dependent steps on a chip that is a quarter to
-  // half full, so K in two halves doubles the tiles and halves the chains; the halves meet in one small
-  // reduction.  Measured at 2,048 rows: 119 -> 85 us incl. the reduction; at 2,560 / 3,072 rows the
-  // doubled tiles share CUs and it loses (118 -> 131, 121 -> 137 us).  DX_NTP_FC_FWD_KSPLIT=0: off.
-  static const bool ksplit_on = [] { const char *e = getenv("DX_NTP_FC_FWD_KSPLIT"); return !(e && atoi(e) == 0); }();
+  // Forward with few tiles: every tile is a chain of K / 32 = 98 dependent steps on a chip that is a
+  // quarter to half full.  K in `kparts` parts multiplies the tiles and shortens the chains; the parts
+  // meet in one small reduction.  Two halves where that still leaves at most ONE tile per CU (<= 16 row
+  // groups of 128): 2,048 rows 119 -> 85 us incl. the reduction, 1,152 rows 200 -> 75 us; at 2,560 /
+  // 3,072 rows the doubled tiles share CUs and it loses (118 -> 131, 121 -> 137 us).  Seven parts (the
+  // other divisor of the 98 steps) for <= 8 row groups, where halves would fill a quarter of the chip.
+  // DX_NTP_FC_FWD_KSPLIT=0: off; =2: halves only.
+  static const int ksplit_mode = [] { const char *e = getenv("DX_NTP_FC_FWD_KSPLIT"); return e ? atoi(e) : 1; }();
   const long long whole_tiles = (M % ShapeS::BM || N % ShapeS::BN) ? 0 : 1LL * (M / ShapeS::BM) * (N / ShapeS::BN);
-  const bool ksplit = ksplit_on && bias != nullptr && whole_tiles > 0 && K % (2 * kBK) == 0 && ksplit_slabs &&
-                      2LL * M * N <= ksplit_capacity && whole_tiles < ntp_min_tiles() &&
-                      cdiv(M / ShapeS::BM, 8) * 2 * (N / ShapeS::BN) <= 32;
+  int kparts = 1;
+  if (ksplit_mode != 0 && bias != nullptr && whole_tiles > 0 && ksplit_slabs && whole_tiles < ntp_min_tiles()) {
+    const int groups = M / ShapeS::BM, cols = N / ShapeS::BN, steps = K / kBK;
+    if (ksplit_mode == 1 && groups <= 8 && steps % 7 == 0 && 7LL * M * N <= ksplit_capacity) kparts = 7;
+    else if (steps % 2 == 0 && cdiv(groups, 8) * 2 * cols <= 32 && 2LL * M * N <= ksplit_capacity) kparts = 2;
+  }
+  const bool ksplit = kparts > 1;
   if (!ntp_on() || N % ShapeS::BN || K % kBK || lda < K || lda % 4 || M % ShapeS::BM || M / ShapeS::BM < 8 ||
-      (ksplit ? 2 : 1) * whole_tiles < min_tiles || (mask != nullptr) == (bias != nullptr) ||
+      kparts * whole_tiles < min_tiles || (mask != nullptr) == (bias != nullptr) ||
       // 32-bit per-lane byte offsets: rows of A ((tile * BM + R) * lda * 4) and of out / mask
       4LL * M * N >= (1LL << 32) || 4LL * M * lda >= (1LL << 32))
     return DX_ENOSUP;
   DX_REQUIRE(A && W && out && aligned(A, 16) && aligned(W, 16), "ntp_rows: bad operands");
   NtpArgs p;
   std::memset(&p, 0, sizeof(p));
+  p.kparts = 1; p.div_kparts = make_fastdiv(1);
   const int gn = N / ShapeS::BN;
   Gather &g = p.nt.g;
   g.src = A; g.img_stride = lda; g.H = g.W = 1; g.C = K;
@@ -712,15 +722,15 @@ int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, 
   p.div_groups = make_fastdiv(p.groups_per_xcd);
   if (mask) return launch_as<ST_FC_DGRAD, 2, EPI_MASK, ShapeS>(p, stream);
   if (ksplit) {
-    p.ks_shift = 1;
+    p.kparts = kparts; p.div_kparts = make_fastdiv(kparts);
     p.slab_bytes = 4LL * M * N;
-    g.OHW = 2 * gn; g.OW = 2 * gn; g.div_img = make_fastdiv(2 * gn); g.div_row = make_fastdiv(2 * gn);
-    g.seglen = K / 2;
-    p.PA = K / 2;
-    p.tiles_per_xcd = p.blocked ? static_cast<int>((2LL * p.ngroups * gn + 7) / 8) : cdiv(p.ngroups, 8) * 2 * gn;
+    g.OHW = kparts * gn; g.OW = kparts * gn; g.div_img = make_fastdiv(kparts * gn); g.div_row = make_fastdiv(kparts * gn);
+    g.seglen = K / kparts;
+    p.PA = K / kparts;
+    p.tiles_per_xcd = p.blocked ? static_cast<int>((1LL * kparts * p.ngroups * gn + 7) / 8) : cdiv(p.ngroups, 8) * kparts * gn;
     p.nt.out = ksplit_slabs;
     if (int rc = launch_as<ST_FC_FWD, 2, EPI_BIAS, ShapeF>(p, stream)) return rc;
-    const PermuteJob sum{ksplit_slabs, out, 1LL * M * N, 1, 1, 1, 1, 0, 0, 0, 0, 2, 1LL * M * N, 0};
+    const PermuteJob sum{ksplit_slabs, out, 1LL * M * N, 1, 1, 1, 1, 0, 0, 0, 0, kparts, 1LL * M * N, 0};
     return launch_permute_reduce(&sum, 1, stream);
   }
   return launch_as<ST_FC_FWD, 2, EPI_BIAS, ShapeF>(p, stream);
