@@ -284,9 +284,10 @@ int dx_cnn_init(dx_cnn_ctx *c) {
   c->y2_count = mb * d.flat;
   c->hid_count = mb * kHid;
   c->head_count = mb * kHeadLd;
-  // rollout path: [ksplit][B][512] partial slabs, ksplit = 7 (B <= 1024), else 1
+  // [parts][B][512] partial sums of the linear layer's forward: 7 parts up to 1,024 rows (rollout path,
+  // small minibatches) and for the ring kernel's K split up to 2,560 rows (3,072 rows of capacity)
   long long hs = mb;
-  const long long mid = mb < 1024 ? mb : 1024;
+  const long long mid = mb < 3072 ? mb : 3072;
   if (hs < 7 * mid) hs = 7 * mid;
   c->hid_slab_count = hs * kHid;
   return DX_OK;

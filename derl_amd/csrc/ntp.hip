@@ -680,14 +680,18 @@ int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, 
   // groups of 128): 2,048 rows 119 -> 85 us incl. the reduction, 1,152 rows 200 -> 75 us; at 2,560 /
   // 3,072 rows the doubled tiles share CUs and it loses (118 -> 131, 121 -> 137 us).  Seven parts (the
   // other divisor of the 98 steps) for <= 8 row groups, where halves would fill a quarter of the chip.
-  // DX_NTP_FC_FWD_KSPLIT=0: off; =2: halves only.
+  // DX_NTP_FC_FWD_KSPLIT=0: off; =2: halves only; =7: seven parts wherever the scratch allows (experiments).
   static const int ksplit_mode = [] { const char *e = getenv("DX_NTP_FC_FWD_KSPLIT"); return e ? atoi(e) : 1; }();
   const long long whole_tiles = (M % ShapeS::BM || N % ShapeS::BN) ? 0 : 1LL * (M / ShapeS::BM) * (N / ShapeS::BN);
   int kparts = 1;
   if (ksplit_mode != 0 && bias != nullptr && whole_tiles > 0 && ksplit_slabs && whole_tiles < ntp_min_tiles()) {
     const int groups = M / ShapeS::BM, cols = N / ShapeS::BN, steps = K / kBK;
-    if (ksplit_mode == 1 && groups <= 8 && steps % 7 == 0 && 7LL * M * N <= ksplit_capacity) kparts = 7;
+    if (ksplit_mode == 7 && steps % 7 == 0 && 7LL * M * N <= ksplit_capacity) kparts = 7;  // experiment: wherever it fits
+    else if (ksplit_mode == 1 && groups <= 8 && steps % 7 == 0 && 7LL * M * N <= ksplit_capacity) kparts = 7;
     else if (steps % 2 == 0 && cdiv(groups, 8) * 2 * cols <= 32 && 2LL * M * N <= ksplit_capacity) kparts = 2;
+    // 17-20 row groups (config 5's shard: 2,560 rows): seven parts again -- 2,304 rows 116 -> 93 us,
+    // 2,560 rows 119 -> 107 us incl. the reduction; from 24 groups on it loses (3,072 rows 122 -> 128 us)
+    else if (ksplit_mode == 1 && groups <= 20 && steps % 7 == 0 && 7LL * M * N <= ksplit_capacity) kparts = 7;
   }
   const bool ksplit = kparts > 1;
   if (!ntp_on() || N % ShapeS::BN || K % kBK || lda < K || lda % 4 || M % ShapeS::BM || M / ShapeS::BM < 8 ||

@@ -230,7 +230,7 @@ typedef struct dx_cnn_ctx {
   long long pk_c0f, pk_c1f, pk_c2f, pk_fcf, pk_hdf, pk_hdb, pk_c1d[4], pk_c2d, pk_fcd, pk_hdd;
   long long packed_count, slab_count;
   long long y0_count, y1_count, y2_count, hid_count, head_count;  /* floats per buffer */
-  long long hid_slab_count;         /* split-K partials of the linear layer (rollout path) */
+  long long hid_slab_count;         /* split-K partials of the linear layer's forward (rollout, small and mid-size minibatches) */
   /* offsets (in floats, inside `packed`) of the bf16 planes [3][N][K] of the NT weight mirrors:
    * conv1 fwd, conv2 fwd, linear fwd, conv1 dgrad (4 parity packs as one matrix), conv2 dgrad,
    * linear dgrad -- operands of the bf16-split GEMMs (igemm_b3.hip) */
