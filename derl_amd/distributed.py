@@ -75,8 +75,9 @@ def init_from_env(backend=None):
     try:
       init_native_comm()
     except _lib.NativeError as error:
-      # every rank fails or succeeds alike (the id broadcast comes first); without the library's
-      # communicator the run continues on torch.distributed's own RCCL collectives, update by update
+      # init_native_comm raises on EVERY rank or on none (its ranks agree through a MIN all-reduce
+      # before any of them leaves): without the library's communicator the whole run continues on
+      # torch.distributed's own RCCL collectives, update by update
       print(f"derl_amd: native RCCL communicator unavailable ({error}); using torch.distributed", flush=True)
   return world_size()
 
@@ -84,23 +85,54 @@ def init_from_env(backend=None):
 def init_native_comm():
   """Creates the library's RCCL communicator over the ranks of the default process group: rank 0
   makes the unique id (dx_comm_unique_id), one torch.distributed broadcast hands it out, every
-  rank joins (dx_comm_init) on its current device."""
+  rank joins (dx_comm_init) on its current device.
+
+  The ranks AGREE on the outcome before any of them acts on it.  A rank whose library call fails
+  keeps the error to itself and still takes part in both bootstrap collectives: rank 0 broadcasts
+  an all-zero id when it could not make one (a real id is never all zero), and a MIN all-reduce of
+  the per-rank success flags follows dx_comm_init.  Either every rank returns with the
+  communicator up, or every rank tears its own down again and raises NativeError -- no rank is
+  left waiting in a collective the others never enter, and no two ranks disagree on whether the
+  data path reduces through the library or through torch.distributed."""
   global _native  # pylint: disable=global-statement
   if _native:
     return
   if not is_initialized():
     raise RuntimeError("init_native_comm: torch.distributed is not initialised (the unique id "
                        "travels over it)")
-  ident = (ctypes.c_ubyte * 128)()
-  if rank() == 0:
-    _lib.call("dx_comm_unique_id", ctypes.byref(ident))
   on_gpu = dist.get_backend() == "nccl"
-  carrier = torch.tensor(list(ident), dtype=torch.uint8)
-  if on_gpu:
-    carrier = carrier.cuda()
+  device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+  ident = (ctypes.c_ubyte * 128)()
+  problem = None
+  if rank() == 0:
+    try:
+      _lib.call("dx_comm_unique_id", ctypes.byref(ident))
+    except _lib.NativeError as error:
+      problem = error
+      ident = (ctypes.c_ubyte * 128)()  # the all-zero id tells the others
+  carrier = torch.tensor(list(ident), dtype=torch.uint8, device=device)
   dist.broadcast(carrier, src=0)
-  ident = (ctypes.c_ubyte * 128)(*carrier.cpu().tolist())
-  _lib.call("dx_comm_init", ctypes.byref(ident), rank(), world_size())
+  received = carrier.cpu().tolist()
+  joined = False
+  if not any(received):
+    problem = problem or _lib.NativeError("rank 0 could not create the communicator's unique id")
+  else:
+    ident = (ctypes.c_ubyte * 128)(*received)
+    try:
+      _lib.call("dx_comm_init", ctypes.byref(ident), rank(), world_size())
+      joined = True
+    except _lib.NativeError as error:
+      problem = error
+  verdict = torch.tensor([1 if joined else 0], dtype=torch.int32, device=device)
+  dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+  if int(verdict.item()) == 0:
+    if joined:
+      try:
+        _lib.call("dx_comm_destroy")
+      except _lib.NativeError:
+        pass
+    raise _lib.NativeError(str(problem) if problem is not None else
+                           "another rank could not join the communicator")
   _native = True
 
 

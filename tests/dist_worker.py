@@ -66,6 +66,74 @@ def cpu_math():
   print(f"rank {rank}: cpu_math OK", flush=True)
 
 
+def bootstrap_agreement():
+  """init_native_comm with the library calls replaced by scripted ones (no GPU, gloo): whatever
+  fails on whichever rank, BOTH ranks leave the bootstrap the same way -- with the communicator,
+  or with NativeError and their own communicator torn down -- and the next collective of the
+  process group still matches up (nobody is left inside the id broadcast)."""
+  from derl_amd import _lib
+  world, rank = distributed.world_size(), distributed.rank()
+  assert world == 2
+  real_call = _lib.call
+  log = []
+
+  def scripted(fail_id_on=None, fail_init_on=None):
+    def call(name, *args):
+      log.append(name)
+      if name == "dx_comm_unique_id":
+        if rank == fail_id_on:
+          raise _lib.NativeError("scripted: no unique id")
+        ident = args[0]._obj
+        for i in range(128):
+          ident[i] = (37 * i + 11) % 251 + 1
+        return 0
+      if name == "dx_comm_init":
+        assert bytes(args[0]._obj) == bytes((37 * i + 11) % 251 + 1 for i in range(128))
+        assert (args[1], args[2]) == (rank, world)
+        if rank == fail_init_on:
+          raise _lib.NativeError("scripted: cannot join")
+        return 0
+      if name == "dx_comm_destroy":
+        return 0
+      return real_call(name, *args)
+    return call
+
+  def attempt(**script):
+    del log[:]
+    _lib.call = scripted(**script)
+    try:
+      distributed.init_native_comm()
+      outcome = "native"
+    except _lib.NativeError as error:
+      outcome = "fallback: " + str(error)
+    finally:
+      _lib.call = real_call
+    ones = torch.ones(3)
+    torch.distributed.all_reduce(ones)  # would hang / mismatch if a rank were still in the bootstrap
+    assert ones.tolist() == [2.0, 2.0, 2.0]
+    native = distributed.native_comm()
+    distributed._native = False  # pylint: disable=protected-access
+    return outcome, native, list(log)
+
+  # rank 1 cannot join: both fall back, rank 0 (which had joined) destroys its communicator
+  outcome, native, calls = attempt(fail_init_on=1)
+  assert outcome.startswith("fallback") and not native, (rank, outcome)
+  assert calls == (["dx_comm_unique_id", "dx_comm_init", "dx_comm_destroy"] if rank == 0 else ["dx_comm_init"]), calls
+  # rank 0 cannot join: the same, mirrored
+  outcome, native, calls = attempt(fail_init_on=0)
+  assert outcome.startswith("fallback") and not native, (rank, outcome)
+  assert calls == (["dx_comm_unique_id", "dx_comm_init"] if rank == 0 else ["dx_comm_init", "dx_comm_destroy"]), calls
+  # rank 0 cannot even make the id: it still broadcasts (zeros); nobody calls dx_comm_init
+  outcome, native, calls = attempt(fail_id_on=0)
+  assert outcome.startswith("fallback") and not native, (rank, outcome)
+  assert calls == (["dx_comm_unique_id"] if rank == 0 else []), calls
+  # nothing fails: both ranks have the communicator
+  outcome, native, calls = attempt()
+  assert outcome == "native" and native, (rank, outcome)
+  assert "dx_comm_destroy" not in calls
+  print(f"rank {rank}: bootstrap_agreement OK", flush=True)
+
+
 def gpu_step():
   import derl_amd as derl
   from derl_amd.optim import Adam
@@ -277,6 +345,6 @@ def rccl_one_rank():
 if __name__ == "__main__":
   mode = sys.argv[1]
   distributed.init_from_env(backend="nccl" if mode.startswith("rccl") else "gloo")
-  {"cpu_math": cpu_math, "gpu_step": gpu_step, "gpu_minibatch_stats": gpu_minibatch_stats,
+  {"cpu_math": cpu_math, "bootstrap_agreement": bootstrap_agreement, "gpu_step": gpu_step, "gpu_minibatch_stats": gpu_minibatch_stats,
    "gpu_learns": gpu_learns, "rccl_one_rank": rccl_one_rank}[mode]()
   distributed.destroy()

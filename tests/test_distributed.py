@@ -24,6 +24,13 @@ def test_sharding_rules_world_size_2_gloo_cpu():
   launch("cpu_math", 29511)
 
 
+def test_native_comm_bootstrap_ranks_agree_on_failure_world_size_2_gloo_cpu():
+  """A library failure on ONE rank during the communicator bootstrap (unique id on rank 0, or
+  dx_comm_init on either rank) makes BOTH ranks fall back, and no rank is left in a collective:
+  dist_worker.bootstrap_agreement."""
+  launch("bootstrap_agreement", 29518)
+
+
 @pytest.mark.gpu
 def test_two_ranks_one_gpu_step_matches_single_process():
   launch("gpu_step", 29512)
