@@ -4,7 +4,7 @@ Import surface mirrors ``derl/__init__.py`` for the on-policy path (PPO / A2C); 
 SAC families of the reference are out of scope."""
 from . import distributed, env, summary
 from .alg import Alg, Loss, Trainer, PPO, PPOLoss, A2C, A2CLoss
-from .anneal import AnnealingVariable, LinearAnneal
+from .anneal import AnnealingVariable, LinearAnneal, TorchSched
 from .factory import Factory, KwargsDict, PPOFactory, A2CFactory
 from .models import NatureCNNBase, NatureCNNModel, make_model, GatheredRows
 from .mlp_models import MLP, MuJoCoModel, MLPCategoricalModel

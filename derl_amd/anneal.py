@@ -1,6 +1,6 @@
 """Schedules that move a 0-dim tensor as training progresses -- the contract of derl/anneal.py
 (``AnnealingVariable``: ``get_tensor`` / ``step`` / ``step_to`` / ``summarize``;
-``LinearAnneal(start, nsteps, end=0.)``).
+``LinearAnneal(start, nsteps, end=0.)``, ``TorchSched(scheduler)``).
 
 The tensor object is created once and mutated in place, so an optimizer that was given
 ``schedule.get_tensor()`` as its learning rate follows the schedule.  ``LinearAnneal.step_to`` jumps
@@ -53,6 +53,29 @@ class AnnealingVariable(ABC):
 
   def summarize(self, global_step):
     summary.add_scalar(f"anneal/{self.name}", self.get_tensor(), global_step=global_step)
+
+
+class TorchSched(AnnealingVariable):
+  """Follows a ``torch.optim.lr_scheduler`` object (derl/anneal.py:46-62): the tensor holds the
+  scheduler's last learning rates, one element per parameter group of the optimizer the scheduler
+  drives.  (No factory uses it; the flat optimizers of this package take ``LinearAnneal``'s 0-dim
+  tensor.  It is here so that code written against derl's annealing API keeps working.)"""
+  def __init__(self, scheduler, name=None):
+    super().__init__(name)
+    self.scheduler = scheduler
+    self.tensor = self._last_rates()
+
+  def _last_rates(self):
+    return torch.tensor(self.scheduler.get_last_lr())
+
+  def get_tensor(self):
+    return self.tensor
+
+  def step(self):
+    self.scheduler.step()
+    self.step_count += 1
+    self.tensor.data = self._last_rates()
+    return self.get_current_value()
 
 
 class LinearAnneal(AnnealingVariable):

@@ -7,10 +7,17 @@
 // this sits inside is derl/alg/common.py:66-78 (Trainer.step: backward -> [all-reduce] -> clip ->
 // optimizer step).
 //
+// ONE communicator is only ever driven from ONE stream: every collective -- the gradient
+// all-reduces, the float64 statistics all-reduce, the parameter broadcast -- is enqueued on the
+// library's stream behind a `ready` event of the caller's stream; the in-stream ones make the
+// caller's stream wait for their `done` event at once, the gradient all-reduces at
+// dx_allreduce_wait.
+//
 // RCCL is resolved with dlopen at dx_comm_init: the library has no link-time dependency on it
 // (it loads, and every other entry point works, on a box without RCCL), and inside a torch
 // process the copy torch already loaded is the one used (same HIP runtime).
 #include "common.hpp"
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
@@ -87,6 +94,50 @@ int require_comm(const char *who) {
   return DX_OK;
 }
 
+#if DX_DIAG
+// Ordering probe (diag flavour only; it computes WRONG results on purpose).
+// DX_COMM_TEST_HOOK="<delay_us>:<scale>": behind every gradient all-reduce the library's stream
+// first idles for delay_us and then multiplies the reduced buffer by `scale`.  At ONE rank an
+// in-place all-reduce is the identity, so the plain one-rank run cannot see a reduction that
+// starts before the backward has written its part of the buffer (that part would be overwritten:
+// unscaled) or a norm / optimizer step that does not wait for the reduction (it would read the
+// buffer before the delayed scaling).  With the hook the update equals a step on `scale` x the
+// gradient only if both orderings hold: tests/dist_worker.py rccl_ordering.
+__global__ void comm_test_hook_kernel(float *buf, long long count, float scale, long long delay_ticks) {
+  const long long start = wall_clock64();  // constant 100 MHz counter: the spin ends on every wave
+  while (wall_clock64() - start < delay_ticks) __builtin_amdgcn_s_sleep(32);
+  for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < count;
+       i += static_cast<long long>(gridDim.x) * blockDim.x)
+    buf[i] *= scale;
+}
+
+int comm_test_hook(float *buf, long long count) {
+  static const char *spec = getenv("DX_COMM_TEST_HOOK");
+  if (spec == nullptr || *spec == 0) return DX_OK;
+  char *end = nullptr;
+  const double delay_us = strtod(spec, &end);
+  const double scale = (end && *end == ':') ? strtod(end + 1, nullptr) : 1.0;
+  const long long ticks = static_cast<long long>(delay_us < 0 ? 0 : (delay_us > 50000 ? 50000 : delay_us)) * 100;
+  hipLaunchKernelGGL(comm_test_hook_kernel, dim3(256), dim3(256), 0, g_comm.stream, buf, count,
+                     static_cast<float>(scale), ticks);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+#endif
+
+// a collective of the communicator's stream that the caller's stream waits for at once
+template <class Issue>
+int comm_in_stream(const char *who, hipStream_t stream, Issue issue) {
+  if (int rc = require_comm(who)) return rc;
+  DX_HIP(hipEventRecord(g_comm.ready, stream));
+  DX_HIP(hipStreamWaitEvent(g_comm.stream, g_comm.ready, 0));
+  if (int rc = issue(g_comm.stream)) return rc;
+  DX_HIP(hipEventRecord(g_comm.done, g_comm.stream));
+  DX_HIP(hipStreamWaitEvent(stream, g_comm.done, 0));  // in-order stream: covers pending reductions too
+  g_comm.pending = false;
+  return DX_OK;
+}
+
 }  // namespace
 
 // what the native update calls between the two halves of the backward (cnn_update.hip)
@@ -98,6 +149,9 @@ int comm_allreduce_async(float *buf, long long count, hipStream_t stream) {
   DX_HIP(hipEventRecord(g_comm.ready, stream));
   DX_HIP(hipStreamWaitEvent(g_comm.stream, g_comm.ready, 0));
   DX_NCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(count), ncclFloat32, ncclSum, g_comm.comm, g_comm.stream));
+#if DX_DIAG
+  if (int rc = comm_test_hook(buf, count)) return rc;
+#endif
   // ... and `stream` does NOT wait for it until dx_allreduce_wait
   DX_HIP(hipEventRecord(g_comm.done, g_comm.stream));
   g_comm.pending = true;
@@ -195,8 +249,11 @@ int dx_allreduce_wait(void *stream) {
 int dx_allreduce_sum_f64(double *buf, long long count, void *stream) {
   DX_TRACE("dx_allreduce_sum_f64");
   DX_REQUIRE(buf != nullptr && count >= 1, "dx_allreduce_sum_f64: bad arguments");
-  if (int rc = require_comm("dx_allreduce_sum_f64")) return rc;
-  DX_NCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(count), ncclFloat64, ncclSum, g_comm.comm, as_stream(stream)));
+  if (int rc = comm_in_stream("dx_allreduce_sum_f64", as_stream(stream), [&](hipStream_t cs) -> int {
+        DX_NCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(count), ncclFloat64, ncclSum, g_comm.comm, cs));
+        return DX_OK;
+      }))
+    return rc;
   ++g_comm.issued;
   g_comm.bytes += 8 * count;
   return DX_OK;
@@ -207,8 +264,10 @@ int dx_comm_broadcast_f32(float *buf, long long count, int root, void *stream) {
   DX_REQUIRE(buf != nullptr && count >= 1, "dx_comm_broadcast_f32: bad arguments");
   if (int rc = require_comm("dx_comm_broadcast_f32")) return rc;
   DX_REQUIRE(root >= 0 && root < g_comm.world, "dx_comm_broadcast_f32: root %d of %d ranks", root, g_comm.world);
-  DX_NCCL(g_rccl.Broadcast(buf, buf, static_cast<size_t>(count), ncclFloat32, root, g_comm.comm, as_stream(stream)));
-  return DX_OK;
+  return comm_in_stream("dx_comm_broadcast_f32", as_stream(stream), [&](hipStream_t cs) -> int {
+    DX_NCCL(g_rccl.Broadcast(buf, buf, static_cast<size_t>(count), ncclFloat32, root, g_comm.comm, cs));
+    return DX_OK;
+  });
 }
 
 }  // extern "C"

@@ -500,7 +500,9 @@ int dx_synth_atari_step(void *frames, long long frame_bytes_total, float *reward
  *                       mean gradient.
  *   dx_allreduce_wait   makes `stream` wait for every reduction issued so far (no-op without a
  *                       communicator: single-process callers need not branch).
- *   dx_allreduce_sum_f64 / dx_comm_broadcast_f32   in-stream (ordered like a kernel on `stream`):
+ *   dx_allreduce_sum_f64 / dx_comm_broadcast_f32   ordered like a kernel on `stream` (they run on
+ *                       the communicator's own stream -- one communicator is only ever driven
+ *                       from one stream -- between a wait for `stream` and a wait BY `stream`):
  *                       the per-minibatch advantage statistics {sum, sumsq, n} of a rollout
  *                       (derl/runners/trajectory_transforms.py:89-92 made global) and the
  *                       initial parameter broadcast.

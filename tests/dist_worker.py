@@ -342,9 +342,76 @@ def rccl_one_rank():
   print("rank 0: rccl_one_rank OK", flush=True)
 
 
+def rccl_ordering():
+  """Stream ordering of the two gradient all-reduces inside the native update, observable at ONE
+  rank.  Diag flavour of the library with DX_COMM_TEST_HOOK="<delay_us>:2": behind every gradient
+  all-reduce the communicator's stream idles for delay_us and then doubles the reduced piece
+  (csrc/comm.hip).  The update then equals a single-process step on 2 x the gradient ONLY IF each
+  reduction starts after the backward has written its piece (else the backward overwrites the
+  doubled values) and the norm / optimizer step waits for both (else it reads the buffer before
+  the delayed doubling) -- orderings that a plain one-rank run (identity all-reduce) cannot see."""
+  import derl_amd as derl
+  from derl_amd import _lib
+  from derl_amd.optim import Adam
+  assert _lib.LIB_PATH.endswith("libderl_amd_diag.so") and os.environ.get("DX_COMM_TEST_HOOK", "").endswith(":2")
+  assert torch.distributed.get_backend() == "nccl" and distributed.native_comm() and distributed.sharded()
+  derl.summary.stop_recording()
+  A, B = 4, 32
+  weights = gi.nature_cnn_weights(A, 3)
+  mb = gi.cnn_minibatch(B, A, 5)
+  logits, vals = oracle.nature_cnn_forward(weights, mb["observations"])
+  lp, _, _ = oracle.categorical_log_prob_entropy(logits, mb["actions"])
+  full = dict(observations=mb["observations"], actions=mb["actions"],
+              log_prob=(lp.numpy() + mb["logp_noise"]).astype(np.float32),
+              advantages=mb["advantages"], values=(vals.numpy() + mb["value_noise"]).astype(np.float32),
+              value_targets=(vals.numpy() + mb["target_noise"]).astype(np.float32))
+
+  class Runner:
+    step_count = 1000
+
+  def run(collectives, grad_scale):
+    saved = distributed.forced
+    distributed.forced = (lambda: True) if collectives else (lambda: False)
+    try:
+      model = derl.NatureCNNModel([A, 1], max_batch=32)
+      model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+      runner = Runner()
+      runner.policy = derl.ActorCriticPolicy(model)
+      lr = derl.LinearAnneal(2.5e-4, 1e6, name="lr")
+      optimizer = Adam(model, lr=lr.get_tensor(), eps=1e-5)
+      trainer = derl.Trainer(optimizer, anneals=[lr], max_grad_norm=0.5)
+      if not collectives:
+        trainer.native_epochs = False  # update by update from Python: the gradient can be scaled in between
+        plain = optimizer.reduce_and_norm
+
+        def scaled_then_norm():
+          model.engine.grads.mul_(grad_scale)
+          return plain()
+        optimizer.reduce_and_norm = scaled_then_norm
+      alg = derl.PPO(runner, trainer, cliprange=0.1, value_loss_coef=0.25, entropy_coef=0.01)
+      data = dict(full)
+      derl.NormalizeAdvantages()(data)
+      losses = [float(alg.step(data).item()) for _ in range(2)]
+      torch.cuda.synchronize()
+      return losses, model.engine.params.clone()
+    finally:
+      distributed.forced = saved
+
+  before = distributed.comm_info()[2]
+  losses_hook, params_hook = run(True, None)
+  assert distributed.comm_info()[2] - before == 5  # 1 statistics + 2 updates x 2 pieces, all through the library
+  losses_twice, params_twice = run(False, 2.0)
+  losses_once, params_once = run(False, 1.0)
+  assert not torch.equal(params_twice, params_once), "the doubled gradient changes nothing: vacuous check"
+  assert losses_hook == losses_twice, (losses_hook, losses_twice)
+  assert torch.equal(params_hook, params_twice), float((params_hook - params_twice).abs().max())
+  print("rank 0: rccl_ordering OK", flush=True)
+
+
 if __name__ == "__main__":
   mode = sys.argv[1]
   distributed.init_from_env(backend="nccl" if mode.startswith("rccl") else "gloo")
   {"cpu_math": cpu_math, "bootstrap_agreement": bootstrap_agreement, "gpu_step": gpu_step, "gpu_minibatch_stats": gpu_minibatch_stats,
-   "gpu_learns": gpu_learns, "rccl_one_rank": rccl_one_rank}[mode]()
+   "gpu_learns": gpu_learns, "rccl_one_rank": rccl_one_rank,
+   "rccl_ordering": rccl_ordering}[mode]()
   distributed.destroy()

@@ -63,6 +63,22 @@ def test_rccl_communicator_behind_the_c_abi_runs_the_data_path_at_world_size_1(o
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("overlap", ["-1", "1"])
+def test_gradient_all_reduces_are_ordered_against_the_backward_and_the_optimizer_step(overlap):
+  """What world size 1 cannot show with an identity all-reduce: the diag flavour's
+  DX_COMM_TEST_HOOK delays and doubles every reduced piece on the communicator's stream, so the
+  update is right only if the reductions run after the backward wrote their piece and before the
+  norm / Adam read it (dist_worker.rccl_ordering)."""
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", RANK="0", WORLD_SIZE="1",
+             LOCAL_RANK="0", DERL_AMD_FORCE_COLLECTIVES="1", OMP_NUM_THREADS="2", DX_BWD_OVERLAP=overlap,
+             DERL_AMD_LIBRARY="diag", DX_COMM_TEST_HOOK="3000:2")
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "rccl_ordering"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+  assert "rccl_ordering OK" in out.stdout
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_reports_ranks_seen_and_refuses_non_rccl_backend():
   """bench.py under torch.distributed.run: the JSON line carries what lets a reader check the
   multi-GPU run (ranks_seen from an all-reduce of ones, the backend, the all-reduce bytes per

@@ -49,6 +49,30 @@ def test_linear_anneal_closed_form_and_errors():
   assert derl.LinearAnneal(1.0, 10, name="lr").name == "lr" and derl.LinearAnneal(1.0, 10).name == "linear_anneal"
 
 
+def test_torch_sched_follows_a_torch_scheduler():
+  """derl/anneal.py:46-62: the tensor tracks scheduler.get_last_lr() (one element per parameter
+  group), the same tensor object throughout, step_to walks step by step and never backwards."""
+  import torch
+  import derl_amd as derl
+  from derl import TorchSched  # the drop-in import path
+  assert TorchSched is derl.TorchSched
+  w = [torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(3))]
+  opt = torch.optim.SGD([dict(params=[w[0]], lr=0.5), dict(params=[w[1]], lr=0.25)])
+  sched = derl.TorchSched(torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.5))
+  assert sched.name == "torch_sched" and sched.step_count == 0
+  tensor = sched.get_tensor()
+  nt.assert_array_equal(tensor.numpy(), np.float32([0.5, 0.25]))
+  opt.step()
+  value = sched.step()
+  assert sched.step_count == 1 and value is not tensor
+  sched.step_to(4)
+  assert sched.get_tensor() is tensor and sched.step_count == 4
+  nt.assert_array_equal(tensor.numpy(), np.float32([0.125, 0.0625]))
+  assert [g["lr"] for g in opt.param_groups] == [0.125, 0.0625]
+  with pytest.raises(ValueError):
+    sched.step_to(3)
+
+
 def test_factory_kwargs_accounting():
   import derl_amd as derl
   kwargs = derl.PPOFactory.get_kwargs()
