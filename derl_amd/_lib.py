@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "libderl_amd.so")
 # the in-kernel stamps and bisecting switches that are compiled out of the product library
 if os.environ.get("DERL_AMD_LIBRARY", "") == "diag":
   LIB_PATH = os.path.join(_PKG, "libderl_amd_diag.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_int, c_float, c_void_p, c_char_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p
 c_size_t, c_int64, c_uint64, c_double = ctypes.c_size_t, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
@@ -54,6 +54,7 @@ SIGNATURES = {
     "dx_mlp_backward": [P, c_int, P],
     "dx_mlp_ppo_epoch": [P, P, P],
     "dx_mlp_persist_plan": [P, c_int, c_longlong, P, P],
+    "dx_mlp_last_route": [],
     "dx_normal_act_f32": [P, P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
     "dx_normal_loss_f32": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
                            c_longlong, P, P, P, c_int, P, P],
@@ -183,7 +184,8 @@ class MlpEpoch(ctypes.Structure):
       ("max_grad_norm", c_double), ("lr", c_double), ("beta1", c_double), ("beta2", c_double),
       ("adam_eps", c_double), ("first_step", c_longlong), ("grad_norm_out", c_void_p),
       ("loss_out", c_void_p), ("grad_norm_stride", c_int), ("persistent", c_int),
-      ("workspace", c_void_p), ("workspace_bytes", c_longlong), ("stats_all", c_void_p)]
+      ("workspace", c_void_p), ("workspace_bytes", c_longlong), ("stats_all", c_void_p),
+      ("status_host", c_void_p)]
 
 
 class CnnEpoch(ctypes.Structure):

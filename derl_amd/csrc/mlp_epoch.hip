@@ -13,7 +13,12 @@ namespace dx {
 long long mlp_persist_workspace_bytes(int G);
 int mlp_persist_workgroups(const dx_mlp_ctx *c, int mbsize, long long samples);
 int launch_mlp_persist_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, int G, hipStream_t stream);
+int mlp_persist_check_status(const dx_mlp_epoch *e);
+int mlp_last_route();
+void mlp_note_route(int route);
 }  // namespace dx
+
+extern "C" int dx_mlp_last_route(void) { return dx::mlp_last_route(); }
 
 extern "C" int dx_mlp_persist_plan(const dx_mlp_ctx *c, int mbsize, long long samples, int *workgroups,
                                    long long *workspace_bytes) {
@@ -40,11 +45,15 @@ extern "C" int dx_mlp_ppo_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, void
   DX_REQUIRE(e->mode == 1 || (e->old_log_prob && e->old_values), "dx_mlp_ppo_epoch: PPO needs the rollout's log_prob / values");
   DX_REQUIRE(c->has_logstd ? e->action_is_f32 == 1 : e->action_is_f32 == 0,
              "dx_mlp_ppo_epoch: Gaussian policies take float32 actions, categorical ones int64");
+  // a persistent epoch that gave up earlier on this workspace: fail here, whatever route this call
+  // would take (the caller's parameters were left untouched by that epoch)
+  if (int rc = dx::mlp_persist_check_status(e)) return rc;
   if (e->persistent && e->global_batch <= 0) {  // one persistent launch where the shape is covered
     const int G = dx::mlp_persist_workgroups(c, e->mbsize, e->samples);
     if (G > 0) return dx::launch_mlp_persist_epoch(c, e, G, dx::as_stream(stream));
   }
   const int P = c->policy_out, D = c->obs_dim;
+  dx::mlp_note_route(0);
   int k = 0;
   for (long long start = 0; start < e->samples; start += e->mbsize, ++k) {
     const int B = static_cast<int>(e->samples - start < e->mbsize ? e->samples - start : e->mbsize);

@@ -27,8 +27,15 @@
 // reduced gradient, partials) is stored write-through (sc1) and read with sc1 loads; a workgroup
 // arrives at a barrier with ONE agent-scope atomic add after all its waves have drained their
 // stores, and polls the counter with sc1 loads (MI355X_MICROARCH.md, inter-workgroup visibility:
-// the "one lane of each storing workgroup adds to one counter" row).  Every spin is bounded: on a
-// timeout the epoch's loss outputs are NaN and the timeout word is set.
+// the "one lane of each storing workgroup adds to one counter" row).  Every spin is bounded, and a
+// give-up is LOUD and harmless: the workgroup that gives up writes which barrier it was (1 + 2 x
+// minibatch + barrier) into the timeout word; the epoch's write-back of parameters, moments and
+// gradient is skipped (the caller's buffers stay untouched), its losses are NaN, and the code goes
+// into a STICKY word of the workspace that makes every later launch on that workspace exit at once
+// and that the host mirrors into the caller's pinned status word -- the next dx_mlp_ppo_epoch on
+// it returns DX_ETIMEOUT naming the barrier (csrc/mlp_epoch.hip).  The grid is checked against the
+// occupancy query when it is planned (one workgroup per CU must fit beside nothing else of this
+// process: the launch is declined while a communicator exists, i.e. in multi-process runs).
 //
 // Results equal dx_mlp_ppo_epoch's to float32 rounding (other tile / slab partition of the sums),
 // not bit for bit; the tests compare both against each other and against the CPU oracle.
@@ -77,7 +84,8 @@ struct PersistArgs {
   float *slabs, *gral;    // [G][kTotalA] partial gradients, [kTotalA] reduced gradient
   float *moments;         // [G][2][kTotalA] every workgroup's own exp_avg / exp_avg_sq (aligned layout)
   double *lossp, *sumsqp;  // [G][40], [G]
-  unsigned *counter, *timeout;
+  unsigned *counter, *timeout, *sticky;
+  unsigned spin_limit;
   int G;
   unsigned long long *stamps;  // optional (DX_MLP_PERSIST_STAMPS=1): [G][5] 100 MHz ticks spent in A, barrier, B, barrier, C
 };
@@ -109,7 +117,8 @@ __device__ __forceinline__ double ld_d(const double *p) {
 }
 
 // Grid barrier: every wave has drained its stores, one lane arrives, polls until `target` arrivals.
-__device__ __forceinline__ void grid_barrier(const PersistArgs &a, unsigned target, int *dead) {
+// `code` = 1 + 2 x minibatch + (0 | 1): what a give-up leaves in the timeout word.
+__device__ __forceinline__ void grid_barrier(const PersistArgs &a, unsigned target, int *dead, unsigned code) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -118,9 +127,12 @@ __device__ __forceinline__ void grid_barrier(const PersistArgs &a, unsigned targ
       unsigned spins = 0;
       while (__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(2);
-        if ((++spins & 1023u) == 0 &&
-            (spins > kSpinLimit || __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++spins;
+        if (spins > a.spin_limit ||
+            ((spins & 1023u) == 0 && __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          unsigned expected = 0;  // the first give-up names the barrier
+          __hip_atomic_compare_exchange_strong(a.timeout, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
           *dead = 1;  // give up for good: later barriers only arrive
           break;
         }
@@ -128,6 +140,12 @@ __device__ __forceinline__ void grid_barrier(const PersistArgs &a, unsigned targ
     }
   }
   __syncthreads();
+}
+// after a barrier: did any workgroup give up so far?  (a give-up's store is complete before that
+// workgroup's NEXT arrival -- s_waitcnt vmcnt(0) opens every barrier -- so whoever passed a later
+// barrier sees it; a give-up at the very last barrier is the workgroup's own `dead`)
+__device__ __forceinline__ bool gave_up(const PersistArgs &a, const int *dead) {
+  return *dead != 0 || __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 // aligned vec4 index -> (LDS index of its first element, validity bits of its four elements,
@@ -218,6 +236,9 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
       __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, static_cast<int>(static_cast<long long>(G) * kTotalA * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_gral = __builtin_amdgcn_make_buffer_rsrc(a.gral, 0, kTotalA * 4, 0x00020000);
 
+  // a workspace poisoned by an earlier give-up: nothing runs on it again (uniform over the grid: the
+  // word is only ever written at the END of a launch)
+  if (__hip_atomic_load(a.sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   // ---- epoch start: the model into LDS, this thread's share of the Adam moments into registers ----
   for (int i = t; i < 2 * kNetLds + 32 + kR * kLd0 + 6 * kR * kLd1 + 3 * kR * kLd0; i += kT) Wl[i] = 0.f;
   if (t == 0) {
@@ -517,7 +538,7 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
       }
     }
     DX_STAMP(0)
-    grid_barrier(a, (++arrivals) * static_cast<unsigned>(G), dead);
+    grid_barrier(a, (++arrivals) * static_cast<unsigned>(G), dead, 1u + 2u * k);
     DX_STAMP(1)
 
     // ================= phase B: slice `wg` of the gradient, summed over all slabs =================
@@ -604,7 +625,7 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
       }
     }
     DX_STAMP(2)
-    grid_barrier(a, (++arrivals) * static_cast<unsigned>(G), dead);
+    grid_barrier(a, (++arrivals) * static_cast<unsigned>(G), dead, 2u + 2u * k);
     DX_STAMP(3)
 
     // ================= phase C: clip + Adam on this workgroup's own copy of the model =================
@@ -622,11 +643,13 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
             c = c < 1.f ? c : 1.f;
           }
           coef_s[0] = c;
+          // the epoch's results go back to the caller only if no barrier of the epoch gave up
+          coef_s[1] = (k == a.nmb - 1 && wg == 0 && !gave_up(a, dead)) ? 1.f : 0.f;
         }
       }
       __syncthreads();
       const float coef = coef_s[0], step_size = sched[k], inv_bc2 = 1.0f / sched[kMaxMb + k];
-      const bool last = k == a.nmb - 1;
+      const bool write_back = coef_s[1] != 0.f;
       constexpr int kBatch = 3;  // vec4 per lane per round: 9 loads in flight
 #pragma unroll 1
       for (int v0 = t; v0 < kVecA; v0 += kBatch * kT) {
@@ -655,7 +678,7 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
                 const float den = __builtin_amdgcn_sqrtf(v4[u][q]) * inv_bc2 + a.eps;
                 const float pnew = Wl[w.lds + q] - step_size * (m4[u][q] * __builtin_amdgcn_rcpf(den));
                 Wl[w.lds + q] = pnew;
-                if (last && wg == 0) {  // epoch end: one workgroup writes the model, the moments and the clipped gradient back
+                if (write_back) {  // epoch end: one workgroup writes the model, the moments and the clipped gradient back
                   a.params[w.canon + q] = pnew;
                   a.exp_avg[w.canon + q] = m4[u][q];
                   a.exp_avg_sq[w.canon + q] = v4[u][q];
@@ -674,7 +697,12 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
 #undef DX_STAMP
   if (a.stamps && t == 0)
     for (int i = 0; i < 5; ++i) a.stamps[wg * 5 + i] = tk[i];
-  if (*dead && wg == G - 1 && t < 8 * a.nmb) a.loss_out[t] = __builtin_nanf("");  // a barrier gave up
+  if (gave_up(a, dead)) {  // a barrier gave up: NaN losses, and the workspace is poisoned for good
+    if (wg == G - 1 && t < 8 * a.nmb) a.loss_out[t] = __builtin_nanf("");
+    if (t == 0)
+      __hip_atomic_store(a.sticky, __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | 0x80000000u,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 size_t persist_lds_bytes() {
@@ -691,16 +719,55 @@ long long mlp_persist_workspace_bytes(int G) {
 
 // number of workgroups for minibatches of `mbsize` rows; 0 = not covered (the caller keeps the
 // launch-per-stage epoch): needs the Gaussian head, obs_pad 32, >= 16 row tiles per minibatch
+// The grid barrier needs every workgroup resident: the grid is at most one workgroup per CU AND at
+// most what the occupancy query grants this kernel with its LDS, and the launch is declined while a
+// communicator exists (a multi-process run: another rank's kernels may hold CUs of a shared GPU).
+// Kernels of OTHER streams of this process delay a workgroup's start but finish by themselves, so
+// they cannot starve the barrier; what is left is bounded by the spin limit and fails loudly.
+bool comm_active();  // comm.hip
+
+static int configure_persist_kernel() {
+  static int configured_device = -1;  // per device: the attribute belongs to the device's code object
+  int dev = 0;
+  DX_HIP(hipGetDevice(&dev));
+  if (configured_device != dev) {
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(persist_lds_bytes())));
+    configured_device = dev;
+  }
+  return DX_OK;
+}
+
 int mlp_persist_workgroups(const dx_mlp_ctx *c, int mbsize, long long samples) {
   if (!c->has_logstd || c->obs_pad != kDP) return 0;
   const int tiles = (mbsize + kR - 1) / kR;
   if (tiles < 16 || (samples + mbsize - 1) / mbsize > kMaxMb) return 0;
-  int dev = 0, cus = 0;
+  if (comm_active()) return 0;
+  int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 0;
+  if (configure_persist_kernel() != DX_OK) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(mlp_persist_kernel), kT,
+                                                   persist_lds_bytes()) != hipSuccess || per_cu < 1)
     return 0;
   int G = tiles < cus ? tiles : cus;  // one workgroup per CU at most: all of them must be resident
   if (G > 256) G = 256;
   return G;
+}
+
+static int g_last_route = -1;
+int mlp_last_route() { return g_last_route; }
+void mlp_note_route(int route) { g_last_route = route; }
+
+// 0 while the caller's status word is clean; DX_ETIMEOUT with the barrier's name otherwise
+int mlp_persist_check_status(const dx_mlp_epoch *e) {
+  if (e->status_host == nullptr) return DX_OK;
+  const unsigned code = *static_cast<const volatile unsigned *>(e->status_host) & 0x7fffffffu;
+  if (code == 0) return DX_OK;
+  return fail(DX_ETIMEOUT, "dx_mlp_ppo_epoch: an earlier persistent epoch on this workspace gave up at grid barrier %u of "
+              "minibatch %u (not every workgroup arrived within the spin limit); that epoch's parameters, moments and "
+              "gradient were NOT written back, its losses are NaN, and the workspace refuses further epochs",
+              (code - 1) % 2, (code - 1) / 2);
 }
 
 int launch_mlp_persist_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, int G, hipStream_t stream) {
@@ -734,6 +801,13 @@ int launch_mlp_persist_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, int G, 
   char *ws = static_cast<char *>(e->workspace);
   a.counter = reinterpret_cast<unsigned *>(ws);
   a.timeout = a.counter + 4;
+  a.sticky = a.counter + 8;  // survives the per-launch reset below
+  a.spin_limit = kSpinLimit;
+#if DX_DIAG
+  // (diag flavour: DX_MLP_PERSIST_SPIN_LIMIT=0 makes every workgroup that does not arrive last give
+  // up at once -- how tests/test_native_epoch_gpu.py forces the failure path)
+  if (const char *v = getenv("DX_MLP_PERSIST_SPIN_LIMIT")) a.spin_limit = static_cast<unsigned>(strtoul(v, nullptr, 10));
+#endif
   a.gral = reinterpret_cast<float *>(ws + 64);
   a.slabs = a.gral + kTotalA;
   a.moments = a.slabs + static_cast<long long>(G) * kTotalA;
@@ -751,16 +825,14 @@ int launch_mlp_persist_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, int G, 
     if (int rc = dx_adv_stats_segments_f32(e->advantages, nullptr, e->samples, e->mbsize, e->stats_all, stream)) return rc;
     a.stats = e->stats_all;
   }
-  DX_HIP(hipMemsetAsync(ws, 0, 64, stream));  // barrier counter and timeout word
-  static bool configured = false;
+  DX_HIP(hipMemsetAsync(ws, 0, 32, stream));  // barrier counter and timeout word (NOT the sticky word)
   const size_t lds = persist_lds_bytes();
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(lds)));
-    configured = true;
-  }
+  if (int rc = configure_persist_kernel()) return rc;
   hipLaunchKernelGGL(mlp_persist_kernel, dim3(G), dim3(kT), lds, stream, a);
   DX_LAUNCH_CHECK();
+  mlp_note_route(1);
+  if (e->status_host)  // the sticky word follows the launch into the caller's pinned status word
+    DX_HIP(hipMemcpyAsync(e->status_host, a.sticky, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
   if (want_stamps) {  // measurement aid (synchronous): where an epoch's time goes, per update
     DX_HIP(hipStreamSynchronize(stream));
     std::vector<unsigned long long> h(5 * G);

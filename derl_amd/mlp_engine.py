@@ -91,8 +91,22 @@ class MlpEngine:
       _lib.call("dx_mlp_pack", ctypes.byref(self.ctx), _lib.stream_ptr(self.device))
       self._packed_version = version
 
+  def check_health(self):
+    """Raises NativeError once a persistent epoch of this engine has given up at a grid barrier
+    (csrc/mlp_persist.hip): the status word is pinned host memory the library fills behind every
+    persistent launch -- reading it costs nothing and needs no synchronisation.  That epoch left
+    parameters, moments and gradient untouched; nothing this engine computed since is trustworthy."""
+    status = getattr(self, "_persist_status_np", None)
+    if status is not None and status[0] != 0:
+      code = (int(status[0]) & 0x7fffffff) - 1
+      raise _lib.NativeError(
+          f"persistent MLP epoch gave up at grid barrier {code % 2} of minibatch {code // 2}: not every "
+          "workgroup arrived within the spin limit; the epoch's parameters were NOT stepped and its losses "
+          "are NaN (set MlpEngine.persistent_epochs = False to train on the launch-per-stage epoch)")
+
   def forward(self, obs):
     """obs (B, obs_dim) float32 on the device -> padded head (B, 32)."""
+    self.check_health()
     if not obs.is_cuda or obs.dtype != torch.float32 or not obs.is_contiguous():
       raise ValueError("observations must be a contiguous float32 GPU tensor")
     if obs.ndim != 2 or obs.shape[1] != self.obs_dim:
@@ -115,6 +129,7 @@ class MlpEngine:
     """Enqueues every minibatch update of ``context`` (runners.onpolicy.EpochContext): advantage
     normalisation, forward, fused loss, backward, gradient norm, clip + Adam per minibatch, all
     from one C call.  Returns the number of updates."""
+    self.check_health()
     arrays = context.shuffled
     samples, mbsize = context.sample_size, context.mbsize
     f32 = torch.float32
@@ -183,11 +198,16 @@ class MlpEngine:
           self._persist_ws = torch.zeros(nbytes.value, dtype=torch.uint8, device=dev)
         if getattr(self, "_persist_stats", None) is None or self._persist_stats.numel() < 3 * updates:
           self._persist_stats = torch.empty(3 * updates, dtype=torch.float64, device=dev)
+        if getattr(self, "_persist_status", None) is None:  # one pinned word, see check_health
+          self._persist_status = torch.zeros(1, dtype=torch.int32).pin_memory()
+          self._persist_status_np = self._persist_status.numpy()
         e.persistent = 1
         e.workspace, e.workspace_bytes = self._persist_ws.data_ptr(), int(self._persist_ws.numel())
         e.stats_all = self._persist_stats.data_ptr()
+        e.status_host = self._persist_status.data_ptr()
     keep = (obs, actions, old_lp, old_v, adv, vt)  # alive until the call has been enqueued
     _lib.call("dx_mlp_ppo_epoch", ctypes.byref(self.ctx), ctypes.byref(e), _lib.stream_ptr(dev))
+    self.last_epoch_route = "persistent" if _lib.load().dx_mlp_last_route() == 1 else "per-stage"
     del keep
     if record_norms:
       optimizer.grad_norm.copy_(context.grad_norms[-1:])

@@ -38,8 +38,9 @@ extern "C" {
 #define DX_EHIP (-2)     /* a HIP runtime call failed                               */
 #define DX_ENOSUP (-3)   /* configuration not supported by the compiled kernels     */
 #define DX_EWS (-4)      /* workspace too small                                     */
+#define DX_ETIMEOUT (-5) /* a persistent kernel's grid barrier gave up (dx_mlp_ppo_epoch) */
 
-#define DX_ABI_VERSION 2
+#define DX_ABI_VERSION 3
 
 int dx_abi_version(void);
 const char *dx_last_error(void);
@@ -445,15 +446,26 @@ typedef struct dx_mlp_epoch {
   void *workspace;             /* persistent epoch: workspace_bytes from dx_mlp_persist_plan */
   long long workspace_bytes;
   double *stats_all;           /* persistent epoch with normalize: (minibatches, 3) scratch */
+  unsigned *status_host;       /* persistent epoch: ONE pinned host word, zero before the first call,
+                                  or NULL.  A persistent launch whose grid barrier gives up leaves
+                                  the caller's parameters / moments / gradient untouched, NaN in
+                                  loss_out, poisons the workspace (later launches on it exit at
+                                  once) and, through an asynchronous copy behind the launch, a
+                                  non-zero code here; every dx_mlp_ppo_epoch given a non-zero
+                                  word returns DX_ETIMEOUT naming the barrier                  */
 } dx_mlp_epoch;
 int dx_mlp_ppo_epoch(const dx_mlp_ctx *ctx, const dx_mlp_epoch *epoch, void *stream);
+/* The route the last dx_mlp_ppo_epoch of this process took: 1 = one persistent launch, 0 = the
+ * per-stage launches, -1 = none yet (tests pin BASELINE config 3 to the persistent route). */
+int dx_mlp_last_route(void);
 /* The persistent form of the same epoch (csrc/mlp_persist.hip): every workgroup keeps the whole
  * model in LDS and its share of the Adam moments in registers; per minibatch forward / loss /
  * backward of its row tiles -> slab, grid barrier, fixed-order slab reduction + |g|^2 partials, grid
  * barrier, clip + Adam on every workgroup's own copy.  Two grid barriers per update instead of ~9
  * dependent launches.  Results equal the launch-per-stage epoch to float32 rounding (other partition
  * of the sums), not bit for bit.  Covered: Gaussian policy, obs_dim <= 32, >= 512-row minibatches,
- * <= 64 minibatches, single process.  *workgroups = 0 when the shape is not covered (then
+ * <= 64 minibatches, single process (never while a communicator exists), and a grid of one
+ * workgroup per CU that the occupancy query grants.  *workgroups = 0 when the shape is not covered (then
  * `persistent` is ignored and the launch-per-stage epoch runs). */
 int dx_mlp_persist_plan(const dx_mlp_ctx *ctx, int mbsize, long long samples, int *workgroups_host,
                         long long *workspace_bytes_host);

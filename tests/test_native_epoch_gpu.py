@@ -302,6 +302,8 @@ def test_persistent_epoch_matches_launch_per_stage_epoch_and_oracle():
 
   fast, slow = go(True), go(False)
   assert fast["used"] and not slow["used"], "the persistent epoch was not taken"
+  assert fast["alg"].model.engine.last_epoch_route == "persistent"
+  assert slow["alg"].model.engine.last_epoch_route == "per-stage"
   assert np.all(np.isfinite(fast["losses"])), "a grid barrier timed out"
   nt.assert_allclose(fast["losses"], slow["losses"], rtol=1e-5, atol=1e-6)
   nt.assert_allclose(fast["params"], slow["params"], rtol=0, atol=1e-6)
@@ -326,3 +328,65 @@ def test_persistent_epoch_matches_launch_per_stage_epoch_and_oracle():
   got = alg.model.engine.named_views(fast["after_first"])
   for k in names:
     nt.assert_allclose(got[k].cpu().numpy(), params[k], rtol=0, atol=5e-6, err_msg=k)
+
+
+_GIVE_UP_CHILD = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {tests!r})
+import derl_amd as derl
+from derl_amd import _lib
+from test_native_epoch_gpu import make_alg
+assert _lib.LIB_PATH.endswith("libderl_amd_diag.so")
+alg, calls = make_alg("gaussian", True, 65, 40, 2, 3)
+engine, opt = alg.model.engine, alg.trainer.optimizer
+it = alg.runner.run()
+data = next(it)
+derl.summary.stop_recording()
+before = engine.params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+loss = alg.step(data)          # enqueues the first epoch as one persistent launch
+torch.cuda.synchronize()
+assert engine.last_epoch_route == "persistent"
+assert not np.isfinite(loss.item()), loss.item()                         # NaN losses ...
+assert all(torch.equal(a, b) for a, b in zip(before, (engine.params, opt.exp_avg, opt.exp_avg_sq))), \
+    "parameters or moments were stepped by an epoch whose barrier gave up"  # ... and nothing stepped
+assert engine._persist_status_np[0] != 0
+for _ in range(3):             # the rest of the epoch only hands out the (NaN) results
+  alg.step(next(it))
+try:
+  alg.step(next(it))           # the next epoch: the library refuses, naming the barrier
+except _lib.NativeError as error:
+  assert "grid barrier" in str(error) and "NOT" in str(error), str(error)
+  print("GAVE UP LOUDLY:", error)
+else:
+  raise AssertionError("the epoch after a give-up was accepted")
+engine._persist_status_np = None   # past the engine's own check: the C-ABI itself refuses too
+try:
+  alg.trainer.optimizer.native_epoch(alg.loss_fn, data["state"]["epoch"][0])
+except _lib.NativeError as error:
+  assert "dx_mlp_ppo_epoch" in str(error) and "grid barrier" in str(error), str(error)
+  print("C-ABI REFUSED:", error)
+else:
+  raise AssertionError("dx_mlp_ppo_epoch accepted a poisoned status word")
+assert torch.equal(before[0], engine.params)
+"""
+
+
+def test_persistent_epoch_gives_up_loudly_and_steps_nothing():
+  """The failure path of the persistent epoch's grid barrier, forced: the diag flavour of the
+  library with DX_MLP_PERSIST_SPIN_LIMIT=0 makes every workgroup that is not the last to arrive
+  give up on its first poll.  The epoch must leave parameters and Adam moments untouched, return
+  NaN losses, and the next epoch must raise NativeError naming the barrier -- from the engine's
+  host-side check and from dx_mlp_ppo_epoch itself (DX_ETIMEOUT)."""
+  import os
+  import subprocess
+  import sys
+  tests = os.path.dirname(os.path.abspath(__file__))
+  root = os.path.dirname(tests)
+  env = dict(os.environ, DERL_AMD_LIBRARY="diag", DX_MLP_PERSIST_SPIN_LIMIT="0")
+  out = subprocess.run([sys.executable, "-c", _GIVE_UP_CHILD.format(root=root, tests=tests)], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+  assert "GAVE UP LOUDLY" in out.stdout and "C-ABI REFUSED" in out.stdout, out.stdout[-2000:]

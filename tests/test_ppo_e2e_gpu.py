@@ -373,6 +373,10 @@ def test_ppo_factory_config3_first_epoch_matches_oracle():
       params[k], state[k]["m"], state[k]["v"] = oracle.adam_step(
           params[k], g, state[k]["m"], state[k]["v"], i + 1, lr, eps=1e-5)
   assert alg.trainer.step_count == nmb
+  # the route the bench runs: ONE persistent launch for the epoch (128 workgroups x 32 minibatches)
+  from derl_amd import _lib
+  assert alg.model.engine.last_epoch_route == "persistent" and _lib.load().dx_mlp_last_route() == 1, \
+      "config 3 left the persistent epoch (csrc/mlp_persist.hip)"
   after = alg.model.state_dict()
   for k in names:  # 32 Adam steps of <= lr each: differences stay at rounding level
     nt.assert_allclose(after[k].cpu().numpy(), params[k], rtol=0, atol=2e-5, err_msg=k)
