@@ -120,13 +120,26 @@ class Trainer:
       return None
     return engine
 
+  _EPOCH_ORDER = (
+      "Trainer.step: the native epoch (Trainer.native_epochs) enqueued EVERY update of this epoch "
+      "when its first minibatch was stepped, so the reference's one-update-per-step semantics "
+      "(derl/alg/common.py:66-78) only hold if the epoch's minibatches are stepped once each, in "
+      "order, with nothing reading the policy in between: {what}.  Set "
+      "trainer.native_epochs = False to train update by update.")
+
   def _epoch_fast_path(self, alg, data):
     """(context, k) when EVERY update of this minibatch's epoch can be (or already was) enqueued
     from one native call: the minibatch is the untouched slice of the epoch's arrays (frames: the
     epoch's index into the untouched rollout buffer) and its advantages are either the raw slice
     or what NormalizeAdvantages made of it (the transform records its epsilon in the context: the
-    native epoch normalises with THAT epsilon, or not at all).  A caller that abandons an epoch
-    halfway still gets all of its updates applied -- set ``native_epochs = False`` then."""
+    native epoch normalises with THAT epsilon, or not at all).
+
+    What the native epoch cannot give is the reference's view of the parameters BETWEEN the
+    minibatch steps of an epoch (all updates are applied at minibatch 0).  That difference is never
+    silent: stepping an epoch's minibatches out of order or twice, handing a later minibatch of a
+    consumed epoch in edited form, starting another epoch before this one's minibatches were all
+    stepped, and ``policy.act`` / ``state_dict`` between two minibatch steps of a consumed epoch
+    (``engine.open_epoch``) all raise RuntimeError naming ``native_epochs = False``."""
     engine = self._native_ready(alg)
     if engine is None:
       return None
@@ -135,6 +148,17 @@ class Trainer:
     if entry is None:
       return None
     context, k = entry
+    return self._epoch_fast_path_checked(alg, data, context, k, entry)
+
+  def _epoch_fast_path_checked(self, alg, data, context, k, entry):
+    result = self._epoch_compare(alg, data, context, k, entry)
+    if result is None and context.consumed:
+      raise RuntimeError(self._EPOCH_ORDER.format(
+          what=f"minibatch {k} of an epoch whose updates are already applied arrived edited (a transform "
+               "replaced one of its arrays), so stepping it would apply an update twice"))
+    return result
+
+  def _epoch_compare(self, alg, data, context, k, entry):
     if (context.consumed and getattr(data, "epoch", None) is entry and not data.touched
         and context.verified is data.__class__):
       # a LazyMinibatch straight from the iterator whose only outside contact was NormalizeAdvantages'
@@ -198,6 +222,17 @@ class Trainer:
     return EpochContext(arrays, batch, batch, order_dev=index, lazy={"observations": observations})
 
   def _step_epoch(self, alg, context, k):
+    engine = alg.model.engine
+    open_context = getattr(engine, "open_epoch", None)
+    if open_context is not None and open_context is not context:
+      engine.open_epoch = None
+      raise RuntimeError(self._EPOCH_ORDER.format(
+          what=f"a new epoch was stepped while minibatches {open_context.next_k}.."
+               f"{open_context.num_minibatches - 1} of the previous one were never stepped (their updates "
+               "are applied nevertheless)"))
+    if k != context.next_k:
+      raise RuntimeError(self._EPOCH_ORDER.format(
+          what=f"minibatch {k} was stepped where minibatch {context.next_k} of the epoch is due"))
     recording = summary.should_record()
     for anneal in self.anneals:
       if recording:
@@ -218,6 +253,10 @@ class Trainer:
                            global_step=self.step_count)
     alg.loss_fn.call_count += 1
     self.step_count += 1
+    context.next_k = k + 1
+    # between now and the epoch's last minibatch the parameters are AHEAD of what the reference
+    # would show: the policy / model refuse to be read meanwhile (see _epoch_fast_path)
+    engine.open_epoch = context if context.next_k < context.num_minibatches else None
     return context.loss_scalars[k]
 
   def step(self, alg, data):

@@ -75,6 +75,11 @@ class _MlpActorCritic(nn.Module):
     self.engine.watch(list(self.parameters()))
     self.engine.mark_dirty()
 
+  def state_dict(self, *args, **kwargs):
+    from .policies import refuse_mid_epoch  # pylint: disable=import-outside-toplevel
+    refuse_mid_epoch(self, "model.state_dict")
+    return super().state_dict(*args, **kwargs)
+
   def load_state_dict(self, state_dict, strict=True):
     result = super().load_state_dict(state_dict, strict)
     self.engine.mark_dirty()

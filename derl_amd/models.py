@@ -122,6 +122,11 @@ class NatureCNNModel(nn.Module):
     """Grows the activation workspaces (parameters and optimizer state are kept)."""
     self.engine.reserve(max_batch)
 
+  def state_dict(self, *args, **kwargs):
+    from .policies import refuse_mid_epoch  # pylint: disable=import-outside-toplevel
+    refuse_mid_epoch(self, "model.state_dict")
+    return super().state_dict(*args, **kwargs)
+
   def load_state_dict(self, state_dict, strict=True):
     result = super().load_state_dict(state_dict, strict)
     self.engine.mark_dirty()

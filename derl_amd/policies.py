@@ -23,6 +23,19 @@ class Policy(ABC):
     """Returns `dict` of all the outputs of the policy."""
 
 
+def refuse_mid_epoch(model, what):
+  """Between two minibatch steps of an epoch whose updates were all enqueued by one native call
+  (Trainer.native_epochs) the parameters are AHEAD of what derl's Trainer.step would show
+  (derl/alg/common.py:66-78 applies one update per step): reading the policy then raises instead
+  of silently answering from post-epoch parameters."""
+  context = getattr(getattr(model, "engine", None), "open_epoch", None)
+  if context is not None:
+    raise RuntimeError(
+        f"{what} between minibatch steps {context.next_k - 1} and {context.next_k} of an epoch whose "
+        f"{context.num_minibatches} updates are already applied (Trainer.native_epochs: one native call per "
+        "epoch).  Set trainer.native_epochs = False to evaluate the policy between minibatch updates.")
+
+
 class DeviceCategorical:
   """What ``act(training=True)`` returns under "distribution" for a categorical policy:
   holds the padded head output the fused loss kernel consumes.  ``log_prob`` / ``entropy``
@@ -67,16 +80,19 @@ class ActorCriticPolicy(Policy):
     _ = update_state
     if state is not None:
       raise NotImplementedError()
+    refuse_mid_epoch(self.model, "policy.act")
     return self.model.policy_act(self, inputs, training)
 
   def act_into(self, observations, actions_out, log_prob_out, values_out):
     """Rollout act for the device-resident runner: writes straight into the rollout
     buffers' slots for this step (no per-step allocations or copies)."""
+    refuse_mid_epoch(self.model, "policy.act_into")
     self.model.policy_act_into(self, observations, actions_out, log_prob_out, values_out)
 
   def rollout_into(self, env, buffers, horizon):
     """Whole-rollout fast path when model and env support enqueuing all steps from one native
     call (same launches as the per-step loop).  Returns False if unsupported."""
+    refuse_mid_epoch(self.model, "policy.rollout_into")
     fused = getattr(self.model, "policy_rollout_into", None)
     return bool(fused and fused(self, env, buffers, horizon))
 

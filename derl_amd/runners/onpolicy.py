@@ -32,6 +32,7 @@ class EpochContext:
     # order_dev[k * mbsize : (k + 1) * mbsize] of lazy[key] (GatheredRows); order_dev None = identity
     self.order_dev, self.lazy = order_dev, lazy or {}
     self.consumed = False
+    self.next_k = 0         # the minibatch Trainer.step hands out next (the epoch is stepped in order, once)
     self.losses = None      # (minibatches, 8) loss terms, filled by the native epoch
     self.grad_norms = None  # (minibatches,) pre-clip gradient norms when summaries are recorded
     self.stats_ready = None  # (minibatches, 3) global advantage statistics of a sharded run

@@ -199,6 +199,73 @@ def test_native_epoch_declines_when_a_transform_edited_the_minibatch():
     assert alg.trainer.optimizer.step_count == 4
 
 
+@pytest.mark.parametrize("kind", ["gaussian", "cnn"])
+def test_native_epoch_never_silently_differs_from_one_update_per_step(kind):
+  """derl's Trainer.step applies exactly one update (alg/common.py:66-78); the native epoch applies
+  all of an epoch's at minibatch 0.  Every way a caller could OBSERVE that difference raises
+  RuntimeError naming ``native_epochs = False`` instead of answering from post-epoch parameters:
+  reading the policy / the model between two minibatch steps, stepping a minibatch twice or out of
+  order, handing a later minibatch of the consumed epoch in edited form (it would be applied a
+  second time), and starting the next epoch with minibatches of this one left over.  A run that
+  steps every minibatch once, in order, is untouched (and may read the policy between EPOCHS)."""
+  import derl_amd as derl
+  nenvs, horizon = (32, 16) if kind == "gaussian" else (8, 16)
+
+  def fresh():
+    alg, calls = make_alg(kind, True, nenvs, horizon, 2, 4)
+    it = alg.runner.run()
+    first = next(it)
+    derl.summary.stop_recording()
+    alg.step(first)
+    assert calls == [4] and alg.model.engine.open_epoch is not None
+    return alg, it, first
+
+  # (1) reading the policy or the model mid-epoch
+  alg, it, first = fresh()
+  probe = alg.runner.unwrapped._buffers["obs"][0] if hasattr(alg.runner.unwrapped, "_buffers") else None
+  for read in (lambda: alg.model.state_dict(), lambda: alg.loss(first),
+               lambda: alg.runner.policy.act(probe)):
+    with pytest.raises(RuntimeError, match="native_epochs = False"):
+      read()
+  for _ in range(3):  # ... and the epoch can still be finished, after which reading is fine again
+    alg.step(next(it))
+  assert alg.model.engine.open_epoch is None
+  alg.model.state_dict()
+  alg.runner.policy.act(probe)
+  assert alg.trainer.step_count == 4 == alg.trainer.optimizer.step_count
+  # (2) the same minibatch twice / a minibatch skipped
+  alg, it, first = fresh()
+  with pytest.raises(RuntimeError, match="minibatch 0 was stepped where minibatch 1"):
+    alg.step(first)
+  alg, it, first = fresh()
+  next(it)
+  with pytest.raises(RuntimeError, match="minibatch 2 was stepped where minibatch 1"):
+    alg.step(next(it))
+  # (3) a later minibatch of the consumed epoch arrives edited: no second application of its update
+  alg, it, first = fresh()
+  second = next(it)
+  second["log_prob"] = second["log_prob"] * 0.5
+  before = alg.trainer.optimizer.step_count
+  with pytest.raises(RuntimeError, match="arrived edited"):
+    alg.step(second)
+  assert alg.trainer.optimizer.step_count == before == 4
+  # (4) the next epoch is started with minibatches of this one never stepped
+  alg, it, first = fresh()
+  for _ in range(3):
+    next(it)
+  with pytest.raises(RuntimeError, match="never stepped"):
+    alg.step(next(it))
+  # per-update mode has none of these restrictions (the reference's semantics, update by update)
+  alg, calls = make_alg(kind, False, nenvs, horizon, 2, 4)
+  it = alg.runner.run()
+  first = next(it)
+  derl.summary.stop_recording()
+  alg.step(first)
+  alg.model.state_dict()
+  alg.step(first)
+  assert calls == [] and alg.trainer.optimizer.step_count == 2
+
+
 def _scalars_of_a_run(native):
   """Every scalar the summaries record over one rollout's updates, as (tag, global_step, value)."""
   import derl_amd as derl
