@@ -3,6 +3,7 @@ import torch
 
 from .common import Alg, Loss, _LossBackward
 from .. import distributed, summary
+from ..policies import refuse_mid_epoch
 
 
 class ActorCriticDeviceLoss(Loss):
@@ -39,6 +40,7 @@ class ActorCriticDeviceLoss(Loss):
   def _evaluate(self, data, cliprange, value_loss_coef, entropy_coef):
     """Forward + fused loss.  Returns (terms float32[8] on the device, backward closure)."""
     self._check(data, need_old=self.mode == 0)
+    refuse_mid_epoch(self.model, "evaluating the loss")
     f32 = torch.float32
     batch = data["actions"].shape[0]
     global_batch = batch * distributed.world_size()
