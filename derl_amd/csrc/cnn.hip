@@ -850,11 +850,33 @@ static int fc_ksplit(int B, int flat) {
   return ks;
 }
 
+// DX_CONVSTACK=0: the rollout's conv layers as three launches (igemm_lat.hip / conv0_b16.hip) instead of
+// the one-workgroup-per-image launch of convstack.hip; DX_CONVSTACK_MAX_B: largest batch it takes
+static bool convstack_on(int B) {
+  static int on = -1, max_b = 0;
+  if (on < 0) {
+    const char *e = getenv("DX_CONVSTACK");
+    const char *m = getenv("DX_CONVSTACK_MAX_B");
+    max_b = m ? atoi(m) : 1024;
+    on = e ? (atoi(e) != 0) : 1;
+  }
+  return on != 0 && B <= max_b;
+}
+
 // conv0 .. linear layer (split-K slabs) of a rollout step; the caller finishes with a heads launch
 static int act_trunk(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B, NTArgs *fc, hipStream_t s) {
   const Plan plan = make_plan(c, B);
-  for (int st = ST_CONV0_FWD; st <= ST_CONV2_FWD; ++st)
-    if (int rc = run_stage(c, st, obs, obs_is_u8, nullptr, B, plan, s)) return rc;
+  if (obs_is_u8 && !conv0_f32() && convstack_supported(c->in_h, c->in_w, c->in_c) && convstack_on(B)) {
+    // the three conv layers of every image in ONE launch, y0 / y1 never leave the CU (convstack.hip)
+    if (int rc = launch_convstack_image(static_cast<const uint8_t *>(obs), planes(c, c->pb_c0f), c->params + c->off_b[0],
+                                        c->packed + c->pk_c1f, c->params + c->off_b[1], c->packed + c->pk_c2f,
+                                        c->params + c->off_b[2], c->y2, B, s))
+      return rc;
+    g_route[ST_CONV0_FWD] = g_route[ST_CONV1_FWD] = g_route[ST_CONV2_FWD] = "convstack";
+  } else {
+    for (int st = ST_CONV0_FWD; st <= ST_CONV2_FWD; ++st)
+      if (int rc = run_stage(c, st, obs, obs_is_u8, nullptr, B, plan, s)) return rc;
+  }
   const int ks = fc_ksplit(B, c->flat);
   DX_REQUIRE(static_cast<long long>(ks) * B * kHid <= c->hid_slab_count, "dx_cnn_act: hid_slabs too small");
   *fc = nt_args(rows_gather(c->y2, c->flat), c->packed + c->pk_fcf, c->params + c->off_b[3],

@@ -206,6 +206,11 @@ int launch_conv0_fwd_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t str
 int launch_conv0_wgrad_b16(const Conv0Args &a, int nblocks, hipStream_t stream);
 // rollout-sized batches: 32x32 tile per workgroup, pre-split weight planes Wb [3][32][256] bf16
 int launch_conv0_lat_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t stream);
+// the rollout's whole conv stack, one workgroup per 84 x 84 x 4 uint8 frame (convstack.hip): y0 / y1 stay in LDS
+bool convstack_supported(int in_h, int in_w, int in_c);
+int launch_convstack_image(const uint8_t *obs, const uint16_t *Wb0, const float *bias0, const float *W1,
+                           const float *bias1, const float *W2, const float *bias2, float *y2, int B,
+                           hipStream_t stream);
 // heads forward + categorical loss + heads dgrad / wgrad partials + loss scalars in one launch (heads.hip)
 int launch_heads_loss_fused(const float *hid, const float *Wh, const float *bh, const int64_t *actions,
                             const float *old_log_prob, const float *advantages, const float *old_values,

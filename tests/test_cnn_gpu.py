@@ -312,6 +312,38 @@ def test_fused_rollout_act_matches_unfused_path(batch, A):
   nt.assert_allclose(values.cpu().numpy(), vals.numpy()[:, 0], rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("batch", [1, 5, 128, 300])
+def test_image_resident_conv_stack_matches_layer_by_layer_kernels(batch):
+  """The rollout's one-launch conv stack (csrc/convstack.hip: one workgroup per frame, y0 / y1 kept
+  in LDS, conv0 on exact bf16 planes, conv1 / conv2 as 16x16x4 fp32 MFMA tiles + one pixel on the
+  vector ALUs) against the layer-by-layer forward's y2 and the float64 oracle -- frames with
+  extreme bytes (0 / 255 rows) included, and the route recorded."""
+  from derl_amd import _lib
+  weights = gi.nature_cnn_weights(4, 77)
+  obs_np = gi.frames(batch, 31 + batch)
+  obs_np[0, :3] = 255
+  obs_np[-1, -5:] = 0
+  obs = torch.from_numpy(obs_np).to(DEV)
+  eng = make_engine(4, weights, max_batch=max(batch, 64))
+  eng.forward(obs)
+  want = eng.y2[:batch * 3136].clone()
+  eng.y2.fill_(float("nan"))
+  actions = torch.empty(batch, dtype=torch.int64, device=DEV)
+  log_prob, values = torch.empty(batch, device=DEV), torch.empty(batch, device=DEV)
+  eng.act(obs, actions, log_prob, values, uniforms=torch.rand(batch, device=DEV))
+  torch.cuda.synchronize()
+  lib = _lib.load()
+  assert [lib.dx_cnn_last_route(i).decode() for i in range(3)] == ["convstack"] * 3
+  got = eng.y2[:batch * 3136]
+  scale = float(want.abs().max())
+  nt.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+  # ReLU sides agree except where the pre-activation is within rounding of zero
+  flipped = ((got > 0) != (want > 0)) & (torch.maximum(got, want) > 1e-4 * scale)
+  assert not bool(flipped.any())
+  _, vals = oracle.nature_cnn_forward(weights, obs_np)
+  nt.assert_allclose(values.cpu().numpy(), vals.numpy()[:, 0], rtol=1e-4, atol=2e-5)
+
+
 def test_backward_in_two_parts_equals_whole_backward():
   """dx_cnn_backward_part(0) then (1) (the split a data-parallel caller overlaps its all-reduce
   with) gives bit-identical gradients, and part 0 alone already finalises the tail."""
