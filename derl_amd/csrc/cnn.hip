@@ -289,6 +289,9 @@ int dx_cnn_init(dx_cnn_ctx *c) {
   long long hs = mb;
   const long long mid = mb < 3072 ? mb : 3072;
   if (hs < 7 * mid) hs = 7 * mid;
+  // the rollout's weight-stationary linear layer (fc_rollout.hip) writes 14 parts, up to 1,024 rows
+  const long long act_rows = mb < 1024 ? mb : 1024;
+  if (hs < fc_rollout_parts() * act_rows) hs = fc_rollout_parts() * act_rows;
   c->hid_slab_count = hs * kHid;
   return DX_OK;
 }
@@ -842,8 +845,22 @@ int dx_cnn_backward_part(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, co
   return backward_stages(c, first, last, obs, obs_is_u8, sample_idx, B, plan, part == 1 ? 1 : part == 3 ? 3 : 2, s);
 }
 
+// DX_FC_ROLLOUT=0: the rollout's linear layer on the 32x32-tile split-K latency kernel (igemm_lat.hip)
+// instead of the weight-stationary kernel of fc_rollout.hip; DX_FC_ROLLOUT_MAX_B: largest batch it takes
+static bool fc_rollout_on(int B, int flat) {
+  static int on = -1, max_b = 0;
+  if (on < 0) {
+    const char *e = getenv("DX_FC_ROLLOUT");
+    const char *m = getenv("DX_FC_ROLLOUT_MAX_B");
+    max_b = m ? atoi(m) : 1024;
+    on = e ? (atoi(e) != 0) : 1;
+  }
+  return on != 0 && B <= max_b && fc_rollout_supported(B, kHid, flat);
+}
+
 // split of the 3136-deep linear layer over K for small batches (98 K-steps = 2 x 7 x 7)
 static int fc_ksplit(int B, int flat) {
+  if (fc_rollout_on(B, flat)) return fc_rollout_parts();
   const int steps = flat / 64 * 64 == flat ? flat / 64 : flat / 32;  // 64-deep K steps when possible
   int ks = B <= 1024 ? 7 : 1;
   while (ks > 1 && steps % ks) --ks;
@@ -883,6 +900,11 @@ static int act_trunk(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B,
                 c->hid_slabs, kHid, B, kHid, c->flat);
   fc->ksplit = ks;
   fc->slab_stride = static_cast<long long>(B) * kHid;
+  if (fc_rollout_on(B, c->flat)) {  // every weight read once per launch (fc_rollout.hip)
+    g_route[ST_FC_FWD] = "fc_rollout";
+    return launch_fc_rollout(c->y2, c->packed + c->pk_fcf, c->params + c->off_b[3], c->hid_slabs, B, s);
+  }
+  g_route[ST_FC_FWD] = "igemm_nt split-K";
   return launch_nt(*fc, false, EPI_BIAS, ST_FC_FWD, s);
 }
 

@@ -25,6 +25,9 @@
 // everywhere (v_mfma_f32_16x16x4_f32 is an fma chain, the bf16 products are exact).
 #include "igemm.hpp"
 #include "igemm_dev.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace dx {
 namespace {
@@ -53,6 +56,7 @@ struct ConvStackArgs {
   const float *bias2;
   float *y2;             // (B, 7, 7, 64) NHWC
   int B;
+  unsigned long long *stamps;  // DX_DIAG only (DX_CS_DIAG=1): [B][8] shader-clock stamps of wave 0, else NULL
 };
 
 // two bytes -> two bf16 (exact: the fp32 of an integer < 256 has a zero low half)
@@ -167,6 +171,9 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   const int n16 = lane & 15, kq = lane >> 4;
   const int oc = 16 * nt + n16;
   const uint8_t *src = a.obs + static_cast<long long>(blockIdx.x) * kFrameB;
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DX_CS_MARK(i) if (kDiag && a.stamps) tk[i] = __builtin_amdgcn_s_memtime();
+  DX_CS_MARK(0)
 
   // ---- everything this workgroup reads from memory, issued before anything is waited for ----
   u32x4 fr[4];  // the frame: 1,764 pieces of 16 bytes
@@ -195,6 +202,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
     *reinterpret_cast<u32x4 *>(smem + oW0 + (i >> 10) * kWPlaneB + ((i >> 5) & 31) * kWRowB + (i & 31) * 16) = wv[u];
   }
   __syncthreads();
+  DX_CS_MARK(1)
 
   // ---- conv0: 13 tiles of 32 pixels, waves 0-4 take two ----
   if (wave < 5) conv0_tiles<2>(smem, wave, lane, bias0);
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
     for (int s = 0; s < 18; ++s) b2[s] = *reinterpret_cast<const f32x4 *>(w2 + 16 * s);
   }
   __syncthreads();  // y0 complete; the frame's bytes are free
+  DX_CS_MARK(2)
 
   float *red = reinterpret_cast<float *>(smem + oFrame);
   float *y1 = reinterpret_cast<float *>(smem + oY1);
@@ -223,6 +232,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
     float accx = 0.f;
     if (kh2 == 0) conv1_half<0>(smem, pb, pbx, b1, acc, accx);
     else conv1_half<1>(smem, pb, pbx, b1, acc, accx);
+    DX_CS_MARK(3)
     if (kh2 == 1) {
 #pragma unroll
       for (int mt = 0; mt < 5; ++mt)
@@ -246,6 +256,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       if (kq == 0) y1[80 * kY1P + oc] = x > 0.f ? x : 0.f;
     }
     __syncthreads();
+    DX_CS_MARK(4)
   }
   {  // ---- conv2 ----
     int pb[3];
@@ -259,6 +270,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
     float accx = 0.f;
     if (kh2 == 0) conv2_half<0>(smem, pb, pbx, b2, acc, accx);
     else conv2_half<1>(smem, pb, pbx, b2, acc, accx);
+    DX_CS_MARK(5)
     if (kh2 == 1) {
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt)
@@ -283,6 +295,12 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       if (kq == 0) out[48 * 64 + oc] = x > 0.f ? x : 0.f;
     }
   }
+  DX_CS_MARK(6)
+#undef DX_CS_MARK
+  if (kDiag && a.stamps && tid == 0) {
+    tk[7] = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 8; ++i) a.stamps[blockIdx.x * 8 + i] = tk[i];
+  }
 }
 
 }  // namespace
@@ -304,7 +322,27 @@ int launch_convstack_image(const uint8_t *obs, const uint16_t *Wb0, const float 
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     configured_device = dev;
   }
-  const ConvStackArgs a{obs, Wb0, bias0, W1, bias1, W2, bias2, y2, B};
+  ConvStackArgs a{obs, Wb0, bias0, W1, bias1, W2, bias2, y2, B, nullptr};
+#if DX_DIAG
+  if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles (wave 0 of every workgroup), summarised on stderr (synchronous)
+    unsigned long long *dev = nullptr;
+    DX_HIP(hipMalloc(&dev, static_cast<size_t>(B) * 64));
+    a.stamps = dev;
+    hipLaunchKernelGGL(convstack_image_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
+    DX_LAUNCH_CHECK();
+    DX_HIP(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> h(static_cast<size_t>(B) * 8);
+    DX_HIP(hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost));
+    DX_HIP(hipFree(dev));
+    double ph[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < B; ++b)
+      for (int i = 0; i < 6; ++i) ph[i] += static_cast<double>(h[b * 8 + i + 1] - h[b * 8 + i]) / B;
+    fprintf(stderr, "[convstack B=%d] cycles per workgroup (wave 0): loads + LDS fill %.0f, conv0 %.0f, conv1 loop %.0f, "
+            "conv1 reduce + y1 %.0f, conv2 loop %.0f, conv2 reduce + store %.0f, total %.0f\n", B, ph[0], ph[1], ph[2], ph[3],
+            ph[4], ph[5], ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]);
+    return DX_OK;
+  }
+#endif
   hipLaunchKernelGGL(convstack_image_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;

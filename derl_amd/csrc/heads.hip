@@ -153,7 +153,22 @@ __device__ __forceinline__ void heads_act_fused_block(const HeadsActArgs &p, int
   const float u_given = uniforms ? uniforms[b] : 0.f;
   float h[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float *row = hid_slabs + static_cast<long long>(b) * 512 + lane * 8;
-  // slabs in batches of 7 with all loads issued before the first add (clamped index, masked add)
+  // slabs in batches of 7 with all loads issued before the first add (clamped index, masked add);
+  // exactly 14 slabs (the weight-stationary linear layer of fc_rollout.hip) as ONE batch: one memory
+  // round trip instead of two, summed in slab order like the loop below
+  if (nslab == 14) {
+    float4 u[14], w[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      u[i] = *reinterpret_cast<const float4 *>(row + i * slab_stride);
+      w[i] = *reinterpret_cast<const float4 *>(row + i * slab_stride + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      h[0] += u[i].x; h[1] += u[i].y; h[2] += u[i].z; h[3] += u[i].w;
+      h[4] += w[i].x; h[5] += w[i].y; h[6] += w[i].z; h[7] += w[i].w;
+    }
+  } else
   for (int z0 = 0; z0 < nslab; z0 += 7) {
     float4 u[7], w[7];
 #pragma unroll

@@ -211,6 +211,10 @@ bool convstack_supported(int in_h, int in_w, int in_c);
 int launch_convstack_image(const uint8_t *obs, const uint16_t *Wb0, const float *bias0, const float *W1,
                            const float *bias1, const float *W2, const float *bias2, float *y2, int B,
                            hipStream_t stream);
+// the rollout's linear layer, weight-stationary split-K (fc_rollout.hip): slabs [parts][M][512], bias on slab 0
+int fc_rollout_parts();
+bool fc_rollout_supported(int M, int N, int K);
+int launch_fc_rollout(const float *A, const float *W, const float *bias, float *slabs, int M, hipStream_t stream);
 // heads forward + categorical loss + heads dgrad / wgrad partials + loss scalars in one launch (heads.hip)
 int launch_heads_loss_fused(const float *hid, const float *Wh, const float *bh, const int64_t *actions,
                             const float *old_log_prob, const float *advantages, const float *old_values,
