@@ -95,7 +95,7 @@ class CnnCtx(ctypes.Structure):
       + [(n, ctypes.c_longlong) for n in ("pk_c2d", "pk_fcd", "pk_hdd", "packed_count", "slab_count",
                                           "y0_count", "y1_count", "y2_count", "hid_count", "head_count",
                                           "hid_slab_count", "pb_c1f", "pb_c2f", "pb_fcf", "pb_c1d",
-                                          "pb_c2d", "pb_fcd", "pb_c0f")]
+                                          "pb_c2d", "pb_fcd", "pb_c0f", "pk_wc", "pk_beff", "pk_wcs")]
       + [(n, c_void_p) for n in ("params", "grads", "packed", "y0", "y1", "y2", "hid", "head",
                                  "dy0", "dy1", "dy2", "dhid", "dhead", "slabs", "hid_slabs")])
 _RESTYPES = {"dx_last_error": c_char_p, "dx_launch_count": c_longlong, "dx_cnn_last_route": c_char_p}

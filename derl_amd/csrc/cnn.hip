@@ -117,6 +117,14 @@ bool nt_dma_on() {
 
 const char *g_route[ST_COUNT] = {};  // kernel family of the last launch of every stage (run_stage)
 
+// DX_FC_FACTORED=0: the linear layer and the heads as separate GEMM stages (the layer-by-layer
+// association) also where the factored tail of tail.hip applies (84 x 84 frames, <= 7 actions)
+bool fc_factored_env() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("DX_FC_FACTORED"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 constexpr int kBiasChunks = 256;  // row chunks of the linear layer's bias-gradient launch (512 workgroups)
 
 int roundup(long long v, int m) { return static_cast<int>((v + m - 1) / m * m); }
@@ -204,6 +212,10 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
     p.s[l].direct = 0;
     p.s[l].bsplit = 0;  // 0 = msplit (set below)
     long long b_cap = 0;  // bias partials beyond the weight slabs' count
+    if (l == L_FC && tail_supported(c->flat, c->num_actions)) {  // the factored tail's partial G slabs live here
+      const long long need = (tail_slab_floats(c->max_batch) + static_cast<long long>(N) * K - 1) / (static_cast<long long>(N) * K);
+      if (ms_cap < need) ms_cap = need;
+    }
     if (l == L_FC && wgrad_direct_on()) {  // capacity for the dedicated kernel's slices / bias chunks
       const long long slices = fc_wgrad_slices(c->max_batch >= 256 ? c->max_batch : 256, K);
       if (ms_cap < slices) ms_cap = slices;
@@ -276,6 +288,8 @@ int dx_cnn_init(dx_cnn_ctx *c) {
   c->pb_c1f = take_planes(wsz[1]); c->pb_c2f = take_planes(wsz[2]); c->pb_fcf = take_planes(wsz[3]);
   c->pb_c1d = take_planes(wsz[1]); c->pb_c2d = take_planes(wsz[2]); c->pb_fcd = take_planes(wsz[3]);
   c->pb_c0f = take_planes(wsz[0]);
+  c->pk_wc = take(8LL * d.flat); c->pk_beff = take(64);
+  c->pk_wcs = take(tail_supported(d.flat, A) ? tail_pack_scratch_floats() : 0);
   c->packed_count = po;
   c->slab_count = make_plan(c, c->max_batch).total;
   const long long mb = c->max_batch;
@@ -315,7 +329,11 @@ static uint16_t *planes(const dx_cnn_ctx *c, long long off) {
 // canonical parameters -> packed mirrors.  part 1 = what the FIRST conv layer's forward reads (its
 // forward mirror and the bf16 planes of it), part 2 = every other mirror, 3 = both.  The split lets
 // dx_cnn_ppo_epoch start the next minibatch's first layer while the rest is still being packed.
-static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s) {
+static bool fc_factored(const dx_cnn_ctx *c) { return fc_factored_env() && tail_supported(c->flat, c->num_actions); }
+
+// `light`: without the mirrors only the layer-by-layer linear layer / heads read (pk_fcf, pk_fcd and their
+// planes): what dx_cnn_ppo_epoch packs between the updates of an epoch when the factored tail is on
+static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s, bool light = false) {
   const int A = c->num_actions, IC0 = c->in_c, P = c->h2 * c->w2, flat = c->flat;
   const float *w = c->params;
   float *pk = c->packed;
@@ -357,7 +375,13 @@ static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s) {
   j[n - 1].scatter = 1;
   add(w + c->off_w[5], pk + c->pk_hdd + A, kHid, kHid, 1, 1, 1, kHeadLd, 0, 0, 0);
   j[n - 1].scatter = 1;
-  if (int rc = launch_pack_fused(j, n, w + c->off_w[3], pk + c->pk_fcf, pk + c->pk_fcd, kHid, P, kC2, s)) return rc;
+  if (fc_factored(c))  // Wc = Wh Wfc and beff: the factored tail's only mirror
+    if (int rc = launch_tail_pack(w, c->off_w, c->off_b, A, pk + c->pk_wc, pk + c->pk_beff, pk + c->pk_wcs, s)) return rc;
+  if (light) {
+    if (int rc = launch_permute_reduce(j, n, s)) return rc;
+  } else if (int rc = launch_pack_fused(j, n, w + c->off_w[3], pk + c->pk_fcf, pk + c->pk_fcd, kHid, P, kC2, s)) {
+    return rc;
+  }
   // bf16 planes (second launch: reads the mirrors packed above): conv0 for the rollout kernel,
   // the other NT mirrors only for the opt-in bf16-split GEMMs
   const float *src[7] = {pk + c->pk_c0f, pk + c->pk_c1f, pk + c->pk_c2f, pk + c->pk_fcf, pk + c->pk_c1d[0],
@@ -730,7 +754,9 @@ int dx_cnn_forward_trunk(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, co
   DX_TRACE("dx_cnn_forward_trunk");
   if (int rc = check_ctx(c, "dx_cnn_forward_trunk", B, false)) return rc;
   DX_REQUIRE(obs != nullptr, "dx_cnn_forward_trunk: null observations");
-  return forward_stages(c, ST_CONV0_FWD, ST_FC_FWD, obs, obs_is_u8, sample_idx, B, as_stream(stream));
+  // with the factored tail the trunk ends at y2: dx_cnn_heads_loss_f32 reads it directly
+  return forward_stages(c, ST_CONV0_FWD, fc_factored(c) ? ST_CONV2_FWD : ST_FC_FWD, obs, obs_is_u8, sample_idx, B,
+                        as_stream(stream));
 }
 
 // ctx->hid (B,512) -> ctx->head, the loss scalars, ctx->dhead, ctx->dhid and the heads' weight /
@@ -744,6 +770,13 @@ int dx_cnn_heads_loss_f32(const dx_cnn_ctx *c, const int64_t *actions, const flo
                           void *stream) {
   DX_TRACE("dx_cnn_heads_loss_f32");
   if (int rc = check_ctx(c, "dx_cnn_heads_loss_f32", B, true)) return rc;
+  if (fc_factored(c)) {  // out = y2 Wc^T + beff, the loss and dL/dout in one launch (heads.hip: tail_loss_kernel)
+    g_route[ST_FC_FWD] = g_route[ST_HEADS_FWD] = g_route[ST_HEADS_WGRAD] = g_route[ST_HEADS_DGRAD] = "tail_factored";
+    return launch_tail_loss(c->y2, c->packed + c->pk_wc, c->packed + c->pk_beff, actions, old_log_prob, advantages,
+                            old_values, value_targets, norm_stats, norm_eps, adv_normalized_out, c->head, c->dhead, B,
+                            c->num_actions, mode, cliprange, value_loss_coef, entropy_coef, global_batch, partials,
+                            partials_capacity, counter, loss_out, as_stream(stream));
+  }
   const Plan plan = make_plan(c, B);
   g_route[ST_HEADS_FWD] = g_route[ST_HEADS_WGRAD] = g_route[ST_HEADS_DGRAD] = "heads_loss_fused";
   return launch_heads_loss_fused(c->hid, c->packed + c->pk_hdf, c->packed + c->pk_hdb, actions, old_log_prob,
@@ -778,12 +811,35 @@ static bool bwd_overlap(int B) {
 // finalisation `which` (finalize_grads).  With the side stream and the whole gradient to finalise
 // (which == 3) the slabs of everything but conv0 are reduced ON the side stream, under the first
 // conv layer's weight gradient (the last stage of the chain), and only conv0's own slabs after it.
+// slabs -> gradients for the bits of `which` (finalize_grads); with the factored tail bit 2 (linear layer +
+// heads) is tail.hip's G reduction instead of a slab reduction
+static int finalize_any(const dx_cnn_ctx *c, const Plan &plan, int which, int B, bool factored, hipStream_t s) {
+  if (factored && (which & 2)) {
+    if (int rc = launch_tail_grads(c->params, c->grads, c->off_w, c->off_b, c->num_actions,
+                                   c->slabs + plan.s[L_FC].w_off, B, s))
+      return rc;
+    which &= ~2;
+  }
+  return which != 0 ? finalize_grads(c, plan, which, s) : DX_OK;
+}
+
 static int backward_stages(const dx_cnn_ctx *c, int first, int last, const void *obs, int obs_is_u8,
-                           const int32_t *sample_idx, int B, const Plan &plan, int which, hipStream_t s) {
+                           const int32_t *sample_idx, int B, const Plan &plan, int which, hipStream_t s,
+                           bool factored = false) {
   SideStream *side = bwd_overlap(B) ? side_stream() : nullptr;
   bool forked = false;
   int rc = DX_OK;
   for (int st = first; st <= last && rc == DX_OK; ++st) {
+    if (factored && (st == ST_FC_WGRAD || st == ST_FC_DGRAD)) {
+      // the factored tail: ONE pass over y2 gives dy2 and the partial G / s (tail.hip) in the place of the
+      // linear layer's weight- and data-gradient GEMMs
+      if (st == ST_FC_WGRAD) {
+        g_route[ST_FC_WGRAD] = g_route[ST_FC_DGRAD] = "tail_factored";
+        rc = launch_tail_bwd(c->y2, c->dhead, c->packed + c->pk_wc, c->dy2, c->slabs + plan.s[L_FC].w_off, B,
+                             c->num_actions, s);
+      }
+      continue;
+    }
     // DX_BWD_OVERLAP_MASK: which weight-gradient stages go aside (1 = linear layer, 2 = conv2, 4 = conv1)
     static const int aside_mask = [] { const char *e = getenv("DX_BWD_OVERLAP_MASK"); return e ? atoi(e) : 7; }();
     const bool aside = side != nullptr && ((st == ST_FC_WGRAD && (aside_mask & 1)) || (st == ST_CONV2_WGRAD && (aside_mask & 2)) ||
@@ -800,7 +856,7 @@ static int backward_stages(const dx_cnn_ctx *c, int first, int last, const void 
     rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, aside ? side->stream[0] : s);
     static const bool side_finalize = [] { const char *e = getenv("DX_BWD_SIDE_FINALIZE"); return !(e && atoi(e) == 0); }();
     if (rc == DX_OK && aside && side_finalize && st == ST_CONV1_WGRAD && which == 3 && last == ST_CONV0_WGRAD) {
-      rc = finalize_grads(c, plan, 2 | 8, side->stream[0]);
+      rc = finalize_any(c, plan, 2 | 8, B, factored, side->stream[0]);
       which = 4;
     }
   }
@@ -809,7 +865,7 @@ static int backward_stages(const dx_cnn_ctx *c, int first, int last, const void 
                         hipStreamWaitEvent(s, side->join[0], 0) == hipSuccess;
     if (!joined && rc == DX_OK) rc = fail(DX_EHIP, "backward: cannot join the side stream");
   }
-  if (rc == DX_OK && which != 0) rc = finalize_grads(c, plan, which, s);
+  if (rc == DX_OK && which != 0) rc = finalize_any(c, plan, which, B, factored, s);
   return rc;
 }
 
@@ -842,7 +898,11 @@ int dx_cnn_backward_part(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, co
   // parts 2 / 3: the heads' dgrad and weight-gradient slabs already exist (dx_cnn_heads_loss_f32)
   const int first = part == 0 ? ST_HEADS_WGRAD : part == 1 ? ST_CONV2_WGRAD : ST_FC_WGRAD;
   const int last = (part == 0 || part == 2) ? ST_FC_DGRAD : ST_CONV0_WGRAD;
-  return backward_stages(c, first, last, obs, obs_is_u8, sample_idx, B, plan, part == 1 ? 1 : part == 3 ? 3 : 2, s);
+  // parts 2 / 3 follow dx_cnn_heads_loss_f32: with the factored tail that call left dL/dout in ctx->dhead and
+  // the linear layer's share of the backward is tail.hip's
+  const bool factored = (part == 2 || part == 3) && fc_factored(c);
+  return backward_stages(c, first, last, obs, obs_is_u8, sample_idx, B, plan, part == 1 ? 1 : part == 3 ? 3 : 2, s,
+                         factored);
 }
 
 // DX_FC_ROLLOUT=0: the rollout's linear layer on the 32x32-tile split-K latency kernel (igemm_lat.hip)
@@ -880,6 +940,9 @@ static bool convstack_on(int B) {
   return on != 0 && B <= max_b;
 }
 
+// the rollout takes the factored tail wherever the training path does
+static bool act_factored(const dx_cnn_ctx *c) { return fc_factored(c); }
+
 // conv0 .. linear layer (split-K slabs) of a rollout step; the caller finishes with a heads launch
 static int act_trunk(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B, NTArgs *fc, hipStream_t s) {
   const Plan plan = make_plan(c, B);
@@ -894,6 +957,7 @@ static int act_trunk(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B,
     for (int st = ST_CONV0_FWD; st <= ST_CONV2_FWD; ++st)
       if (int rc = run_stage(c, st, obs, obs_is_u8, nullptr, B, plan, s)) return rc;
   }
+  if (act_factored(c)) return DX_OK;  // the caller finishes with tail_act: out = y2 Wc^T + beff (no 512-wide layer at all)
   const int ks = fc_ksplit(B, c->flat);
   DX_REQUIRE(static_cast<long long>(ks) * B * kHid <= c->hid_slab_count, "dx_cnn_act: hid_slabs too small");
   *fc = nt_args(rows_gather(c->y2, c->flat), c->packed + c->pk_fcf, c->params + c->off_b[3],
@@ -917,6 +981,11 @@ int dx_cnn_act(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B, const
   hipStream_t s = as_stream(stream);
   NTArgs a;
   if (int rc = act_trunk(c, obs, obs_is_u8, B, &a, s)) return rc;
+  if (act_factored(c)) {
+    g_route[ST_FC_FWD] = g_route[ST_HEADS_FWD] = "tail_factored";
+    return launch_tail_act(c->y2, c->packed + c->pk_wc, c->packed + c->pk_beff, B, c->num_actions, uniforms, seed,
+                           counter, actions, log_prob, values, s);
+  }
   return launch_heads_act_fused(c->hid_slabs, a.ksplit, a.slab_stride, c->packed + c->pk_hdf,
                                 c->packed + c->pk_hdb, B, c->num_actions, uniforms, seed, counter,
                                 actions, log_prob, values, s);
@@ -952,7 +1021,8 @@ int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_
   // this size, and the host pays 5.5 / 15.7 ms of launches instead of 3.5.
   int lanes = rollout_lanes() < kMaxLanes ? rollout_lanes() : kMaxLanes;
   while (lanes > 1 && !(N / lanes >= rollout_lane_min() && N % (4 * lanes) == 0 && (frame / lanes) % 16 == 0 &&
-                        static_cast<long long>(lanes) * fc_ksplit(N / lanes, c->flat) * (N / lanes) * kHid <= c->hid_slab_count))
+                        (act_factored(c) ||
+                         static_cast<long long>(lanes) * fc_ksplit(N / lanes, c->flat) * (N / lanes) * kHid <= c->hid_slab_count)))
     --lanes;
   SideStream *side = lanes > 1 ? side_stream() : nullptr;
   if (lanes > 1 && side == nullptr) return DX_EHIP;
@@ -982,6 +1052,13 @@ int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_
       rc = act_trunk(lc, obs + t * frame + l * pframe, 1, part, &a, ls);
       if (rc != DX_OK) break;
       const long long row = static_cast<long long>(t) * N + l * part;
+      if (act_factored(c)) {
+        rc = launch_tail_act_synth(lc->y2, c->packed + c->pk_wc, c->packed + c->pk_beff, part, c->num_actions,
+                                   policy_seed, policy_counter + t, actions + row, log_prob + row, values + row,
+                                   obs + (t + 1) * frame + l * pframe, pframe, rewards + row, resets + row, env_seed,
+                                   env_counter + t, p_reward, p_reset, l * part, l * (pframe / 16), ls);
+        continue;
+      }
       rc = launch_heads_act_synth(lc->hid_slabs, a.ksplit, a.slab_stride, c->packed + c->pk_hdf,
                                   c->packed + c->pk_hdb, part, c->num_actions, policy_seed,
                                   policy_counter + t, actions + row, log_prob + row, values + row,
@@ -1030,6 +1107,13 @@ int cnn_forward_range(const dx_cnn_ctx *c, int first, int last, const void *obs,
 }
 
 int cnn_pack_part(const dx_cnn_ctx *c, int part, hipStream_t s) { return pack_part(c, part, s); }
+
+// the mirrors between two updates of a native epoch: with the factored tail everything but the linear
+// layer's GEMM mirrors (nothing reads them until the epoch's last update has packed them again)
+int cnn_pack_between_updates(const dx_cnn_ctx *c, bool last_update, hipStream_t s) {
+  return pack_part(c, 3, s, fc_factored(c) && !last_update);
+}
+bool cnn_fc_factored(const dx_cnn_ctx *c) { return fc_factored(c); }
 
 // the library's side stream, ordered after everything enqueued on `s` so far (NULL: unavailable)
 hipStream_t cnn_side_begin(hipStream_t s) {

@@ -24,6 +24,8 @@ int comm_wait(hipStream_t stream);
 int cnn_forward_range(const dx_cnn_ctx *c, int first, int last, const void *obs, int obs_is_u8,
                       const int32_t *sample_idx, int B, hipStream_t s);
 int cnn_pack_part(const dx_cnn_ctx *c, int part, hipStream_t s);
+int cnn_pack_between_updates(const dx_cnn_ctx *c, bool last_update, hipStream_t s);
+bool cnn_fc_factored(const dx_cnn_ctx *c);
 hipStream_t cnn_side_begin(hipStream_t s);
 int cnn_side_end(hipStream_t s);
 }  // namespace dx
@@ -112,7 +114,8 @@ static int epoch_body(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream, 
       if (int rc = cnn_forward_range(c, ST_CONV0_FWD, ST_CONV0_FWD, obs, e->obs_is_u8, idx, B, s)) return rc;
       tail_on_side = false;
       if (int rc = cnn_side_end(s)) return rc;
-      if (int rc = cnn_forward_range(c, ST_CONV1_FWD, fused_heads ? ST_FC_FWD : ST_HEADS_FWD, obs, e->obs_is_u8, idx, B, s)) return rc;
+      const int trunk_last = cnn_fc_factored(c) ? ST_CONV2_FWD : ST_FC_FWD;
+      if (int rc = cnn_forward_range(c, ST_CONV1_FWD, fused_heads ? trunk_last : ST_HEADS_FWD, obs, e->obs_is_u8, idx, B, s)) return rc;
     } else if (fused_heads) {
       if (int rc = dx_cnn_forward_trunk(c, obs, e->obs_is_u8, idx, B, stream)) return rc;
     } else {
@@ -179,8 +182,8 @@ static int epoch_body(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream, 
                                             e->npartials, e->max_grad_norm, e->lr, e->beta1, e->opt_eps, norm_out, stream))
         return rc;
     }
-    // the mirrors follow every update (after the last one: the next rollout can act at once)
-    if (int rc = dx_cnn_pack(c, stream)) return rc;
+    // the mirrors follow every update (after the last one: everything, the next rollout can act at once)
+    if (int rc = cnn_pack_between_updates(c, !more || !fused_heads, s)) return rc;
   }
   return DX_OK;
 }

@@ -542,6 +542,124 @@ __device__ __forceinline__ Softmax half_softmax_dpp(float logit, bool is_logit) 
   return r;
 }
 
+// what the fused loss kernels know about the loss (members of their argument structs)
+struct LossParams {
+  int A, mode;
+  bool normalize;
+  float cliprange, value_loss_coef, entropy_coef, inv_batch;
+};
+
+// One row of the categorical PPO / A2C loss, lane = column of the 32-wide head row `x` (both halves
+// of the wave hold the same row): the terms of categorical_loss_kernel and the gradient w.r.t. this
+// lane's head output.  `act` and the per-row scalars are uniform over the wave.
+struct CatRow { float g, adv, ent, pl, vl, v; };
+__device__ __forceinline__ CatRow categorical_loss_row(const LossParams &a, float x, int col, bool is_logit, int act,
+                                                       float adv, float vt, float old_lp, float old_v, float meanf,
+                                                       float denom) {
+  const int A = a.A;
+  const Softmax sm = half_softmax_dpp(x, is_logit);
+  const float ent = -half_sum_dpp(is_logit ? sm.p * sm.logp : 0.f);
+  const float lp = lane_value(sm.logp, act);
+  const float v = lane_value(x, A);
+  if (a.normalize) adv = (adv - meanf) / denom;
+  float pl, vl, dlp, dv;
+  if (a.mode == 0) {
+    const float ratio = expf(lp - old_lp);
+    const float l1 = -ratio * adv;
+    pl = l1;
+    bool active = true;
+    if (a.cliprange >= 0.f) {
+      const float lo = 1.f - a.cliprange, hi = 1.f + a.cliprange;
+      const float rc = fminf(fmaxf(ratio, lo), hi);
+      const float l2 = -rc * adv;
+      pl = fmaxf(l1, l2);
+      active = (l1 > l2) || (ratio >= lo && ratio <= hi);
+    }
+    dlp = active ? -adv * ratio * a.inv_batch : 0.f;
+    const float d = v - vt;
+    const float e1 = d * d;
+    vl = e1;
+    bool vactive = true;
+    if (a.cliprange >= 0.f) {
+      const float dvo = v - old_v;
+      const float vc = old_v + fminf(fmaxf(dvo, -a.cliprange), a.cliprange);
+      const float e2 = (vc - vt) * (vc - vt);
+      vl = fmaxf(e1, e2);
+      vactive = (e1 > e2) || (fabsf(dvo) <= a.cliprange);
+    }
+    dv = vactive ? a.value_loss_coef * 2.f * d * a.inv_batch : 0.f;
+  } else {
+    pl = -lp * adv;
+    dlp = -adv * a.inv_batch;
+    const float d = v - vt;
+    vl = d * d;
+    dv = a.value_loss_coef * 2.f * d * a.inv_batch;
+  }
+  float gu = 0.f;  // dL/dhead[col]
+  if (is_logit)
+    gu = dlp * ((col == act ? 1.f : 0.f) - sm.p) + a.entropy_coef * a.inv_batch * sm.p * (sm.logp + ent);
+  else if (col == A)
+    gu = dv;
+  return CatRow{gu, adv, ent, pl, vl, v};
+}
+
+// The end of a fused loss launch: every workgroup's float64 partial sums of the eight loss terms are
+// written through, and the LAST workgroup (atomic ticket) reduces them in workgroup order to the
+// eight loss scalars of loss_reduce_kernel and resets the ticket.  lsum: [waves][8] doubles in LDS,
+// already holding each wave's sums; NW = waves per workgroup.
+template <int NW>
+__device__ __forceinline__ void loss_finish(double *lsum, unsigned *ticket_lds, double *partials, unsigned *counter,
+                                            float *loss_out, int B, float value_loss_coef, float entropy_coef) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 8) {  // write-through: the last workgroup reads every workgroup's partials
+    double tot = lsum[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tot += lsum[w * 8 + threadIdx.x];
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(partials + blockIdx.x * 8 + threadIdx.x),
+                       __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    *ticket_lds = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*ticket_lds != gridDim.x - 1) return;
+  // ---- last workgroup: loss_reduce_kernel over the partials (sc1 loads) ----
+  double t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < static_cast<int>(gridDim.x); i += 64 * NW)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      t8[j] += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(partials + i * 8 + j),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    t8[j] = wave_sum_d(t8[j]);
+    if (lane == 0) lsum[wave * 8 + j] = t8[j];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[8];
+    for (int j = 0; j < 8; ++j) {
+      t[j] = lsum[j];
+      for (int w = 1; w < NW; ++w) t[j] += lsum[w * 8 + j];
+    }
+    const double count = B;
+    const float policy = static_cast<float>(t[0] / count), ent = static_cast<float>(t[1] / count);
+    const float value = static_cast<float>(t[2] / count);
+    float *out = loss_out;
+    out[0] = (policy - entropy_coef * ent) + value_loss_coef * value;
+    out[1] = policy; out[2] = ent; out[3] = value;
+    out[4] = static_cast<float>(t[3] / count);
+    out[5] = static_cast<float>(t[4] / count);
+    out[6] = static_cast<float>(t[5] / count);
+    const double mean_v = t[4] / count;
+    const double var_v = count > 1 ? (t[7] - count * mean_v * mean_v) / (count - 1) : 0.0;
+    out[7] = static_cast<float>(1.0 - (t[6] / count) / var_v);
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
+}
+
 struct HeadsLossArgs {
   const float *hid;        // [B][512]
   const float *Wh, *bh;    // packed heads [32][512] (rows 0..A-1 policy, row A value), bias [32]
@@ -570,6 +688,7 @@ __global__ __launch_bounds__(64 * kHlWaves) void heads_loss_fused_kernel(const H
   __shared__ unsigned ticket;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31;
   const int A = a.A;
+  const LossParams lparams{a.A, a.mode, a.stats != nullptr, a.cliprange, a.value_loss_coef, a.entropy_coef, a.inv_batch};
   float4 wu[8], ww[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -634,54 +753,9 @@ __global__ __launch_bounds__(64 * kHlWaves) void heads_loss_fused_kernel(const H
     for (int u = 0; u < kAhead; ++u) {
       x[u] += bias_col;
       if (col > A) x[u] = 0.f;  // padding columns
-      // ---- categorical_loss_kernel, lane = column (both halves of the wave hold this row) ----
-      const Softmax sm = half_softmax_dpp(x[u], is_logit);
-      const float ent = -half_sum_dpp(is_logit ? sm.p * sm.logp : 0.f);
       const int act = __builtin_amdgcn_readfirstlane(p_act[u]);  // uniform: one row per wave
-      const float lp = lane_value(sm.logp, act);
-      const float v = lane_value(x[u], A);
-      float adv = p_adv[u];
-      if (a.stats) adv = (adv - meanf) / denom;
-      const float vt = p_vt[u];
-      float pl, vl, dlp, dv;
-      if (a.mode == 0) {
-        const float old_lp = p_olp[u], old_v = p_ov[u];
-        const float ratio = expf(lp - old_lp);
-        const float l1 = -ratio * adv;
-        pl = l1;
-        bool active = true;
-        if (a.cliprange >= 0.f) {
-          const float lo = 1.f - a.cliprange, hi = 1.f + a.cliprange;
-          const float rc = fminf(fmaxf(ratio, lo), hi);
-          const float l2 = -rc * adv;
-          pl = fmaxf(l1, l2);
-          active = (l1 > l2) || (ratio >= lo && ratio <= hi);
-        }
-        dlp = active ? -adv * ratio * a.inv_batch : 0.f;
-        const float d = v - vt;
-        const float e1 = d * d;
-        vl = e1;
-        bool vactive = true;
-        if (a.cliprange >= 0.f) {
-          const float dvo = v - old_v;
-          const float vc = old_v + fminf(fmaxf(dvo, -a.cliprange), a.cliprange);
-          const float e2 = (vc - vt) * (vc - vt);
-          vl = fmaxf(e1, e2);
-          vactive = (e1 > e2) || (fabsf(dvo) <= a.cliprange);
-        }
-        dv = vactive ? a.value_loss_coef * 2.f * d * a.inv_batch : 0.f;
-      } else {
-        pl = -lp * adv;
-        dlp = -adv * a.inv_batch;
-        const float d = v - vt;
-        vl = d * d;
-        dv = a.value_loss_coef * 2.f * d * a.inv_batch;
-      }
-      float gu = 0.f;  // dL/dhead[col]
-      if (is_logit)
-        gu = dlp * ((col == act ? 1.f : 0.f) - sm.p) + a.entropy_coef * a.inv_batch * sm.p * (sm.logp + ent);
-      else if (col == A)
-        gu = dv;
+      const CatRow cr = categorical_loss_row(lparams, x[u], col, is_logit, act, p_adv[u], p_vt[u], p_olp[u], p_ov[u], meanf, denom);
+      const float gu = cr.g, adv = cr.adv, ent = cr.ent, pl = cr.pl, vl = cr.vl, v = cr.v;
       g[u] = ok[u] ? gu : 0.f;  // rows past the slice contribute nothing
       advn[u] = adv; entv[u] = ent; plv[u] = pl; vlv[u] = vl; vv[u] = v;
     }
@@ -758,53 +832,209 @@ __global__ __launch_bounds__(64 * kHlWaves) void heads_loss_fused_kernel(const H
     for (int w = 1; w < kHlWaves; ++w) t += bsum[w * 32 + threadIdx.x];
     a.bias_slab[static_cast<long long>(blockIdx.x) * kHeadLd + threadIdx.x] = t;
   }
-  if (threadIdx.x < 8) {  // write-through: the last workgroup reads every workgroup's partials
-    double tot = lsum[threadIdx.x];
+  loss_finish<kHlWaves>(lsum, &ticket, a.partials, a.counter, a.loss_out, a.B, a.value_loss_coef, a.entropy_coef);
+}
+
+// ---- the FACTORED tail of the Nature CNN (csrc/tail.hip has the rest) ----
+// derl's linear layer is followed by NO activation (derl/models.py:112-115, 198-203): the 3136 -> 512
+// layer and the two heads are ONE affine map of the flattened conv output, out = y2 Wc^T + beff with
+// Wc = Wh Wfc (A + 1 rows of 3136).  The kernels below read y2 where their predecessors read the
+// 512-wide hidden row: the same loss, the same sampling rule, 1/100 of the multiplies.
+
+constexpr int kTailK = 3136;   // floats per flattened conv output (7 x 7 x 64, NHWC order)
+constexpr int kTailQ = 12;     // float4 per lane of a row held by one wave (12 x 64 x 4 = 3072) + one float
+constexpr int kTlWaves = 8;
+
+struct TailLossArgs {
+  const float *y2;         // [B][3136]
+  const float *Wc, *beff;  // [8][3136] (rows 0..A-1 policy, row A value, the rest zero), [8]
+  const int64_t *actions;
+  const float *old_log_prob, *advantages, *old_values, *value_targets;
+  const double *stats;     // optional {sum, sumsq, n} of the raw advantages: normalise here
+  float norm_eps;
+  float *adv_norm_out;
+  float *head, *dhead;     // [B][32]
+  double *partials;        // [gridDim.x][8]
+  unsigned *counter;
+  float *loss_out;         // [8]
+  int B, A, rows_per_wg, mode;
+  float cliprange, value_loss_coef, entropy_coef, inv_batch;
+};
+
+// the A + 1 dot products of NR rows held in registers (y: 12 float4 + 1 float per lane and row) with
+// the rows of Wc in LDS: lane j (and j + 32) of x[u] ends up with output j of row u
+template <int NR>
+__device__ __forceinline__ void tail_dots(const float *wc_lds, int NJ, const float4 (&y)[NR][kTailQ], const float (&yt)[NR],
+                                          int lane, int col, float (&x)[NR]) {
+  for (int j = 0; j < NJ; ++j) {  // uniform
+    const float *w = wc_lds + j * kTailK;
+    float part[NR];
 #pragma unroll
-    for (int w = 1; w < kHlWaves; ++w) tot += lsum[w * 8 + threadIdx.x];
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.partials + blockIdx.x * 8 + threadIdx.x),
-                       __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (ticket != gridDim.x - 1) return;
-  // ---- last workgroup: loss_reduce_kernel over the partials (sc1 loads) ----
-  double t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = threadIdx.x; i < static_cast<int>(gridDim.x); i += 64 * kHlWaves)
+    for (int u = 0; u < NR; ++u) part[u] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      t8[j] += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.partials + i * 8 + j),
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  __syncthreads();
+    for (int q = 0; q < kTailQ; ++q) {
+      const float4 w4 = reinterpret_cast<const float4 *>(w)[lane + 64 * q];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    t8[j] = wave_sum_d(t8[j]);
-    if (lane == 0) lsum[wave * 8 + j] = t8[j];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t[8];
-    for (int j = 0; j < 8; ++j) {
-      t[j] = lsum[j];
-      for (int w = 1; w < kHlWaves; ++w) t[j] += lsum[w * 8 + j];
+      for (int u = 0; u < NR; ++u) {
+        part[u] = fmaf(y[u][q].x, w4.x, part[u]);
+        part[u] = fmaf(y[u][q].y, w4.y, part[u]);
+        part[u] = fmaf(y[u][q].z, w4.z, part[u]);
+        part[u] = fmaf(y[u][q].w, w4.w, part[u]);
+      }
     }
-    const double count = a.B;
-    const float policy = static_cast<float>(t[0] / count), ent = static_cast<float>(t[1] / count);
-    const float value = static_cast<float>(t[2] / count);
-    float *out = a.loss_out;
-    out[0] = (policy - a.entropy_coef * ent) + a.value_loss_coef * value;
-    out[1] = policy; out[2] = ent; out[3] = value;
-    out[4] = static_cast<float>(t[3] / count);
-    out[5] = static_cast<float>(t[4] / count);
-    out[6] = static_cast<float>(t[5] / count);
-    const double mean_v = t[4] / count;
-    const double var_v = count > 1 ? (t[7] - count * mean_v * mean_v) / (count - 1) : 0.0;
-    out[7] = static_cast<float>(1.0 - (t[6] / count) / var_v);
-    __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    const float wt = w[64 * 4 * kTailQ + lane];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const float tot = wave_sum_all(fmaf(yt[u], wt, part[u]));
+      x[u] = col == j ? tot : x[u];
+    }
   }
+}
+
+// forward of the factored tail + categorical PPO / A2C loss + its gradient w.r.t. the A + 1 outputs +
+// the loss scalars, ONE launch: what the linear layer's forward and heads_loss_fused_kernel did
+__global__ __launch_bounds__(64 * kTlWaves) void tail_loss_kernel(const TailLossArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tl_smem[];  // Wc rows, then [waves][8] doubles
+  __shared__ unsigned ticket;
+  double *lsum = reinterpret_cast<double *>(tl_smem + 8 * kTailK);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31;
+  const int A = a.A, NJ = A + 1;
+  const LossParams lparams{a.A, a.mode, a.stats != nullptr, a.cliprange, a.value_loss_coef, a.entropy_coef, a.inv_batch};
+  for (int i = threadIdx.x; i < NJ * (kTailK / 4); i += 64 * kTlWaves)
+    reinterpret_cast<float4 *>(tl_smem)[i] = reinterpret_cast<const float4 *>(a.Wc)[i];
+  const float bias_col = col < 8 ? a.beff[col] : 0.f;
+  float meanf = 0.f, denom = 1.f;
+  if (a.stats) {  // adv_apply_kernel's expression
+    const double cnt = a.stats[2], mean = a.stats[0] / cnt;
+    double var = a.stats[1] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    meanf = static_cast<float>(mean);
+    denom = static_cast<float>(sqrt(var)) + a.norm_eps;
+  }
+  __syncthreads();
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool is_logit = col < A;
+  const int row_begin = blockIdx.x * a.rows_per_wg;
+  const int row_end = min(a.B, row_begin + a.rows_per_wg);
+  constexpr int kAhead = 2;  // rows per wave and pass: every Wc fragment read from LDS serves both
+  for (int r0 = row_begin + wave; r0 < row_end; r0 += kTlWaves * kAhead) {
+    float4 y[kAhead][kTailQ];
+    float yt[kAhead], p_adv[kAhead], p_vt[kAhead], p_olp[kAhead], p_ov[kAhead];
+    int p_act[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int row = min(r0 + kTlWaves * u, a.B - 1);
+      const float *base = a.y2 + static_cast<long long>(row) * kTailK;
+#pragma unroll
+      for (int q = 0; q < kTailQ; ++q) y[u][q] = reinterpret_cast<const float4 *>(base)[lane + 64 * q];
+      yt[u] = base[64 * 4 * kTailQ + lane];
+      p_act[u] = static_cast<int>(a.actions[row]);
+      p_adv[u] = a.advantages[row];
+      p_vt[u] = a.value_targets[row];
+      p_olp[u] = a.mode == 0 ? a.old_log_prob[row] : 0.f;
+      p_ov[u] = a.mode == 0 ? a.old_values[row] : 0.f;
+    }
+    float x[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) x[u] = 0.f;
+    tail_dots<kAhead>(tl_smem, NJ, y, yt, lane, col, x);
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const bool ok = r0 + kTlWaves * u < row_end;  // uniform
+      x[u] += bias_col;
+      if (col > A) x[u] = 0.f;  // padding columns
+      const int act = __builtin_amdgcn_readfirstlane(p_act[u]);
+      const CatRow cr = categorical_loss_row(lparams, x[u], col, is_logit, act, p_adv[u], p_vt[u], p_olp[u], p_ov[u], meanf, denom);
+      if (!ok) continue;  // rows past the slice: nothing stored, nothing summed
+      const int b = r0 + kTlWaves * u;
+      if (a.stats && a.adv_norm_out && lane == 0) a.adv_norm_out[b] = cr.adv;
+      if (lane < 32) {
+        a.head[static_cast<long long>(b) * kHeadLd + col] = x[u];
+        a.dhead[static_cast<long long>(b) * kHeadLd + col] = cr.g;
+      }
+      const float vt = p_vt[u];
+      s[0] += cr.pl; s[1] += cr.ent; s[2] += cr.vl; s[3] += cr.adv; s[4] += cr.v; s[5] += vt;
+      s[6] += static_cast<double>(cr.v - vt) * (cr.v - vt); s[7] += static_cast<double>(cr.v) * cr.v;
+    }
+  }
+  if (lane < 8) {
+    double mine = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine = lane == i ? s[i] : mine;
+    lsum[wave * 8 + lane] = mine;
+  }
+  __syncthreads();
+  loss_finish<kTlWaves>(lsum, &ticket, a.partials, a.counter, a.loss_out, a.B, a.value_loss_coef, a.entropy_coef);
+}
+
+// rollout: out = y2 Wc^T + beff and the categorical sampling of heads_act_fused_block, one wave per row
+struct TailActArgs {
+  const float *y2;
+  const float *Wc, *beff;
+  int B, A;
+  const float *uniforms;
+  uint64_t seed, counter;
+  int64_t *actions;
+  float *log_prob, *values;
+  int b0;  // index of row 0 in the whole batch (sampling stream position of a batch slice)
+};
+
+__device__ __forceinline__ void tail_act_block(const TailActArgs &p, int block, float *wc_lds) {
+  const int lane = threadIdx.x & 63, col = lane & 31;
+  const int A = p.A, NJ = A + 1;
+  const int b = block * 4 + (threadIdx.x >> 6);
+  const int row = min(b, p.B - 1);
+  float4 y[1][kTailQ];
+  float yt[1];
+  const float *base = p.y2 + static_cast<long long>(row) * kTailK;
+#pragma unroll
+  for (int q = 0; q < kTailQ; ++q) y[0][q] = reinterpret_cast<const float4 *>(base)[lane + 64 * q];
+  yt[0] = base[64 * 4 * kTailQ + lane];
+  const float bias_col = col < 8 ? p.beff[col] : 0.f;
+  const float u_given = p.uniforms ? p.uniforms[row] : 0.f;
+  for (int i = threadIdx.x; i < NJ * (kTailK / 4); i += 256)
+    reinterpret_cast<float4 *>(wc_lds)[i] = reinterpret_cast<const float4 *>(p.Wc)[i];
+  __syncthreads();
+  if (b >= p.B) return;  // whole wave exits together (after the barrier)
+  float xs[1] = {0.f};
+  tail_dots<1>(wc_lds, NJ, y, yt, lane, col, xs);
+  const float x = xs[0] + bias_col;
+  // categorical head (see heads_act_fused_block); lane indices below are uniform -> v_readlane
+  float mx = -INFINITY;
+  for (int k = 0; k < A; ++k) mx = fmaxf(mx, lane_value(x, k));
+  const bool is_logit = col < A;
+  const float e = is_logit ? expf(x - mx) : 0.f;
+  float acc = 0.f, cdf = 0.f;
+  for (int k = 0; k < A; ++k) {  // sequential float32 running sum in column order
+    acc += lane_value(e, k);
+    if (k == col) cdf = acc;
+  }
+  const float u = p.uniforms ? u_given : uniform01(p.seed, p.counter, b + p.b0);
+  const float thresh = u * acc;
+  const unsigned long long below = __ballot(is_logit && cdf <= thresh);
+  int act = __popcll(below & 0xffffffffull);
+  if (act > A - 1) act = A - 1;
+  const float lse = mx + logf(acc);
+  const float la = lane_value(x, act) - lse;
+  const float val = lane_value(x, A);
+  if (lane == 0) {
+    p.actions[b] = act;
+    p.log_prob[b] = la;
+    p.values[b] = val;
+  }
+}
+
+__global__ __launch_bounds__(256) void tail_act_kernel(const TailActArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float ta_smem[];
+  tail_act_block(p, blockIdx.x, ta_smem);
+}
+
+// with the synthetic device env's next observation batch / rewards / resets in the other workgroups
+// (heads_act_synth_kernel's arrangement)
+__global__ __launch_bounds__(256) void tail_act_synth_kernel(const TailActArgs p, const dx::SynthArgs e, int act_blocks) {
+  extern __shared__ __attribute__((aligned(16))) float ta_smem[];
+  if (static_cast<int>(blockIdx.x) < act_blocks) tail_act_block(p, blockIdx.x, ta_smem);
+  else dx::synth_atari_block(e, blockIdx.x - act_blocks, gridDim.x - act_blocks);
 }
 
 // the categorical loss_reduce_kernel with a row stride of 40 doubles
@@ -997,6 +1227,82 @@ int launch_heads_act_synth(const float *hid_slabs, int nslab, long long slab_str
                     p_reward, p_reset, vec0, env0};
   const int hb = cdiv(B, 4);
   hipLaunchKernelGGL(heads_act_synth_kernel, dim3(hb + synth_blocks(e.nvec, B)), dim3(256), 0, stream, p, e, hb);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+// forward + loss of the factored tail (tail_loss_kernel); DX_ENOSUP for more than 7 actions
+int launch_tail_loss(const float *y2, const float *Wc, const float *beff, const int64_t *actions,
+                     const float *old_log_prob, const float *advantages, const float *old_values,
+                     const float *value_targets, const double *stats, float norm_eps, float *adv_norm_out, float *head,
+                     float *dhead, int B, int A, int mode, float cliprange, float value_loss_coef, float entropy_coef,
+                     long long global_batch, double *partials, int partials_capacity, unsigned *counter,
+                     float *loss_out, hipStream_t stream) {
+  if (A + 1 > 8) return DX_ENOSUP;
+  DX_REQUIRE(B >= 1 && A >= 1, "tail_loss: bad shape B=%d A=%d", B, A);
+  DX_REQUIRE(mode == 0 || mode == 1, "tail_loss: mode must be 0 (PPO) or 1 (A2C)");
+  DX_REQUIRE(y2 && Wc && beff && actions && advantages && value_targets && head && dhead && partials && counter && loss_out,
+             "tail_loss: null pointer");
+  DX_REQUIRE(mode == 1 || (old_log_prob && old_values), "tail_loss: PPO needs old_log_prob / old_values");
+  // 16 rows per workgroup at least (one pass of its 8 waves x 2 rows), 256 workgroups at most
+  int nwg = cdiv(B, 16) < 256 ? cdiv(B, 16) : 256;
+  const int rows = cdiv(B, nwg);
+  nwg = cdiv(B, rows);
+  DX_REQUIRE(partials_capacity >= 8 * nwg, "tail_loss: partials needs %d doubles", 8 * nwg);
+  if (global_batch <= 0) global_batch = B;
+  const TailLossArgs a{y2, Wc, beff, actions, old_log_prob, advantages, old_values, value_targets, stats, norm_eps,
+                       adv_norm_out, head, dhead, partials, counter, loss_out, B, A, rows, mode, cliprange,
+                       value_loss_coef, entropy_coef, 1.0f / static_cast<float>(global_batch)};
+  constexpr int lds = 8 * kTailK * 4 + kTlWaves * 8 * 8;
+  static int configured_device = -1;
+  int dev = 0;
+  DX_HIP(hipGetDevice(&dev));
+  if (configured_device != dev) {
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tail_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured_device = dev;
+  }
+  hipLaunchKernelGGL(tail_loss_kernel, dim3(nwg), dim3(64 * kTlWaves), lds, stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+static int configure_tail_act() {
+  static int configured_device = -1;
+  int dev = 0;
+  DX_HIP(hipGetDevice(&dev));
+  if (configured_device != dev) {
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tail_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kTailK * 4));
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tail_act_synth_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kTailK * 4));
+    configured_device = dev;
+  }
+  return DX_OK;
+}
+
+// the rollout's factored tail: y2 (B, 3136) -> actions / log_prob / values
+int launch_tail_act(const float *y2, const float *Wc, const float *beff, int B, int A, const float *uniforms, uint64_t seed,
+                    uint64_t counter, int64_t *actions, float *log_prob, float *values, hipStream_t stream) {
+  DX_REQUIRE(B >= 1 && A >= 1 && A + 1 <= 8, "tail_act: bad shape B=%d A=%d", B, A);
+  DX_REQUIRE(y2 && Wc && beff && actions && log_prob && values, "tail_act: null pointer");
+  if (int rc = configure_tail_act()) return rc;
+  const TailActArgs p{y2, Wc, beff, B, A, uniforms, seed, counter, actions, log_prob, values, 0};
+  hipLaunchKernelGGL(tail_act_kernel, dim3(cdiv(B, 4)), dim3(256), (A + 1) * kTailK * 4, stream, p);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+int launch_tail_act_synth(const float *y2, const float *Wc, const float *beff, int B, int A, uint64_t seed, uint64_t counter,
+                          int64_t *actions, float *log_prob, float *values, void *frames, long long frame_bytes,
+                          float *rewards, uint8_t *resets, uint64_t env_seed, uint64_t env_counter, float p_reward,
+                          float p_reset, int env0, long long vec0, hipStream_t stream) {
+  DX_REQUIRE(B >= 1 && A >= 1 && A + 1 <= 8, "tail_act_synth: bad shape B=%d A=%d", B, A);
+  DX_REQUIRE(y2 && Wc && beff && actions && log_prob && values, "tail_act_synth: null pointer");
+  DX_REQUIRE(frames && frame_bytes > 0 && frame_bytes % 16 == 0 && aligned(frames, 16),
+             "tail_act_synth: frames must be 16-byte aligned, size a multiple of 16");
+  if (int rc = configure_tail_act()) return rc;
+  const TailActArgs p{y2, Wc, beff, B, A, nullptr, seed, counter, actions, log_prob, values, env0};
+  const SynthArgs e{static_cast<uint4 *>(frames), frame_bytes / 16, rewards, resets, B, env_seed, env_counter,
+                    p_reward, p_reset, vec0, env0};
+  const int ab = cdiv(B, 4);
+  hipLaunchKernelGGL(tail_act_synth_kernel, dim3(ab + synth_blocks(e.nvec, B)), dim3(256), (A + 1) * kTailK * 4, stream, p, e, ab);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

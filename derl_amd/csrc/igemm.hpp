@@ -215,6 +215,28 @@ int launch_convstack_image(const uint8_t *obs, const uint16_t *Wb0, const float 
 int fc_rollout_parts();
 bool fc_rollout_supported(int M, int N, int K);
 int launch_fc_rollout(const float *A, const float *W, const float *bias, float *slabs, int M, hipStream_t stream);
+// the factored tail: linear layer + heads as one affine map of y2 (tail.hip, heads.hip)
+bool tail_supported(int flat, int num_actions);
+long long tail_pack_scratch_floats();
+long long tail_slab_floats(int B);
+int launch_tail_pack(const float *params, const long long *off_w, const long long *off_b, int A, float *Wc, float *beff,
+                     float *scratch, hipStream_t stream);
+int launch_tail_loss(const float *y2, const float *Wc, const float *beff, const int64_t *actions,
+                     const float *old_log_prob, const float *advantages, const float *old_values,
+                     const float *value_targets, const double *stats, float norm_eps, float *adv_norm_out, float *head,
+                     float *dhead, int B, int A, int mode, float cliprange, float value_loss_coef, float entropy_coef,
+                     long long global_batch, double *partials, int partials_capacity, unsigned *counter,
+                     float *loss_out, hipStream_t stream);
+int launch_tail_bwd(const float *y2, const float *dhead, const float *Wc, float *dy2, float *scratch, int B, int A,
+                    hipStream_t stream);
+int launch_tail_grads(const float *params, float *grads, const long long *off_w, const long long *off_b, int A,
+                      float *scratch, int B, hipStream_t stream);
+int launch_tail_act(const float *y2, const float *Wc, const float *beff, int B, int A, const float *uniforms, uint64_t seed,
+                    uint64_t counter, int64_t *actions, float *log_prob, float *values, hipStream_t stream);
+int launch_tail_act_synth(const float *y2, const float *Wc, const float *beff, int B, int A, uint64_t seed, uint64_t counter,
+                          int64_t *actions, float *log_prob, float *values, void *frames, long long frame_bytes,
+                          float *rewards, uint8_t *resets, uint64_t env_seed, uint64_t env_counter, float p_reward,
+                          float p_reset, int env0, long long vec0, hipStream_t stream);
 // heads forward + categorical loss + heads dgrad / wgrad partials + loss scalars in one launch (heads.hip)
 int launch_heads_loss_fused(const float *hid, const float *Wh, const float *bh, const int64_t *actions,
                             const float *old_log_prob, const float *advantages, const float *old_values,

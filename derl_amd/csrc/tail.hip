@@ -1,0 +1,341 @@
+// The FACTORED tail of the Nature-CNN actor-critic: linear layer + both heads as ONE affine map.
+//
+// derl's NatureCNNBase ends in `linear(3136 -> 512)` with NO activation behind it (derl/models.py:112-115:
+// the ReLUs follow the three convolutions only), and NatureCNNModel applies its output layers straight
+// to that (derl/models.py:198-203).  For output_units = [A, 1] the network's last three matrices are
+// therefore one affine map of the flattened conv output y2:
+//     out = Wh (Wfc y2 + bfc) + bh = Wc y2 + beff,   Wc = Wh Wfc  ((A + 1) x 3136),  beff = Wh bfc + bh,
+// and the reverse-mode gradients derl's autograd forms (derl/alg/common.py:70) re-associate the same way:
+//     dL/dWfc = dhid^T y2 = Wh^T (dout^T y2) = Wh^T G        G = dout^T y2  ((A + 1) x 3136)
+//     dL/dWh  = dout^T hid = G Wfc^T + s bfc^T               s = sum_b dout_b
+//     dL/dbfc = Wh^T s,   dL/dbh = s,   dL/dy2 = dhid Wfc = dout Wc.
+// These are the SAME function and the SAME gradients (every parameter of the reference's state_dict gets
+// its full gradient; nothing is approximated), in the association that costs (A + 1) x 3136 multiplies
+// per sample where the layer-by-layer association costs 512 x 3136: the three largest-K GEMM stages of an
+// update (linear forward, weight gradient, data gradient: 680 us of a 3.0 ms update at minibatch 8192)
+// become two passes over y2 that are bound by HBM.  Rounding differs from the layer-by-layer order at
+// the fp32 level only (both orders against float64 on random data of the layer's shapes: 3-6e-7 of the largest element either way).
+//
+//   tail_pack_*      Wc (NHWC column order of y2) and beff from the canonical parameters, every update
+//   tail_loss_kernel (heads.hip) out, loss, dout
+//   tail_bwd_kernel  dy2 = relu'(y2) * (dout Wc), G partials, s partials: one pass over y2
+//   tail_greduce / tail_grads  G -> dWfc, dWh, dbfc, dbh straight into the flat gradient buffer
+#include "igemm.hpp"
+
+namespace dx {
+namespace {
+
+constexpr int kK = 3136, kNH = 512, kP = 49, kJ = 8;  // flat width (49 pixels x 64 channels), hidden width, pixels, padded outputs
+constexpr int kChunks = 8;                                       // n chunks of the Wc product
+constexpr int kBwdThreads = 448, kBwdCols = kK / kBwdThreads;    // 7 columns per thread
+
+struct TailWeights {
+  const float *Wfc, *bfc;  // canonical [512][c * 49 + p], [512]
+  const float *Wp, *bp;    // policy head [A][512], [A]
+  const float *Wv, *bv;    // value head [1][512], [1]
+  int A;
+};
+
+__device__ __forceinline__ float head_weight(const TailWeights &w, int j, int n) {
+  return j < w.A ? w.Wp[j * kNH + n] : (j == w.A ? w.Wv[n] : 0.f);
+}
+
+// partial[chunk][j][kc] = sum over the chunk's 64 hidden units n of Wh[j][n] Wfc[n][kc]
+__global__ __launch_bounds__(256) void tail_pack_partial_kernel(const TailWeights w, float *partial) {
+  __shared__ float sWh[kJ][64];
+  __shared__ float red[4][kJ][64];
+  const int t = threadIdx.x, col = t & 63, ng = t >> 6;
+  const int colblk = blockIdx.x % kP, chunk = blockIdx.x / kP;
+  for (int i = t; i < kJ * 64; i += 256) sWh[i >> 6][i & 63] = head_weight(w, i >> 6, chunk * 64 + (i & 63));
+  const int kc = colblk * 64 + col;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = w.Wfc[static_cast<long long>(chunk * 64 + ng * 16 + i) * kK + kc];
+  __syncthreads();
+  float acc[kJ];
+#pragma unroll
+  for (int j = 0; j < kJ; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) acc[j] = fmaf(sWh[j][ng * 16 + i], v[i], acc[j]);
+#pragma unroll
+  for (int j = 0; j < kJ; ++j) red[ng][j][col] = acc[j];
+  __syncthreads();
+  for (int i = t; i < kJ * 64; i += 256) {
+    const int j = i >> 6, c = i & 63;
+    partial[static_cast<long long>(chunk * kJ + j) * kK + colblk * 64 + c] = ((red[0][j][c] + red[1][j][c]) + red[2][j][c]) + red[3][j][c];
+  }
+}
+
+// Wc[j][p * 64 + c] = sum of the chunks' partial[.][j][c * 49 + p]; last block: beff[j] = Wh[j] . bfc + bh[j]
+__global__ __launch_bounds__(256) void tail_pack_finish_kernel(const float *partial, const TailWeights w, float *Wc, float *beff) {
+  const int t = threadIdx.x;
+  if (blockIdx.x == gridDim.x - 1) {
+    __shared__ float red[4][kJ];
+    float part[kJ];
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) part[j] = 0.f;
+    for (int n = t; n < kNH; n += 256) {
+      const float b = w.bfc[n];
+#pragma unroll
+      for (int j = 0; j < kJ; ++j) part[j] = fmaf(head_weight(w, j, n), b, part[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part[j] += __shfl_xor(part[j], o);
+      if ((t & 63) == 0) red[t >> 6][j] = part[j];
+    }
+    __syncthreads();
+    if (t < kJ) {
+      const float bh = t < w.A ? w.bp[t] : (t == w.A ? w.bv[0] : 0.f);
+      beff[t] = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) + bh;
+    }
+    return;
+  }
+  const int i = blockIdx.x * 256 + t;
+  if (i >= kJ * kK) return;
+  const int j = i / kK, k = i - j * kK, p = k >> 6, c = k & 63;
+  const int kc = c * kP + p;
+  float v = 0.f;
+#pragma unroll
+  for (int chunk = 0; chunk < kChunks; ++chunk) v += partial[static_cast<long long>(chunk * kJ + j) * kK + kc];
+  Wc[i] = v;
+}
+
+struct TailBwdArgs {
+  const float *y2;     // [B][3136]
+  const float *dhead;  // [B][32]: dL/dout in columns 0..A
+  const float *Wc;     // [8][3136]
+  float *dy2;          // [B][3136]
+  float *gslab;        // [gridDim.x][8][3136] partial G
+  float *sslab;        // [gridDim.x][8] partial s
+  int B, rows_per_wg;
+};
+
+// One pass over y2: dy2 = relu'(y2) * (dout Wc) and this workgroup's partial G = dout^T y2, s = sum dout.
+// A thread owns 7 columns (t, t + 448, ...: coalesced dword accesses) with their Wc and G entries in
+// registers; the A + 1 gradient values of a row are the same for every thread.
+template <int NJ>
+__global__ __launch_bounds__(kBwdThreads) void tail_bwd_kernel(const TailBwdArgs a) {
+  const int t = threadIdx.x;
+  float wc[NJ][kBwdCols], g[NJ][kBwdCols], sacc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    sacc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kBwdCols; ++i) {
+      wc[j][i] = a.Wc[j * kK + t + kBwdThreads * i];
+      g[j][i] = 0.f;
+    }
+  }
+  const int r0 = blockIdx.x * a.rows_per_wg, r1 = min(a.B, r0 + a.rows_per_wg);
+  constexpr int kRows = 4;  // rows in flight
+  for (int r = r0; r < r1; r += kRows) {
+    float y[kRows][kBwdCols], d[kRows][NJ];
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const long long row = min(r + u, a.B - 1);
+#pragma unroll
+      for (int i = 0; i < kBwdCols; ++i) y[u][i] = a.y2[row * kK + t + kBwdThreads * i];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) d[u][j] = a.dhead[row * 32 + j];  // the same address in every lane
+    }
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      if (r + u >= r1) break;  // uniform
+      float *out = a.dy2 + static_cast<long long>(r + u) * kK + t;
+#pragma unroll
+      for (int i = 0; i < kBwdCols; ++i) {
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          dsum = fmaf(d[u][j], wc[j][i], dsum);
+          g[j][i] = fmaf(d[u][j], y[u][i], g[j][i]);
+        }
+        out[kBwdThreads * i] = y[u][i] > 0.f ? dsum : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) sacc[j] += d[u][j];
+    }
+  }
+  float *slab = a.gslab + static_cast<long long>(blockIdx.x) * kJ * kK;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < kBwdCols; ++i) slab[j * kK + t + kBwdThreads * i] = g[j][i];
+  if (t == 0) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) a.sslab[blockIdx.x * kJ + j] = sacc[j];
+  }
+}
+
+// G[j][k] = sum over the workgroups' partials (fixed order), in y2's column order and in the canonical
+// order of Wfc's columns (k = p * 64 + c  ->  c * 49 + p); block (0, j) also sums s[j]
+__global__ __launch_bounds__(256) void tail_greduce_kernel(const float *gslab, const float *sslab, int nslab, int nj, float *Gc, float *s) {
+  __shared__ float red[4][64];
+  __shared__ float sred[256];
+  const int t = threadIdx.x, c = t & 63, sg = t >> 6;
+  const int p = blockIdx.x, j = blockIdx.y;
+  if (j >= nj) {  // rows beyond the A + 1 outputs read as zero in the heads' dot products (uniform branch)
+    if (t < 64) Gc[j * kK + c * kP + p] = 0.f;
+    if (p == 0 && t == 0) s[j] = 0.f;
+    return;
+  }
+  float v = 0.f;
+  for (int z0 = sg; z0 < nslab; z0 += 32) {  // eight loads in flight, added in slab order
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int z = z0 + 4 * u;
+      x[u] = z < nslab ? gslab[(static_cast<long long>(z) * kJ + j) * kK + p * 64 + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += x[u];
+  }
+  red[sg][c] = v;
+  if (p == 0) {
+    float sv = 0.f;
+    for (int z = t; z < nslab; z += 256) sv += sslab[z * kJ + j];
+    sred[t] = sv;
+  }
+  __syncthreads();
+  if (t < 64) Gc[j * kK + c * kP + p] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+  if (p == 0 && t == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < 256; ++i) tot += sred[i];
+    s[j] = tot;
+  }
+}
+
+struct TailGradArgs {
+  TailWeights w;
+  const float *Gc;  // [8][3136] canonical column order
+  const float *s;   // [8]
+  float *dWfc, *dbfc, *dWp, *dbp, *dWv, *dbv;  // views of the flat gradient buffer (canonical layout)
+  int nj;           // A + 1
+};
+
+constexpr int kGradBlocksW = kNH * (kK / 4) / 256;  // 1568: dWfc, one float4 per thread
+
+// dWfc = Wh^T G | dWh = G Wfc^T + s bfc^T | dbfc = Wh^T s, dbh = s -- three roles in one grid
+__global__ __launch_bounds__(256) void tail_grads_kernel(const TailGradArgs a) {
+  const int t = threadIdx.x, blk = blockIdx.x;
+  if (blk < kGradBlocksW) {
+    const int idx = blk * 256 + t, n = idx / (kK / 4), q = idx - n * (kK / 4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < a.nj; ++j) {  // uniform
+      const float wh = head_weight(a.w, j, n);
+      const float4 g4 = reinterpret_cast<const float4 *>(a.Gc + j * kK)[q];
+      acc.x = fmaf(wh, g4.x, acc.x); acc.y = fmaf(wh, g4.y, acc.y);
+      acc.z = fmaf(wh, g4.z, acc.z); acc.w = fmaf(wh, g4.w, acc.w);
+    }
+    reinterpret_cast<float4 *>(a.dWfc + static_cast<long long>(n) * kK)[q] = acc;
+    return;
+  }
+  if (blk < kGradBlocksW + kNH) {
+    __shared__ float red[4][kJ];
+    const int n = blk - kGradBlocksW;
+    float part[kJ];
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) part[j] = 0.f;
+    for (int kc = t; kc < kK; kc += 256) {
+      const float wfc = a.w.Wfc[static_cast<long long>(n) * kK + kc];
+#pragma unroll
+      for (int j = 0; j < kJ; ++j) part[j] = fmaf(a.Gc[j * kK + kc], wfc, part[j]);  // rows >= A + 1 of Gc are zero
+    }
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part[j] += __shfl_xor(part[j], o);
+      if ((t & 63) == 0) red[t >> 6][j] = part[j];
+    }
+    __syncthreads();
+    if (t < a.nj) {
+      const float v = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) + a.s[t] * a.w.bfc[n];
+      if (t < a.w.A) a.dWp[t * kNH + n] = v;
+      else a.dWv[n] = v;
+    }
+    return;
+  }
+  for (int n = t; n < kNH; n += 256) {
+    float v = 0.f;
+    for (int j = 0; j < a.nj; ++j) v = fmaf(head_weight(a.w, j, n), a.s[j], v);
+    a.dbfc[n] = v;
+  }
+  if (t < a.w.A) a.dbp[t] = a.s[t];
+  if (t == a.w.A) a.dbv[0] = a.s[t];
+}
+
+template <int NJ>
+int launch_tail_bwd_as(const TailBwdArgs &a, int nwg, hipStream_t stream) {
+  hipLaunchKernelGGL(tail_bwd_kernel<NJ>, dim3(nwg), dim3(kBwdThreads), 0, stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+TailWeights tail_weights(const float *params, const long long *off_w, const long long *off_b, int A) {
+  return TailWeights{params + off_w[3], params + off_b[3], params + off_w[4], params + off_b[4],
+                     params + off_w[5], params + off_b[5], A};
+}
+
+}  // namespace
+
+bool tail_supported(int flat, int num_actions) { return flat == kK && num_actions + 1 <= kJ; }
+
+// floats of scratch: Wc product partials (inside `packed`), and G slabs + Gc + s (inside `slabs`)
+long long tail_pack_scratch_floats() { return static_cast<long long>(kChunks) * kJ * kK; }
+int tail_bwd_workgroups(int B) {
+  const int nwg = cdiv(B, 8) < 256 ? cdiv(B, 8) : 256;  // >= 8 rows per workgroup, one workgroup per CU at most
+  return cdiv(B, cdiv(B, nwg));
+}
+long long tail_slab_floats(int B) { return (static_cast<long long>(tail_bwd_workgroups(B)) + 2) * kJ * kK + 64; }
+
+// Wc [8][3136] (y2's column order), beff [8] from the canonical parameters; scratch: tail_pack_scratch_floats()
+int launch_tail_pack(const float *params, const long long *off_w, const long long *off_b, int A, float *Wc, float *beff,
+                     float *scratch, hipStream_t stream) {
+  DX_REQUIRE(params && Wc && beff && scratch && A >= 1 && A + 1 <= kJ, "tail_pack: bad arguments");
+  const TailWeights w = tail_weights(params, off_w, off_b, A);
+  hipLaunchKernelGGL(tail_pack_partial_kernel, dim3(kP * kChunks), dim3(256), 0, stream, w, scratch);
+  DX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tail_pack_finish_kernel, dim3(cdiv(kJ * kK, 256) + 1), dim3(256), 0, stream, scratch, w, Wc, beff);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+// dy2 and the partial G / s of the minibatch (scratch: tail_slab_floats(B) floats); then
+// launch_tail_grads turns them into the linear layer's and the heads' gradients
+int launch_tail_bwd(const float *y2, const float *dhead, const float *Wc, float *dy2, float *scratch, int B, int A,
+                    hipStream_t stream) {
+  DX_REQUIRE(y2 && dhead && Wc && dy2 && scratch && B >= 1 && A >= 1 && A + 1 <= kJ, "tail_bwd: bad arguments");
+  const int nwg = tail_bwd_workgroups(B);
+  const TailBwdArgs a{y2, dhead, Wc, dy2, scratch, scratch + static_cast<long long>(nwg) * kJ * kK, B, cdiv(B, nwg)};
+  switch (A + 1) {
+    case 2: return launch_tail_bwd_as<2>(a, nwg, stream);
+    case 3: return launch_tail_bwd_as<3>(a, nwg, stream);
+    case 4: return launch_tail_bwd_as<4>(a, nwg, stream);
+    case 5: return launch_tail_bwd_as<5>(a, nwg, stream);
+    case 6: return launch_tail_bwd_as<6>(a, nwg, stream);
+    case 7: return launch_tail_bwd_as<7>(a, nwg, stream);
+    default: return launch_tail_bwd_as<8>(a, nwg, stream);
+  }
+}
+
+int launch_tail_grads(const float *params, float *grads, const long long *off_w, const long long *off_b, int A,
+                      float *scratch, int B, hipStream_t stream) {
+  DX_REQUIRE(params && grads && scratch && B >= 1 && A >= 1 && A + 1 <= kJ, "tail_grads: bad arguments");
+  const int nwg = tail_bwd_workgroups(B);
+  const float *gslab = scratch, *sslab = scratch + static_cast<long long>(nwg) * kJ * kK;
+  float *Gc = scratch + (static_cast<long long>(nwg) + 1) * kJ * kK;
+  float *s = Gc + kJ * kK;
+  hipLaunchKernelGGL(tail_greduce_kernel, dim3(kP, kJ), dim3(256), 0, stream, gslab, sslab, nwg, A + 1, Gc, s);
+  DX_LAUNCH_CHECK();
+  const TailGradArgs a{tail_weights(params, off_w, off_b, A), Gc, s, grads + off_w[3], grads + off_b[3], grads + off_w[4],
+                       grads + off_b[4], grads + off_w[5], grads + off_b[5], A + 1};
+  hipLaunchKernelGGL(tail_grads_kernel, dim3(kGradBlocksW + kNH + 1), dim3(256), 0, stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+}  // namespace dx

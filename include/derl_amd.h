@@ -237,6 +237,9 @@ typedef struct dx_cnn_ctx {
    * linear dgrad -- operands of the bf16-split GEMMs (igemm_b3.hip) */
   long long pb_c1f, pb_c2f, pb_fcf, pb_c1d, pb_c2d, pb_fcd;
   long long pb_c0f;                 /* conv0 fwd planes: operand of the rollout first-layer kernel */
+  /* the factored tail (csrc/tail.hip): Wc = Wh Wfc as [8][flat] in y2's column order, beff [8],
+   * and the scratch of their product -- offsets in floats inside `packed` */
+  long long pk_wc, pk_beff, pk_wcs;
   /* ---- device buffers (caller-allocated, fp32) ---- */
   float *params, *grads;            /* param_count */
   float *packed;                    /* packed_count; ZERO-FILLED once by the owner: dx_cnn_pack
