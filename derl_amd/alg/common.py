@@ -151,6 +151,9 @@ class Trainer:
     return self._epoch_fast_path_checked(alg, data, context, k, entry)
 
   def _epoch_fast_path_checked(self, alg, data, context, k, entry):
+    if context.consumed and k != context.next_k:  # (before the comparison: a minibatch stepped twice compares unequal too)
+      raise RuntimeError(self._EPOCH_ORDER.format(
+          what=f"minibatch {k} was stepped where minibatch {context.next_k} of the epoch is due"))
     result = self._epoch_compare(alg, data, context, k, entry)
     if result is None and context.consumed:
       raise RuntimeError(self._EPOCH_ORDER.format(
