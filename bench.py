@@ -23,9 +23,17 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STAGES = ["conv0_fwd", "conv1_fwd", "conv2_fwd", "fc_fwd", "heads_fwd", "heads_wgrad",
-          "heads_dgrad", "fc_wgrad", "fc_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad",
-          "conv1_dgrad", "conv0_wgrad", "finalize"]
+# dx_cnn_stage's numbering (csrc/igemm.hpp: enum Stage): the layer-by-layer association of the network
+STAGE_IDS = ["conv0_fwd", "conv1_fwd", "conv2_fwd", "fc_fwd", "heads_fwd", "heads_wgrad",
+             "heads_dgrad", "fc_wgrad", "fc_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad",
+             "conv1_dgrad", "conv0_wgrad", "finalize"]
+STAGES = list(STAGE_IDS)
+# what an update launches when the linear layer + heads run as ONE affine map of y2 (csrc/tail.hip; the
+# default for 84 x 84 frames and <= 7 actions): tail_loss = forward + loss + dL/dout
+# (dx_cnn_heads_loss_f32), tail_bwd = dy2 + the linear layer's / heads' gradients
+# (dx_cnn_backward_part 2: one pass over y2, the G reduction, the gradient products)
+FACTORED_STAGES = ["conv0_fwd", "conv1_fwd", "conv2_fwd", "tail_loss", "tail_bwd", "conv2_wgrad",
+                   "conv2_dgrad", "conv1_wgrad", "conv1_dgrad", "conv0_wgrad", "finalize"]
 # algorithmic multiply-accumulates per sample (dgrad = the transposed
 # convolution's MACs = forward MACs, no padding waste counted)
 MACS = dict(conv0=3_276_800, conv1=2_654_208, conv2=1_806_336, fc=1_605_632)
@@ -37,18 +45,22 @@ BF16X3_STAGES = ("conv0_fwd", "conv0_wgrad")
 PEAK_HBM_GBPS = 8000.0
 
 
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+
+
 def pmc_traffic(stage, minibatch):
-  """HBM bytes per launch of `stage` from the committed PMC passes (profiles/r03_a_pmc_traffic.json,
-  made by tools/pmc_passes.sh + tools/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-  separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes).  Counters cannot be read from
-  inside this process, so the figure is the one measured at minibatch 8192 and only reported for
-  that shape; otherwise null."""
-  path = os.path.join(ROOT, "profiles", "r03_a_pmc_traffic.json")
+  """(HBM bytes per launch of `stage`, the commit the counters were taken at) from the committed PMC
+  passes (PMC_FILE, made by tools/pmc_passes.sh + tools/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE /
+  WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes).  Counters cannot
+  be read from inside this process, so the figure is the one measured at minibatch 8192 and only
+  reported for that shape; otherwise null."""
+  path = os.path.join(ROOT, PMC_FILE)
   if minibatch != 8192 or not os.path.exists(path):
-    return None
+    return None, None
   with open(path) as f:
-    entry = json.load(f)["stages"].get(stage)
-  return entry["hbm_bytes"] if entry else None
+    data = json.load(f)
+  entry = data["stages"].get(stage)
+  return (entry["hbm_bytes"] if entry else None), data.get("commit")
 
 
 def stage_flops(name, batch, num_actions):
@@ -61,8 +73,10 @@ def stage_flops(name, batch, num_actions):
 
 
 def time_stages(model, obs, idx, batch, iters=10):
-  """Average duration (us) of every network stage at `batch`, with HIP events on the stream
-  the kernels are launched on (torch's current stream)."""
+  """Average duration (us) of every stage of an update at `batch`, with HIP events on the stream
+  the kernels are launched on (torch's current stream).  Sets ``time_stages.names`` (the stages the
+  training loop really runs: FACTORED_STAGES when the linear layer + heads run as one affine map)
+  and ``time_stages.routes``."""
   import ctypes
   from derl_amd import _lib
   eng = model.engine
@@ -71,34 +85,50 @@ def time_stages(model, obs, idx, batch, iters=10):
   eng.pack()
   is_u8 = int(obs.dtype == torch.uint8)
   stream = _lib.stream_ptr(eng.device)
+  lib = _lib.load()
+  factored = bool(lib.dx_cnn_tail_factored(ctypes.byref(eng.ctx)))
+  names = FACTORED_STAGES if factored else STAGES
+  dev = eng.device
+  actions = torch.randint(0, eng.num_actions, (batch,), dtype=torch.int64, device=dev)
+  zeros = torch.zeros(batch, device=dev)
+  adv = torch.randn(batch, device=dev)
+  partials = torch.empty(8 * ((batch + 7) // 8), dtype=torch.float64, device=dev)
+  terms = torch.empty(8, device=dev)
 
-  def launch(stage):
-    _lib.call("dx_cnn_stage", ctypes.byref(eng.ctx), stage, _lib.ptr(obs), is_u8, _lib.ptr(idx),
-              batch, stream)
+  def launch(name):
+    if name == "tail_loss":
+      eng.heads_loss(batch, actions, zeros, adv, zeros, zeros, 0, 0.1, 0.25, 0.01, batch, partials, terms)
+    elif name == "tail_bwd":
+      _lib.call("dx_cnn_backward_part", ctypes.byref(eng.ctx), _lib.ptr(obs), is_u8, _lib.ptr(idx), batch, 2, stream)
+    else:
+      _lib.call("dx_cnn_stage", ctypes.byref(eng.ctx), STAGE_IDS.index(name), _lib.ptr(obs), is_u8, _lib.ptr(idx),
+                batch, stream)
 
   # In situ: every pass runs the stages in pipeline order (a stage then finds its input where the
   # training loop leaves it -- partly in the last-level cache -- and the clocks are where a busy
   # GPU keeps them), one event pair per stage.  Timing one stage back to back right after an idle
   # gap measured the clock ramp instead: 477 us against the 405-415 us the same kernel takes in the
   # rocprofv3 trace of the training loop.
-  n = len(STAGES)
-  for stage in range(n):  # defines every buffer
-    launch(stage)
-  eng.dhead[:batch * 32].normal_()
+  n = len(names)
+  if not factored:
+    for name in names:  # defines every buffer
+      launch(name)
+    eng.dhead[:batch * 32].normal_()
   for _ in range(3):  # warm-up passes
-    for stage in range(n):
-      launch(stage)
+    for name in names:
+      launch(name)
   marks = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(iters)]
   for it in range(iters):
     marks[it][0].record()
-    for stage in range(n):
-      launch(stage)
-      marks[it][stage + 1].record()
+    for k, name in enumerate(names):
+      launch(name)
+      marks[it][k + 1].record()
   torch.cuda.synchronize()
-  lib = _lib.load()
-  time_stages.routes = {name: lib.dx_cnn_last_route(stage).decode() for stage, name in enumerate(STAGES)}
-  return {name: sum(marks[it][stage].elapsed_time(marks[it][stage + 1]) for it in range(iters)) * 1e3 / iters
-          for stage, name in enumerate(STAGES)}
+  time_stages.names = names
+  time_stages.routes = {name: lib.dx_cnn_last_route(STAGE_IDS.index(name)).decode() if name in STAGE_IDS else "tail_factored"
+                        for name in names}
+  return {name: sum(marks[it][k].elapsed_time(marks[it][k + 1]) for it in range(iters)) * 1e3 / iters
+          for k, name in enumerate(names)}
 
 
 def time_gae(T, N, iters=20):
@@ -136,7 +166,7 @@ def main():
                       "(BASELINE.md 3.1: the GPU run's shapes)")
   parser.add_argument("--cpu-iterations", type=int, default=3, help="timed CPU iterations after --cpu-warmup")
   parser.add_argument("--cpu-warmup", type=int, default=1)
-  parser.add_argument("--cpu-budget-s", type=float, default=35.0,
+  parser.add_argument("--cpu-budget-s", type=float, default=90.0,
                       help="cuts the timed CPU iterations (never below 1) to fit this many seconds")
   parser.add_argument("--no-roofline", action="store_true")
   parser.add_argument("--no-other-configs", action="store_true")
@@ -254,14 +284,53 @@ def main():
 
   # whole-iteration MFMA roofline: one env step costs the rollout forward, 1/nsteps of
   # the bootstrap forward and num_epochs x (forward + backward ~ 3 forwards) of the update
-  fwd_mflop = 2.0 * (sum(MACS.values()) + (env.action_space.n + 1) * 512) / 1e6
+  import ctypes
+  from derl_amd import _lib
+  A1 = env.action_space.n + 1
+  factored = bool(_lib.load().dx_cnn_tail_factored(ctypes.byref(alg.model.engine.ctx)))
+  fwd_mflop = 2.0 * (sum(MACS.values()) + A1 * 512) / 1e6
   per_step_mflop = fwd_mflop * (1.0 + 1.0 / args.nsteps + 3.0 * kwargs["num_epochs"])
   bound = PEAK_F32_MFMA_TFLOPS * 1e6 / per_step_mflop * world
+  # the HONEST ceiling: what the kernels execute, each part at the peak of the unit it runs on --
+  # conv1 / conv2 on fp32 MFMA (forward once per rollout step and, per epoch, forward + weight gradient +
+  # data gradient), the first conv on bf16 MFMA with 3 executed flops per algorithmic one (forward; per
+  # epoch forward + weight gradient: its input needs no gradient), the linear layer + heads either as
+  # fp32 GEMMs or, factored into one affine map of y2, as HBM passes over y2 (y2 read by the forward /
+  # loss pass, read again and dy2 written by the backward pass)
+  roll = 1.0 + 1.0 / args.nsteps
+  epochs = kwargs["num_epochs"]
+  f32_mflop = 2e-6 * (MACS["conv1"] + MACS["conv2"]) * (roll + 3.0 * epochs)
+  bf16_mflop = 3.0 * 2e-6 * MACS["conv0"] * (roll + 2.0 * epochs)
+  tail_mflop = 2e-6 * (MACS["fc"] + A1 * 512) * (roll + 3.0 * epochs)
+  hbm_bytes = 0.0
+  if factored:
+    executed_tail_mflop = 2e-6 * A1 * 3136 * (roll + 3.0 * epochs)
+    hbm_bytes = 3136 * 4 * (roll + 3.0 * epochs)  # per env step: y2 once per rollout step, 3 times per epoch sample
+    f32_s = f32_mflop / (PEAK_F32_MFMA_TFLOPS * 1e6)
+  else:
+    executed_tail_mflop = tail_mflop
+    f32_s = (f32_mflop + tail_mflop) / (PEAK_F32_MFMA_TFLOPS * 1e6)
+  floor_s = f32_s + bf16_mflop / (PEAK_BF16_MFMA_TFLOPS * 1e6) + hbm_bytes / (PEAK_HBM_GBPS * 1e9)
+  composite = 1.0 / floor_s * world
   result["iteration_roofline"] = {
       "bound": "mfma", "algorithmic_mflop_per_env_step": round(per_step_mflop, 1),
       "bound_env_steps_per_s": round(bound, 1), "frac": round(value / bound, 4),
-      "note": "fp32-MFMA peak x n_gpus / algorithmic flops per env step; the first conv layer runs on "
-              "bf16 MFMA, so this is a reference line, not a hard ceiling"}
+      "note": "fp32-MFMA peak x n_gpus / the flops per env step of the reference's layer-by-layer association "
+              "(SURVEY.md 8d); a reference line, NOT a ceiling: the first conv layer runs on bf16 MFMA and, "
+              "when `linear_layer_and_heads` says factored, the linear layer + heads cost (A + 1) x 3136 "
+              "multiplies per sample instead of 512 x 3136 -- `composite` prices what is executed",
+      "linear_layer_and_heads": ("factored: ONE affine map of y2 (derl/models.py:112-115 has no activation behind "
+                                 "the linear layer), Wc = Wh Wfc; same outputs and gradients, other association"
+                                 if factored else "layer by layer"),
+      "composite": {
+          "executed_mflop_per_env_step": {"fp32_mfma": round(f32_mflop + (0.0 if factored else tail_mflop), 2),
+                                          "bf16_mfma_3x": round(bf16_mflop, 2),
+                                          "linear_layer_and_heads": round(executed_tail_mflop, 3)},
+          "hbm_bytes_per_env_step_of_the_factored_tail": round(hbm_bytes, 1),
+          "peaks": {"fp32_mfma_TFLOPs": PEAK_F32_MFMA_TFLOPS, "bf16_mfma_TFLOPs": PEAK_BF16_MFMA_TFLOPS,
+                    "hbm_GBps": PEAK_HBM_GBPS},
+          "floor_ms_per_iteration": round(floor_s * args.nsteps * nenvs_total / world * 1e3, 2),
+          "bound_env_steps_per_s": round(composite, 1), "frac": round(value / composite, 4)}}
 
   if rank == 0 and not args.no_roofline:
     model = alg.model
@@ -283,10 +352,11 @@ def main():
     ev1.record()
     ev1.synchronize()
     act_us = ev0.elapsed_time(ev1) * 1e3 / 20
-    fwd_flops = sum(stage_flops(n, nenvs, A) for n in STAGES if n.endswith("_fwd"))
+    names = time_stages.names
+    fwd_flops = sum(stage_flops(n, nenvs, A) for n in STAGE_IDS if n.endswith("_fwd"))
     # dominant kernel = the training stage with the largest share of a PPO iteration
     # (updates take ~80 % of the iteration; every stage is its own kernel symbol)
-    flop_stages = [n for n in STAGES if stage_flops(n, 1, A) > 0 and not n.startswith("heads")]
+    flop_stages = [n for n in names if stage_flops(n, 1, A) > 0 and not n.startswith("heads")]
     dominant = max(flop_stages, key=lambda n: train[n])
     tf = stage_flops(dominant, mb, A) / (train[dominant] * 1e-6) / 1e12
     peak = PEAK_F32_MFMA_TFLOPS
@@ -301,24 +371,34 @@ def main():
              "us_per_iteration": round(train[n] * updates_per_iter, 1)}
       if n in BF16X3_STAGES:
         row["mfma"] = "bf16 x3 (exact split); train_TFLOPs counts algorithmic fp32 flops"
+      if n in ("tail_loss", "tail_bwd"):  # HBM passes over y2 (+ dy2 and the partial G slabs for tail_bwd)
+        nbytes = mb * 3136 * 4 * (1 if n == "tail_loss" else 2) + (0 if n == "tail_loss" else 2 * 256 * (A + 1) * 3136 * 4)
+        row.update(bound="hbm", algorithmic_bytes=nbytes, GBps=round(nbytes / (train[n] * 1e-6) / 1e9, 1),
+                   frac=round(nbytes / (train[n] * 1e-6) / 1e9 / PEAK_HBM_GBPS, 4))
       return row
 
-    table = {n: stage_row(n) for n in STAGES}
-    total_flops = sum(stage_flops(n, mb, A) for n in STAGES)
-    total_us = sum(train[n] for n in STAGES)
+    table = {n: stage_row(n) for n in names}
+    # flops of the reference's association for the whole network (the factored tail executes fewer)
+    total_flops = sum(stage_flops(n, mb, A) for n in STAGE_IDS)
+    total_us = sum(train[n] for n in names)
     result["roofline"] = {
         "bound": "mfma", "kernel": f"{dominant} (minibatch {mb})",
         "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(tf / peak, 4), "traffic": pmc_traffic(dominant, mb),
+        "frac": round(tf / peak, 4), "traffic": pmc_traffic(dominant, mb)[0],
+        "traffic_source": f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes) taken at "
+                          f"commit {pmc_traffic(dominant, mb)[1]}",
         "timing": "HIP events around each stage launched alone (the stage table below).  In the training loop "
                   "the weight-gradient stages of the linear layer / conv2 / conv1 run on a side stream beside "
                   "the data-gradient chain (DX_BWD_OVERLAP, minibatches >= 2048), so rocprofv3's per-kernel "
                   "averages of the default command contain launches that shared the chip; the same command "
                   "with DX_BWD_OVERLAP=0 gives the stand-alone averages "
-                  "(profiles/r03_d_bench_kernel_stats.csv / r03_d_bench_kernel_stats_serial.csv)",
+                  "(profiles/r04_*_bench_kernel_stats.csv / r04_*_bench_kernel_stats_serial.csv)",
         "network_fwd_bwd": {"us": round(total_us, 1),
                             "achieved": round(total_flops / (total_us * 1e-6) / 1e12, 2),
-                            "frac": round(total_flops / (total_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                            "frac": round(total_flops / (total_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                            "note": "flops of the reference's layer-by-layer association / measured time of one "
+                                    "update's stages: with the factored tail this 'fraction' can exceed what the "
+                                    "fp32 pipes could do -- see iteration_roofline.composite for the honest ceiling"},
         "rollout_act": {"batch": nenvs, "us": round(act_us, 1),
                         "achieved": round(fwd_flops / (act_us * 1e-6) / 1e12, 2)},
         "stages": table}

@@ -667,8 +667,8 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       }
       return took("igemm_tn", tn(L_C0, conv_gather(obs, sample_idx, c->in_h, c->in_w, IC0, c->h0, c->w0, 4, 8, 8), c->dy0, kC0,
                                   M0, kC0, 64 * IC0, obs_is_u8 != 0));
-    case ST_FINALIZE:
-      return took("finalize", finalize_grads(c, plan, 3, s));
+    case ST_FINALIZE:  // (with the factored tail the linear layer / heads have no slabs: the conv layers only)
+      return took("finalize", finalize_grads(c, plan, fc_factored(c) ? 1 : 3, s));
     default:
       return fail(DX_EINVAL, "dx_cnn: unknown stage %d", stage);
   }
@@ -1078,6 +1078,11 @@ int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_
     }
   }
   return rc;
+}
+
+// 1 when this ctx's updates and rollouts run the linear layer + heads as one affine map of y2 (tail.hip)
+int dx_cnn_tail_factored(const dx_cnn_ctx *c) {
+  return (c != nullptr && c->struct_bytes == static_cast<int>(sizeof(dx_cnn_ctx)) && fc_factored(c)) ? 1 : 0;
 }
 
 // Kernel family the LAST launch of `stage` took ("ntp", "wgrad_direct", "igemm_pix", ...; "" before any).

@@ -366,6 +366,13 @@ int dx_cnn_ppo_epoch(const dx_cnn_ctx *ctx, const dx_cnn_epoch *epoch, void *str
  * The routes depend on tile counts and divisibility by 128 images: tests pin BASELINE's minibatches
  * to the fast families, bench.py prints the route of every stage. */
 const char *dx_cnn_last_route(int stage);
+/* 1 when this ctx takes the FACTORED tail (csrc/tail.hip): derl's linear layer has no activation behind
+ * it (derl/models.py:112-115, 198-203), so linear layer + heads are one affine map out = Wc y2 + beff with
+ * Wc = Wh Wfc; dx_cnn_forward_trunk then ends at y2, dx_cnn_heads_loss_f32 reads y2, dx_cnn_backward_part
+ * (2 / 3) forms dL/dWfc = Wh^T (dout^T y2), dL/dWh, dL/dbfc, dL/dbh and dL/dy2 = dout Wc, and
+ * dx_cnn_act / dx_cnn_rollout_synth sample from y2 Wc^T -- the same outputs and gradients as the
+ * layer-by-layer route to fp32 rounding.  84 x 84 frames, <= 7 actions; DX_FC_FACTORED=0 turns it off. */
+int dx_cnn_tail_factored(const dx_cnn_ctx *ctx);
 int dx_cnn_stage(const dx_cnn_ctx *ctx, int stage, const void *obs, int obs_is_u8,
                  const int32_t *sample_idx, int B, void *stream);
 
