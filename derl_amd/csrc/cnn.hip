@@ -382,14 +382,15 @@ static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s, bool light = 
   } else if (int rc = launch_pack_fused(j, n, w + c->off_w[3], pk + c->pk_fcf, pk + c->pk_fcd, kHid, P, kC2, s)) {
     return rc;
   }
-  // bf16 planes (second launch: reads the mirrors packed above): conv0 for the rollout kernel,
-  // the other NT mirrors only for the opt-in bf16-split GEMMs
+  // bf16 planes (second launch: reads the mirrors packed above): the three conv layers' for the rollout's
+  // conv-stack kernel, the other NT mirrors only for the opt-in bf16-split GEMMs
   const float *src[7] = {pk + c->pk_c0f, pk + c->pk_c1f, pk + c->pk_c2f, pk + c->pk_fcf, pk + c->pk_c1d[0],
                          pk + c->pk_c2d, pk + c->pk_fcd};
   uint16_t *dst[7] = {planes(c, c->pb_c0f), planes(c, c->pb_c1f), planes(c, c->pb_c2f), planes(c, c->pb_fcf),
                       planes(c, c->pb_c1d), planes(c, c->pb_c2d), planes(c, c->pb_fcd)};
   const long long cnt[7] = {wsz0, wsz1, wsz2, wsz3, wsz1, wsz2, wsz3};
-  const int first = (part & 1) ? 0 : 1, count = (use_b3() ? 7 : 1) - first;
+  // (conv0 / conv1 / conv2: operands of the rollout's one-launch conv stack, convstack.hip)
+  const int first = (part & 1) ? 0 : 1, count = (use_b3() ? 7 : 3) - first;
   return count > 0 ? launch_split_planes(src + first, dst + first, cnt + first, count, s) : DX_OK;
 }
 
@@ -943,15 +944,36 @@ static bool convstack_on(int B) {
 // the rollout takes the factored tail wherever the training path does
 static bool act_factored(const dx_cnn_ctx *c) { return fc_factored(c); }
 
+// the conv-stack kernel's operands from the ctx (convstack.hip)
+static ConvStackArgs convstack_args(const dx_cnn_ctx *c, uint8_t *obs, int B) {
+  ConvStackArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.obs = obs;
+  a.Wb0 = planes(c, c->pb_c0f); a.bias0 = c->params + c->off_b[0];
+  a.Wb1 = planes(c, c->pb_c1f); a.bias1 = c->params + c->off_b[1];
+  a.Wb2 = planes(c, c->pb_c2f); a.bias2 = c->params + c->off_b[2];
+  a.B = B; a.T = 1; a.row_stride = B;
+  return a;
+}
+static bool convstack_usable(const dx_cnn_ctx *c, int obs_is_u8, int B) {
+  return obs_is_u8 && !conv0_f32() && convstack_supported(c->in_h, c->in_w, c->in_c) && convstack_on(B);
+}
+// the tail of the policy inside the conv-stack launch: out = y2 Wc^T + beff and the sampling rule
+static void convstack_tail(const dx_cnn_ctx *c, ConvStackArgs *a, const float *uniforms, uint64_t seed, uint64_t counter,
+                           int env0, int64_t *actions, float *log_prob, float *values) {
+  a->Wc = c->packed + c->pk_wc; a->beff = c->packed + c->pk_beff; a->A = c->num_actions;
+  a->uniforms = uniforms; a->seed = seed; a->counter = counter; a->env0 = env0;
+  a->actions = actions; a->log_prob = log_prob; a->values = values;
+}
+
 // conv0 .. linear layer (split-K slabs) of a rollout step; the caller finishes with a heads launch
 static int act_trunk(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B, NTArgs *fc, hipStream_t s) {
   const Plan plan = make_plan(c, B);
-  if (obs_is_u8 && !conv0_f32() && convstack_supported(c->in_h, c->in_w, c->in_c) && convstack_on(B)) {
+  if (convstack_usable(c, obs_is_u8, B)) {
     // the three conv layers of every image in ONE launch, y0 / y1 never leave the CU (convstack.hip)
-    if (int rc = launch_convstack_image(static_cast<const uint8_t *>(obs), planes(c, c->pb_c0f), c->params + c->off_b[0],
-                                        c->packed + c->pk_c1f, c->params + c->off_b[1], c->packed + c->pk_c2f,
-                                        c->params + c->off_b[2], c->y2, B, s))
-      return rc;
+    ConvStackArgs cs = convstack_args(c, static_cast<uint8_t *>(const_cast<void *>(obs)), B);
+    cs.y2 = c->y2;
+    if (int rc = launch_convstack(cs, s)) return rc;
     g_route[ST_CONV0_FWD] = g_route[ST_CONV1_FWD] = g_route[ST_CONV2_FWD] = "convstack";
   } else {
     for (int st = ST_CONV0_FWD; st <= ST_CONV2_FWD; ++st)
@@ -979,6 +1001,15 @@ int dx_cnn_act(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, int B, const
   if (int rc = check_ctx(c, "dx_cnn_act", B, false)) return rc;
   DX_REQUIRE(obs != nullptr && c->hid_slabs != nullptr, "dx_cnn_act: null observations / hid_slabs");
   hipStream_t s = as_stream(stream);
+  if (convstack_usable(c, obs_is_u8, B) && act_factored(c)) {
+    // the WHOLE act step in one launch: conv stack, y2 Wc^T + beff and the sampling, one workgroup per image
+    ConvStackArgs cs = convstack_args(c, static_cast<uint8_t *>(const_cast<void *>(obs)), B);
+    cs.y2 = c->y2;  // (kept: tests and callers may look at the conv output of the last act)
+    convstack_tail(c, &cs, uniforms, seed, counter, 0, actions, log_prob, values);
+    for (int st = ST_CONV0_FWD; st <= ST_CONV2_FWD; ++st) g_route[st] = "convstack";
+    g_route[ST_FC_FWD] = g_route[ST_HEADS_FWD] = "convstack (tail_factored)";
+    return launch_convstack(cs, s);
+  }
   NTArgs a;
   if (int rc = act_trunk(c, obs, obs_is_u8, B, &a, s)) return rc;
   if (act_factored(c)) {
@@ -1009,6 +1040,21 @@ int dx_cnn_rollout_synth(const dx_cnn_ctx *c, uint8_t *obs, int T, int N, int64_
   const long long frame = static_cast<long long>(c->in_h) * c->in_w * c->in_c * N;
   DX_REQUIRE(frame % 16 == 0, "dx_cnn_rollout_synth: frame batch must be a multiple of 16 bytes");
   hipStream_t s = as_stream(stream);
+  if (convstack_usable(c, 1, N) && act_factored(c)) {
+    // ONE launch for the whole horizon: every env's chain frame -> conv stack -> y2 Wc^T -> sample -> next frame
+    // is local to one workgroup (the synthetic env is a hash of (seed, counter, position)), so nothing crosses
+    // workgroups between steps: conv0's weights stay in LDS, the next layer's weight fragments and the next
+    // frame travel / are generated under the matrix instructions, and 129 x 2-5 kernel boundaries are gone.
+    // The same kernel with T = 1 is dx_cnn_act: the buffers equal the per-step loop's bit for bit.
+    ConvStackArgs cs = convstack_args(c, obs, N);
+    convstack_tail(c, &cs, nullptr, policy_seed, policy_counter, 0, actions, log_prob, values);
+    cs.env = 1; cs.T = T; cs.row_stride = N;
+    cs.rewards = rewards; cs.resets = resets; cs.env_seed = env_seed; cs.env_counter = env_counter;
+    cs.p_reward = p_reward; cs.p_reset = p_reset;
+    for (int st = ST_CONV0_FWD; st <= ST_CONV2_FWD; ++st) g_route[st] = "convstack";
+    g_route[ST_FC_FWD] = g_route[ST_HEADS_FWD] = "convstack (tail_factored)";
+    return launch_convstack(cs, s);
+  }
   // Lanes: the envs are cut into equal parts whose steps are independent chains (part A's step
   // t + 1 needs only part A's step t), enqueued on the caller's stream and on side streams, so
   // that one part's launch tails and ramps overlap the others' compute.  Frames, rewards and resets

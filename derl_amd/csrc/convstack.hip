@@ -5,26 +5,40 @@
 // Why: at rollout sizes (128-256 images) the layer-by-layer kernels (igemm_lat.hip: one 32x32 tile per
 // workgroup) stream every operand of every tile through L2 -- 128 KB for 0.5 MMAC -- and ran at
 // 0.21-0.29 of the fp32-MFMA peak, three dependent launches per step.  The whole conv stack of an image
-// is image-local, and 256 images are 256 CUs: here a workgroup keeps ITS image's frame (28 KB), y0
-// (20 x 20 x 32) and y1 (9 x 9 x 64) in LDS, never writes them to memory, and only y2 (7 x 7 x 64)
-// leaves the CU.  The activations are read by the matrix instructions straight from the LDS images
-// (a lane's address is its pixel's base + a compile-time tap offset: one ds_read_b128, no address
-// arithmetic in the loop, pixel pitches of 36 / 72 floats keep the 16-lane read groups on distinct
-// banks); the weights of conv1 / conv2 never touch LDS at all: wave (n tile, K half) is the ONLY reader
-// of its 16 x 256 / 16 x 288 slice of the packed matrix and loads it straight into the B-fragment
-// layout of v_mfma_f32_16x16x4_f32 (lane (n, kq) = 4 consecutive k of row n: 16 / 18 loads per lane,
-// all issued before the first layer starts, L2-resident because every workgroup reads the same 272 KB).
-//   conv0: bf16 matrix cores with EXACT operands (uint8 pixels; fp32 weights pre-split into three
-//          bf16 planes by dx_cnn_pack), v_mfma_f32_32x32x16_bf16, fp32 accumulation -- conv0_b16.hip's
-//          arithmetic; the planes sit in LDS (528-byte rows), 13 pixel tiles of 32 over 8 waves.
-//   conv1: M = 81 pixels = 5 tiles of 16 + ONE pixel, N = 4 tiles of 16, K = 512 in two halves over
-//          the 8 waves.  The 81st pixel rides on the vector ALUs beside the matrix pipe (4 fma per K
-//          step and lane from one broadcast LDS read) instead of a sixth, 94 % empty, tile.
-//   conv2: M = 49 = 3 tiles + one pixel, N = 4 tiles, K = 576 in two halves, the same way.
-// Results equal the layer-by-layer path to fp32 rounding (other summation order); exact fp32 products
-// everywhere (v_mfma_f32_16x16x4_f32 is an fma chain, the bf16 products are exact).
+// is image-local, and 256 images are 256 CUs: here a workgroup keeps ITS image's frame, y0 (20 x 20 x
+// 32) and y1 (9 x 9 x 64) in LDS, never writes them to memory, and only y2 (7 x 7 x 64) leaves the CU.
+//
+// ALL THREE layers run on the bf16 matrix cores at fp32 accuracy:
+//   * conv0 as in conv0_b16.hip: a uint8 pixel is exact in bf16, the fp32 weight splits EXACTLY into
+//     three bf16 terms (hi + mid + lo, pre-split by dx_cnn_pack), every product is exact in fp32,
+//     v_mfma_f32_32x32x16_bf16 accumulates in fp32; the 1/255 is applied once to the finished sum;
+//   * conv1 / conv2: BOTH operands are fp32 values, so both are split exactly into three bf16 terms
+//     (activations when the previous layer's epilogue writes them to LDS, weights by dx_cnn_pack) and
+//     x w = sum of nine exact products.  The six largest -- hi hi, hi mid, mid hi, hi lo, lo hi, mid mid
+//     -- are multiplied (v_mfma_f32_16x16x32_bf16: each product exact in fp32, fp32 accumulation,
+//     smallest terms first); the three dropped ones (mid lo, lo mid, lo lo) are below 2^-23 of the
+//     product, i.e. below the rounding an fp32 fma chain commits on the same sum (kTerms = 9 multiplies
+//     them too).  Six bf16 MFMAs of 16 cycles replace sixteen cycles x 16 of fp32 MFMA: 2.7x less
+//     matrix time than v_mfma_f32_16x16x4_f32 (the first version of this kernel: 30 us per launch,
+//     its conv1 + conv2 loops AT the fp32 matrix rate; stamps in the diag flavour, DX_CS_DIAG).
+// Operands: the activations are read by the matrix instructions straight from the LDS planes (a lane's
+// address is its pixel's base + a compile-time tap offset: one ds_read_b128 per plane, pixel pitches of
+// 80 / 144 bytes keep the 16-lane read groups on distinct banks); the weights of conv1 / conv2 never
+// touch LDS: wave (16-channel tile, K half) is the ONLY reader of its slice of the three planes and
+// loads it straight into the A-fragment layout (lane (channel, k group) = 8 consecutive k of one row),
+// all loads of a layer issued while the previous layer computes (L2-resident: every workgroup reads
+// the same 417 KB).  The matrix products are formed as D[channel][pixel], so a lane ends up with FOUR
+// consecutive channels of its pixel: one 8-byte LDS store per plane, one 16-byte store of y2.
+//   conv0: 13 pixel tiles of 32 over 8 waves (waves 0-4 two tiles: every weight fragment read from LDS
+//          once for both), next chunk's operands read before this chunk's MFMAs.
+//   conv1: M = 81 pixels in 6 tiles of 16, N = 4 tiles of 16 channels, K = 16 taps of 32 in two halves
+//          over the 8 waves; the halves swap three tiles each way through LDS and finish three each.
+//   conv2: M = 49 in 4 tiles, K = 18 steps of 32 in two halves, the same way.
+// Results equal the layer-by-layer path to fp32 rounding (other summation order).
+#include "bf16_split.hpp"
+#include "heads_dev.hpp"
 #include "igemm.hpp"
-#include "igemm_dev.hpp"
+#include "synth_dev.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -32,32 +46,21 @@
 namespace dx {
 namespace {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
+constexpr int kTerms = 6;  // products per fp32 x fp32 (6: everything above 2^-23 of the product; 9: all)
 constexpr int kIn = 84, kFrameB = kIn * kIn * 4, kRowB = kIn * 4;  // uint8 NHWC frame, 4 stacked channels
 constexpr int kP0 = 400, kP1 = 81, kP2 = 49;                       // output pixels of the three layers
-constexpr int kY0P = 36, kY1P = 72;                                // floats per y0 / y1 pixel in LDS (32 / 64 + pad)
+constexpr int kY0P = 80, kY0Plane = kP0 * kY0P;                    // bytes per y0 pixel / plane in LDS (32 bf16 + pad)
+constexpr int kY1P = 144, kY1Plane = kP1 * kY1P;                   // bytes per y1 pixel / plane (64 bf16 + pad)
 constexpr int kWRowB = 528, kWPlaneB = 32 * kWRowB;                // conv0 weight planes in LDS: 256 bf16 + 16 B pad
-constexpr int oFrame = 0, oY0 = oFrame + kFrameB, oY1 = oY0 + kP0 * kY0P * 4, oW0 = oY1 + kP1 * kY1P * 4,
-              kLdsBytes = oW0 + 3 * kWPlaneB;
-constexpr int kRedFloats = 4 * 21 * 64;  // the K halves meet here (aliases the frame, dead after conv0)
-static_assert(oY0 % 16 == 0 && oY1 % 16 == 0 && oW0 % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS layout");
-static_assert(kRedFloats * 4 <= kFrameB, "reduction scratch fits the frame's bytes");
-
-struct ConvStackArgs {
-  const uint8_t *obs;    // (B, 84, 84, 4) uint8
-  const uint16_t *Wb0;   // conv0 weights, three bf16 planes [3][32][256] (k = (kh, kw, c))
-  const float *bias0;
-  const float *W1;       // conv1 packed [64][512] (k = (kh, kw, ic))
-  const float *bias1;
-  const float *W2;       // conv2 packed [64][576]
-  const float *bias2;
-  float *y2;             // (B, 7, 7, 64) NHWC
-  int B;
-  unsigned long long *stamps;  // DX_DIAG only (DX_CS_DIAG=1): [B][8] shader-clock stamps of wave 0, else NULL
-};
+// LDS: [conv0 weight planes][region B].  Region B holds, in turn: the frame (at its end) while conv0
+// multiplies, the three y0 planes, then the three y1 planes (at its start) + the K halves' exchange.
+constexpr int oW0 = 0, oB = oW0 + 3 * kWPlaneB, kRegionB = 3 * kY0Plane, kLdsBytes = oB + kRegionB;
+constexpr int oFrame = oB + kRegionB - kFrameB, oY0 = oB, oY1 = oB, oRed = oB + 3 * kY1Plane;
+constexpr int kRedBytes = 8 * 12 * 64 * 4;  // every wave hands 12 accumulator registers to its partner
+static_assert(oB % 16 == 0 && oFrame % 16 == 0 && oRed % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS layout");
+static_assert(oRed + kRedBytes <= kLdsBytes, "exchange scratch inside region B");
 
 // two bytes -> two bf16 (exact: the fp32 of an integer < 256 has a zero low half)
 __device__ __forceinline__ uint32_t cs_bytes_to_bf16x2(float f0, float f1) {
@@ -77,91 +80,185 @@ __device__ __forceinline__ float cs_div255(float x) {
   const float q = x * r;
   return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
 }
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-// conv0 for NT_ 32-pixel tiles (tile0, tile0 + 8) of this wave: one pass over the 16 K chunks, every
-// weight fragment read from LDS once per chunk for both tiles
+// Workgroup barrier for LDS hand-offs ONLY: waits for this wave's LDS operations, not for its global
+// loads.  __syncthreads() is a fence and drains vmcnt too -- here that would park every wave at each
+// barrier until the NEXT layer's weight fragments (24-27 KB per wave, issued on purpose a layer ahead)
+// have landed: 12,000 of the first version's 54,000 cycles.  Nothing crosses these barriers through
+// global memory.
+// A per-iteration copy of a loop-invariant value the compiler cannot see through: what is derived from it
+// is recomputed inside the step loop (a few integer instructions) instead of being hoisted out of the loop
+// and kept in registers across all of it -- with the hoisted per-lane tables of three layers alive the
+// kernel needed 800 bytes of scratch per lane.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// 16 bytes from a UNIFORM base + a per-lane 32-bit byte offset: the scalar-base form of global_load (one
+// offset register per lane, the plane / step offsets go into the scalar base and the immediate) instead
+// of one 64-bit per-lane address per fragment
+__device__ __forceinline__ u32x4 load16(const void *base_uniform, unsigned lane_bytes) {
+  return *reinterpret_cast<const u32x4 *>(static_cast<const char *>(base_uniform) + lane_bytes);
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// four activations (consecutive channels of one pixel) -> 8 bytes in each of the three bf16 planes
+__device__ __forceinline__ void store_planes4(uint8_t *smem, int off, int plane_bytes, f32x4 v) {
+  const Split4 s = split4(v);
+  *reinterpret_cast<uint2 *>(smem + off) = s.hi;
+  *reinterpret_cast<uint2 *>(smem + off + plane_bytes) = s.mid;
+  *reinterpret_cast<uint2 *>(smem + off + 2 * plane_bytes) = s.lo;
+}
+
+// conv0 for NT_ 32-pixel tiles (tile0, tile0 + 8) of this wave: D[channel][pixel] = sum over the 16 K
+// chunks of W0(planes lo, mid, hi) x pixels; every weight fragment is read from LDS once per chunk for
+// both tiles and the next chunk's operands are read before this chunk's MFMAs
 template <int NT_>
-__device__ __forceinline__ void conv0_tiles(const uint8_t *smem, int tile0, int lane, float bias) {
+__device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int lane, f32x16 (&acc)[2]) {
   const int r = lane & 31, kg = lane >> 5;
   int pb[NT_];
-  f32x16 acc[NT_];
 #pragma unroll
   for (int t = 0; t < NT_; ++t) {
-    const int p = min(32 * (tile0 + 8 * t) + r, kP0 - 1);  // rows past the image compute a copy that is not stored
+    const int p = min(32 * (tile0 + 8 * t) + r, kP0 - 1);  // columns past the image compute a copy that is not stored
     const int oy = p / 20, ox = p - 20 * oy;
-    pb[t] = (4 * oy * kIn + 4 * ox) * 4 + 8 * kg;
+    pb[t] = oFrame + (4 * oy * kIn + 4 * ox) * 4 + 8 * kg;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   }
   const int wb = oW0 + r * kWRowB + 16 * kg;
+  uint2 px[NT_], pxn[NT_];
+  u32x4 wf[3], wfn[3];
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) px[t] = *reinterpret_cast<const uint2 *>(smem + pb[t]);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB);
 #pragma unroll
   for (int c = 0; c < 16; ++c) {  // chunk c: kernel row c / 2, bytes 16 (c % 2) .. + 15 of its 32
-    const int aoff = oFrame + (c >> 1) * kRowB + 16 * (c & 1);
-    bf16x8 af[NT_];
+    if (c + 1 < 16) {
+      const int aoff = ((c + 1) >> 1) * kRowB + 16 * ((c + 1) & 1);
 #pragma unroll
-    for (int t = 0; t < NT_; ++t) af[t] = cs_expand8(*reinterpret_cast<const uint2 *>(smem + pb[t] + aoff));
+      for (int t = 0; t < NT_; ++t) pxn[t] = *reinterpret_cast<const uint2 *>(smem + pb[t] + aoff);
 #pragma unroll
-    for (int pl = 2; pl >= 0; --pl) {
-      const bf16x8 bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB + 32 * c));
-#pragma unroll
-      for (int t = 0; t < NT_; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bf, acc[t], 0, 0, 0);
+      for (int pl = 0; pl < 3; ++pl) wfn[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB + 32 * (c + 1));
     }
-  }
-  float *y0 = reinterpret_cast<float *>(const_cast<uint8_t *>(smem) + oY0);
+    bf16x8 pf[NT_];
 #pragma unroll
-  for (int t = 0; t < NT_; ++t)
+    for (int t = 0; t < NT_; ++t) pf[t] = cs_expand8(px[t]);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {  // C/D layout: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
-      const int p = 32 * (tile0 + 8 * t) + (i & 3) + 8 * (i >> 2) + 4 * kg;
-      const float v = cs_div255(acc[t][i]) + bias;
-      if (p < kP0) y0[p * kY0P + r] = v > 0.f ? v : 0.f;
+    for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[pl]), pf[t], acc[t], 0, 0, 0);
+    if (c + 1 < 16) {
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) px[t] = pxn[t];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) wf[pl] = wfn[pl];
     }
-}
-
-// K half KH of conv1 for this wave's 16 output channels: 5 pixel tiles on the matrix pipe, pixel 80
-// on the vector ALUs.  pb = byte address of the lane's pixel (input pixel (2 oy, 2 ox)) + its k group.
-template <int KH>
-__device__ __forceinline__ void conv1_half(const uint8_t *smem, const int (&pb)[5], int pbx, const f32x4 (&b)[16],
-                                           f32x4 (&acc)[5], float &accx) {
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {  // K step s: tap (kh, kw) = (2 KH + s / 8, (s / 2) % 4), input channels 16 (s % 2) ..
-    const int off = oY0 + (((2 * KH + (s >> 3)) * 20 + ((s >> 1) & 3)) * kY0P + (s & 1) * 16) * 4;
-    f32x4 av[5];
-#pragma unroll
-    for (int mt = 0; mt < 5; ++mt) av[mt] = *reinterpret_cast<const f32x4 *>(smem + pb[mt] + off);
-    const f32x4 ax = *reinterpret_cast<const f32x4 *>(smem + pbx + off);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int mt = 0; mt < 5; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][j], b[s][j], acc[mt], 0, 0, 0);
-    accx = __builtin_fmaf(ax[0], b[s][0], accx);
-    accx = __builtin_fmaf(ax[1], b[s][1], accx);
-    accx = __builtin_fmaf(ax[2], b[s][2], accx);
-    accx = __builtin_fmaf(ax[3], b[s][3], accx);
   }
 }
 
-// K half KH of conv2 (K steps 18 KH .. 18 KH + 17 of 36: tap = step / 4, input channels 16 (step % 4) ..)
-template <int KH>
-__device__ __forceinline__ void conv2_half(const uint8_t *smem, const int (&pb)[3], int pbx, const f32x4 (&b)[18],
-                                           f32x4 (&acc)[3], float &accx) {
+// bias + ReLU + exact three-way split -> the y0 planes.  C/D layout of a 32x32 tile: column (pixel) =
+// lane & 31, rows (channels) of register i = (i & 3) + 8 (i >> 2) + 4 (lane >> 5): registers 4q .. 4q + 3
+// are four consecutive channels
+template <int NT_>
+__device__ __forceinline__ void conv0_store(uint8_t *smem, int tile0, int lane, const f32x16 (&acc)[2], const f32x4 (&bias)[4]) {
+  const int r = lane & 31, kg = lane >> 5;
 #pragma unroll
-  for (int s = 0; s < 18; ++s) {
-    const int g = 18 * KH + s, tap = g >> 2;
-    const int off = oY1 + (((tap / 3) * 9 + tap % 3) * kY1P + (g & 3) * 16) * 4;
-    f32x4 av[3];
+  for (int t = 0; t < NT_; ++t) {
+    const int p = 32 * (tile0 + 8 * t) + r;
+    if (p >= kP0) continue;
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) av[mt] = *reinterpret_cast<const f32x4 *>(smem + pb[mt] + off);
-    const f32x4 ax = *reinterpret_cast<const f32x4 *>(smem + pbx + off);
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int mt = 0; mt < 3; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][j], b[s][j], acc[mt], 0, 0, 0);
-    accx = __builtin_fmaf(ax[0], b[s][0], accx);
-    accx = __builtin_fmaf(ax[1], b[s][1], accx);
-    accx = __builtin_fmaf(ax[2], b[s][2], accx);
-    accx = __builtin_fmaf(ax[3], b[s][3], accx);
+      for (int j = 0; j < 4; ++j) {
+        const float x = cs_div255(acc[t][4 * q + j]) + bias[q][j];
+        v[j] = x > 0.f ? x : 0.f;
+      }
+      store_planes4(smem, oY0 + p * kY0P + (8 * q + 4 * kg) * 2, kY0Plane, v);
+    }
   }
+}
+
+// the products of one 16x16 tile and one K step: weight fragment planes w (hi, mid, lo) x activation
+// fragment planes x, smallest terms first
+__device__ __forceinline__ f32x4 mac_terms(f32x4 acc, const u32x4 (&w)[3], const u32x4 (&x)[3]) {
+#define DX_CS_T(a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w[a]), as_bf16x8(x[b]), acc, 0, 0, 0);
+  if (kTerms == 9) { DX_CS_T(2, 2) DX_CS_T(2, 1) DX_CS_T(1, 2) }
+  DX_CS_T(2, 0) DX_CS_T(0, 2) DX_CS_T(1, 1) DX_CS_T(1, 0) DX_CS_T(0, 1) DX_CS_T(0, 0)
+#undef DX_CS_T
+  return acc;
+}
+
+// One K half of conv1 (KH: taps 8 KH .. 8 KH + 7) or conv2 (KH: steps 9 KH .. 9 KH + 8 of 18) for this wave's
+// 16 channels: NT pixel tiles, activations from the LDS planes (pb = byte address of the lane's pixel
+// and k group in plane 0), the next tile's fragments read before this tile's MFMAs.
+template <int LAYER, int KH, int NT, int NS>
+__device__ __forceinline__ void conv_half(const uint8_t *smem, const int (&pb)[NT], const u32x4 (&w)[NS][3], f32x4 (&acc)[NT]) {
+  constexpr int plane = LAYER == 1 ? kY0Plane : kY1Plane;
+  u32x4 x[3], xn[3];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    int off;
+    if (LAYER == 1) {  // tap (kh, kw) = ((8 KH + s) / 4, s % 4): 32 input channels = one K step
+      off = (((8 * KH + s) >> 2) * 20 + (s & 3)) * kY0P;
+    } else {           // step g = 9 KH + s: tap g / 2, input channels 32 (g % 2) ..
+      const int g = 9 * KH + s, tap = g >> 1;
+      off = ((tap / 3) * 9 + tap % 3) * kY1P + (g & 1) * 64;
+    }
+    if (s == 0) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) x[pl] = *reinterpret_cast<const u32x4 *>(smem + pb[0] + off + pl * plane);
+    }
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      // the fragments of the next tile (or of the next step's first tile) travel while this tile multiplies
+      if (mt + 1 < NT) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xn[pl] = *reinterpret_cast<const u32x4 *>(smem + pb[mt + 1] + off + pl * plane);
+      } else if (s + 1 < NS) {
+        int offn;
+        if (LAYER == 1) {
+          offn = (((8 * KH + s + 1) >> 2) * 20 + ((s + 1) & 3)) * kY0P;
+        } else {
+          const int g = 9 * KH + s + 1, tap = g >> 1;
+          offn = ((tap / 3) * 9 + tap % 3) * kY1P + (g & 1) * 64;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xn[pl] = *reinterpret_cast<const u32x4 *>(smem + pb[0] + offn + pl * plane);
+      }
+      acc[mt] = mac_terms(acc[mt], w[s], x);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) x[pl] = xn[pl];
+    }
+  }
+}
+
+// the K halves' exchange: tiles FROM .. FROM + N - 1 of this wave's accumulators go to its partner
+// (constant indices: a dynamically indexed accumulator array would live in scratch memory)
+template <int FROM, int N, int NT>
+__device__ __forceinline__ void give_tiles(float *red, int wave, int lane, const f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int m = 0; m < N; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(wave * 12 + 4 * m + j) * 64 + lane] = acc[FROM + m][j];
+}
+// tile KEEP + m of this wave + what its partner handed over + bias, ReLU
+template <int KEEP, int NT>
+__device__ __forceinline__ f32x4 finish_tile(const float *red, int partner, int lane, const f32x4 (&acc)[NT], int m, f32x4 bias) {
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float mine = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT - KEEP; ++t) mine = t == m ? acc[KEEP + t][j] : mine;  // m is a constant after unrolling
+    const float x = (mine + red[(partner * 12 + 4 * m + j) * 64 + lane]) + bias[j];
+    v[j] = x > 0.f ? x : 0.f;
+  }
+  return v;
 }
 
 __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArgs a) {
@@ -169,133 +266,236 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave & 3, kh2 = wave >> 2;  // conv1 / conv2: output-channel tile and K half of this wave
   const int n16 = lane & 15, kq = lane >> 4;
-  const int oc = 16 * nt + n16;
-  const uint8_t *src = a.obs + static_cast<long long>(blockIdx.x) * kFrameB;
+  const int e = blockIdx.x;
+  const long long step_bytes = static_cast<long long>(a.row_stride) * kFrameB;  // frames of one step of the whole batch
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define DX_CS_MARK(i) if (kDiag && a.stamps) tk[i] = __builtin_amdgcn_s_memtime();
+#define DX_CS_MARK(i) if (kDiag && a.stamps && t == 0) tk[i] = __builtin_amdgcn_s_memtime();
+  int t = 0;
   DX_CS_MARK(0)
 
-  // ---- everything this workgroup reads from memory, issued before anything is waited for ----
-  u32x4 fr[4];  // the frame: 1,764 pieces of 16 bytes
-#pragma unroll
-  for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const u32x4 *>(src + 16 * min(tid + 512 * u, kFrameB / 16 - 1));
-  u32x4 wv[6];  // conv0's planes: 3 x 32 rows x 32 pieces
-#pragma unroll
-  for (int u = 0; u < 6; ++u) {
-    const int i = u * 512 + tid;
-    wv[u] = *reinterpret_cast<const u32x4 *>(a.Wb0 + (i >> 10) * 8192 + ((i >> 5) & 31) * 256 + (i & 31) * 8);
-  }
-  const float bias0 = a.bias0[lane & 31], bias1 = a.bias1[oc], bias2 = a.bias2[oc];
-  f32x4 b1[16];  // this wave's B fragments of conv1: W1[oc][256 kh2 + 16 s + 4 kq ..]
+  // ---- step 0's frame and conv0's weight planes (resident for the whole launch): issued at once ----
   {
-    const float *w1 = a.W1 + oc * 512 + kh2 * 256 + 4 * kq;
+    const uint8_t *src = a.obs + static_cast<long long>(e) * kFrameB;
+    u32x4 fr[4];  // the frame: 1,764 pieces of 16 bytes
 #pragma unroll
-    for (int s = 0; s < 16; ++s) b1[s] = *reinterpret_cast<const f32x4 *>(w1 + 16 * s);
+    for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const u32x4 *>(src + 16 * min(tid + 512 * u, kFrameB / 16 - 1));
+    u32x4 wv[6];  // conv0's planes: 3 x 32 rows x 32 pieces
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = u * 512 + tid;
+      wv[u] = *reinterpret_cast<const u32x4 *>(a.Wb0 + (i >> 10) * 8192 + ((i >> 5) & 31) * 256 + (i & 31) * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (tid + 512 * u < kFrameB / 16) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * (tid + 512 * u)) = fr[u];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = u * 512 + tid;
+      *reinterpret_cast<u32x4 *>(smem + oW0 + (i >> 10) * kWPlaneB + ((i >> 5) & 31) * kWRowB + (i & 31) * 16) = wv[u];
+    }
   }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-    if (tid + 512 * u < kFrameB / 16) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * (tid + 512 * u)) = fr[u];
-#pragma unroll
-  for (int u = 0; u < 6; ++u) {
-    const int i = u * 512 + tid;
-    *reinterpret_cast<u32x4 *>(smem + oW0 + (i >> 10) * kWPlaneB + ((i >> 5) & 31) * kWRowB + (i & 31) * 16) = wv[u];
-  }
-  __syncthreads();
-  DX_CS_MARK(1)
-
-  // ---- conv0: 13 tiles of 32 pixels, waves 0-4 take two ----
-  if (wave < 5) conv0_tiles<2>(smem, wave, lane, bias0);
-  else conv0_tiles<1>(smem, wave, lane, bias0);
-  // conv2's B fragments travel while conv1 runs
-  f32x4 b2[18];
-  {
-    const float *w2 = a.W2 + oc * 576 + kh2 * 288 + 4 * kq;
-#pragma unroll
-    for (int s = 0; s < 18; ++s) b2[s] = *reinterpret_cast<const f32x4 *>(w2 + 16 * s);
-  }
-  __syncthreads();  // y0 complete; the frame's bytes are free
-  DX_CS_MARK(2)
-
-  float *red = reinterpret_cast<float *>(smem + oFrame);
-  float *y1 = reinterpret_cast<float *>(smem + oY1);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  {  // ---- conv1 ----
-    int pb[5];
+  float *red = reinterpret_cast<float *>(smem + oRed);
+  float *tailred = reinterpret_cast<float *>(smem + oRed + kRedBytes);  // [8 waves][8 outputs]
+  // this lane's byte offsets into a plane of the conv1 / conv2 weights: row (channel) 16 nt + n16, K half, k group kq
+  const unsigned off1 = static_cast<unsigned>(((16 * nt + n16) * 512 + (8 * kh2) * 32 + 8 * kq) * 2);
+  const unsigned off2 = static_cast<unsigned>(((16 * nt + n16) * 576 + (9 * kh2) * 32 + 8 * kq) * 2);
+
+  for (t = 0; t < a.T; ++t) {
+    // conv1's weight fragments travel while conv0 runs: A fragment of v_mfma_f32_16x16x32_bf16 = 8 consecutive k
+    // of row (channel) 16 nt + n16: plane pl, tap 8 kh2 + s, k group kq
+    u32x4 w1[8][3];
+    {
+      const unsigned o1 = static_cast<unsigned>(opaque(static_cast<int>(off1)));
 #pragma unroll
-    for (int mt = 0; mt < 5; ++mt) {
-      const int p = 16 * mt + n16, oy = p / 9, ox = p - 9 * oy;
-      pb[mt] = ((2 * oy * 20 + 2 * ox) * kY0P + 4 * kq) * 4;
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load16(a.Wb1 + pl * (64 * 512) + 32 * s, o1);
     }
-    const int pbx = ((16 * 20 + 16) * kY0P + 4 * kq) * 4;  // output pixel (8, 8)
-    f32x4 acc[5] = {zero4, zero4, zero4, zero4, zero4};
-    float accx = 0.f;
-    if (kh2 == 0) conv1_half<0>(smem, pb, pbx, b1, acc, accx);
-    else conv1_half<1>(smem, pb, pbx, b1, acc, accx);
-    DX_CS_MARK(3)
-    if (kh2 == 1) {
+    lds_barrier();  // this step's frame (and, at step 0, conv0's planes) are in LDS
+    DX_CS_MARK(1)
+
+    // ---- conv0: 13 tiles of 32 pixels, waves 0-4 take two ----
+    {
+      const int lane0 = opaque(lane);
+      f32x16 acc0[2];  // (waves 5-7 use the first only)
+      if (wave < 5) conv0_mfma<2>(smem, wave, lane0, acc0);
+      else conv0_mfma<1>(smem, wave, lane0, acc0);
+      f32x4 bias0[4];  // conv0's bias for this lane's 16 accumulator rows (channels 8 q + 4 (lane >> 5) + j)
 #pragma unroll
-      for (int mt = 0; mt < 5; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) red[(nt * 21 + 4 * mt + j) * 64 + lane] = acc[mt][j];
-      red[(nt * 21 + 20) * 64 + lane] = accx;
+      for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (lane0 >> 5));
+      lds_barrier();  // every wave has read the frame: the y0 planes may overwrite it
+      if (wave < 5) conv0_store<2>(smem, wave, lane0, acc0, bias0);
+      else conv0_store<1>(smem, wave, lane0, acc0, bias0);
     }
-    __syncthreads();
-    if (kh2 == 0) {  // C/D layout: column (output channel) = lane & 15, row (pixel) = 4 (lane >> 4) + j
+    lds_barrier();  // y0 complete
+    DX_CS_MARK(2)
+
+    u32x4 w2[9][3];  // conv2's weight fragments: steps 9 kh2 + s
+    {  // ---- conv1 ----
+      const int lane1 = opaque(lane), n16 = lane1 & 15, kq = lane1 >> 4;
+      int pb[6];
 #pragma unroll
-      for (int mt = 0; mt < 5; ++mt)
+      for (int mt = 0; mt < 6; ++mt) {
+        const int p = min(16 * mt + n16, kP1 - 1), oy = p / 9, ox = p - 9 * oy;
+        pb[mt] = oY0 + (2 * oy * 20 + 2 * ox) * kY0P + 16 * kq;
+      }
+      // the first of conv2's fragments now, the others once conv1 has freed registers
+      const unsigned o2 = static_cast<unsigned>(opaque(static_cast<int>(off2)));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float v = (acc[mt][j] + red[(nt * 21 + 4 * mt + j) * 64 + lane]) + bias1;
-          y1[(16 * mt + 4 * kq + j) * kY1P + oc] = v > 0.f ? v : 0.f;
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w2[s][pl] = load16(a.Wb2 + pl * (64 * 576) + 32 * s, o2);
+      f32x4 acc[6] = {zero4, zero4, zero4, zero4, zero4, zero4};
+      if (kh2 == 0) conv_half<1, 0, 6, 8>(smem, pb, w1, acc);
+      else conv_half<1, 1, 6, 8>(smem, pb, w1, acc);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 2; s < 9; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w2[s][pl] = load16(a.Wb2 + pl * (64 * 576) + 32 * s, o2);
+      DX_CS_MARK(3)
+      lds_barrier();  // every wave has read y0: the exchange scratch and the y1 planes may overwrite it
+      // the K halves swap: half 0 finishes tiles 0-2, half 1 tiles 3-5; each hands the other's three over
+      if (kh2 == 0) give_tiles<3, 3>(red, wave, lane, acc);
+      else give_tiles<0, 3>(red, wave, lane, acc);
+      const int oc0 = 16 * nt + 4 * kq;  // the four channels of this lane's D rows
+      const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);
+      lds_barrier();
+      const int partner = wave ^ 4;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {  // C/D layout: column (pixel) = lane & 15, rows (channels) 4 (lane >> 4) + j
+        const int p = 16 * ((kh2 == 0 ? 0 : 3) + m) + n16;
+        const f32x4 v = kh2 == 0 ? finish_tile<0>(red, partner, lane, acc, m, bias1) : finish_tile<3>(red, partner, lane, acc, m, bias1);
+        if (p < kP1) store_planes4(smem, oY1 + p * kY1P + oc0 * 2, kY1Plane, v);
+      }
+      lds_barrier();
+      DX_CS_MARK(4)
+    }
+    if (a.env && t + 1 <= a.T) {
+      // The synthetic env's NEXT frame of this env (synth_atari_block's hash of (seed, counter, position): the
+      // measurement env ignores the action, so the frame does not wait for this step's sample): into the
+      // rollout buffer and straight into the LDS slot the next step's conv0 reads (free since y0 is dead).
+      // Vector-ALU work placed where the other waves' conv2 keeps the matrix pipe busy.
+      const uint64_t key = synth_mix64(a.env_seed * 0x9E3779B97F4A7C15ull + (a.env_counter + t));
+      uint8_t *dst = a.obs + (t + 1) * step_bytes + static_cast<long long>(e) * kFrameB;
+      for (int v = opaque(tid); v < kFrameB / 16; v += 512) {
+        const uint64_t p = static_cast<uint64_t>(a.env0 + e) * (kFrameB / 16) + v;
+        const uint64_t x = synth_mix64(key + 2 * p * 0x9E3779B97F4A7C15ull);
+        const uint64_t y = synth_mix64(key + (2 * p + 1) * 0x9E3779B97F4A7C15ull);
+        const u32x4 vec = {static_cast<uint32_t>(x), static_cast<uint32_t>(x >> 32), static_cast<uint32_t>(y), static_cast<uint32_t>(y >> 32)};
+        *reinterpret_cast<u32x4 *>(dst + 16 * v) = vec;
+        *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * v) = vec;
+      }
+      if (tid == 0) {
+        const uint64_t r = synth_mix64(~key + static_cast<uint64_t>(a.env0 + e) * 0xD1B54A32D192ED03ull);
+        const float u0 = static_cast<float>(r & 0xffffff) * (1.0f / 16777216.0f);
+        const float u1 = static_cast<float>((r >> 24) & 0xffffff) * (1.0f / 16777216.0f);
+        const long long row = static_cast<long long>(t) * a.row_stride + e;
+        if (a.rewards) a.rewards[row] = u0 < a.p_reward ? ((r >> 63) ? -1.f : 1.f) : 0.f;
+        if (a.resets) a.resets[row] = u1 < a.p_reset ? 1 : 0;
+      }
+    }
+    {  // ---- conv2 ----
+      const int lane2 = opaque(lane), n16 = lane2 & 15, kq = lane2 >> 4;
+      int pb[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int p = min(16 * mt + n16, kP2 - 1), oy = p / 7, ox = p - 7 * oy;
+        pb[mt] = oY1 + (oy * 9 + ox) * kY1P + 16 * kq;
+      }
+      f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+      if (kh2 == 0) conv_half<2, 0, 4, 9>(smem, pb, w2, acc);
+      else conv_half<2, 1, 4, 9>(smem, pb, w2, acc);
+      DX_CS_MARK(5)
+      __builtin_amdgcn_sched_barrier(0);  // (conv2's fragments are dead from here: room for the tail's weights)
+      // the tail's weights for this lane's two pixels x four channels: rows of Wc beyond A + 1 are zero
+      const int p_keep0 = 16 * (kh2 == 0 ? 0 : 2) + n16;
+      const int oc0 = 16 * nt + 4 * kq;
+      const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
+      f32x4 wc[8][2];
+      if (a.Wc) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const unsigned ow = static_cast<unsigned>((min(p_keep0 + 16 * m, kP2 - 1) * 64 + oc0) * 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wc[j][m] = __builtin_bit_cast(f32x4, load16(a.Wc + j * (kP2 * 64), ow));
         }
-      float x = accx + red[(nt * 21 + 20) * 64 + lane];  // this lane's k groups of pixel 80; the four groups meet below
-      x += __shfl_xor(x, 16);
-      x += __shfl_xor(x, 32);
-      x += bias1;
-      if (kq == 0) y1[80 * kY1P + oc] = x > 0.f ? x : 0.f;
-    }
-    __syncthreads();
-    DX_CS_MARK(4)
-  }
-  {  // ---- conv2 ----
-    int pb[3];
+      }
+      // (the exchange scratch lies behind the y1 planes: no wave is still reading what it overwrites)
+      if (kh2 == 0) give_tiles<2, 2>(red, wave, lane, acc);
+      else give_tiles<0, 2>(red, wave, lane, acc);
+      lds_barrier();
+      const int partner = wave ^ 4;
+      f32x4 v2[2];
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) {
-      const int p = 16 * mt + n16, oy = p / 7, ox = p - 7 * oy;
-      pb[mt] = ((oy * 9 + ox) * kY1P + 4 * kq) * 4;
-    }
-    const int pbx = ((6 * 9 + 6) * kY1P + 4 * kq) * 4;  // output pixel (6, 6)
-    f32x4 acc[3] = {zero4, zero4, zero4};
-    float accx = 0.f;
-    if (kh2 == 0) conv2_half<0>(smem, pb, pbx, b2, acc, accx);
-    else conv2_half<1>(smem, pb, pbx, b2, acc, accx);
-    DX_CS_MARK(5)
-    if (kh2 == 1) {
+      for (int m = 0; m < 2; ++m)
+        v2[m] = kh2 == 0 ? finish_tile<0>(red, partner, lane, acc, m, bias2) : finish_tile<2>(red, partner, lane, acc, m, bias2);
+      if (a.y2) {
+        float *out = a.y2 + static_cast<long long>(e) * (kP2 * 64);
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt)
+        for (int m = 0; m < 2; ++m)
+          if (p_keep0 + 16 * m < kP2) *reinterpret_cast<f32x4 *>(out + (p_keep0 + 16 * m) * 64 + oc0) = v2[m];
+      }
+      if (a.Wc) {
+        // ---- the policy's tail: out[j] = sum over (pixel, channel) of y2 Wc[j] + beff[j]; lane sums, wave sums
+        // (DPP), the eight waves' sums meet in LDS in wave order, wave 0 samples (heads.hip: tail_act_block) ----
+        float mine = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[(nt * 21 + 4 * mt + j) * 64 + lane] = acc[mt][j];
-      red[(nt * 21 + 20) * 64 + lane] = accx;
-    }
-    __syncthreads();
-    if (kh2 == 0) {
-      float *out = a.y2 + static_cast<long long>(blockIdx.x) * (kP2 * 64);
+        for (int j = 0; j < 8; ++j) {
+          float part = 0.f;
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float v = (acc[mt][j] + red[(nt * 21 + 4 * mt + j) * 64 + lane]) + bias2;
-          out[(16 * mt + 4 * kq + j) * 64 + oc] = v > 0.f ? v : 0.f;
+          for (int m = 0; m < 2; ++m) {
+            const bool ok = p_keep0 + 16 * m < kP2;
+            float d = v2[m][0] * wc[j][m][0];
+            d = __builtin_fmaf(v2[m][1], wc[j][m][1], d);
+            d = __builtin_fmaf(v2[m][2], wc[j][m][2], d);
+            d = __builtin_fmaf(v2[m][3], wc[j][m][3], d);
+            part += ok ? d : 0.f;
+          }
+          const float tot = wave_sum_all(part);
+          mine = lane == j ? tot : mine;
         }
-      float x = accx + red[(nt * 21 + 20) * 64 + lane];
-      x += __shfl_xor(x, 16);
-      x += __shfl_xor(x, 32);
-      x += bias2;
-      if (kq == 0) out[48 * 64 + oc] = x > 0.f ? x : 0.f;
+        const int lane3 = opaque(lane);
+        if (lane3 < 8) tailred[wave * 8 + lane3] = mine;
+        lds_barrier();
+        if (wave == 0) {
+          const int A = a.A, col = lane3 & 31;
+          float x = 0.f;
+          if (lane3 < 8) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) x += tailred[w * 8 + lane3];
+            x += a.beff[lane3];
+          }
+          float mx = -INFINITY;
+          for (int k = 0; k < A; ++k) mx = fmaxf(mx, lane_value(x, k));
+          const bool is_logit = col < A;
+          const float ex = is_logit ? expf(x - mx) : 0.f;
+          float accs = 0.f, cdf = 0.f;
+          for (int k = 0; k < A; ++k) {  // sequential float32 running sum in column order
+            accs += lane_value(ex, k);
+            if (k == col) cdf = accs;
+          }
+          const float u = a.uniforms ? a.uniforms[e] : uniform01(a.seed, a.counter + t, a.env0 + e);
+          const float thresh = u * accs;
+          const unsigned long long below = __ballot(is_logit && cdf <= thresh);
+          int act = __popcll(below & 0xffffffffull);
+          if (act > A - 1) act = A - 1;
+          const float lse = mx + logf(accs);
+          const float la = lane_value(x, act) - lse;
+          const float val = lane_value(x, A);
+          if (lane3 == 0) {
+            const long long row = static_cast<long long>(t) * a.row_stride + e;
+            a.actions[row] = act;
+            a.log_prob[row] = la;
+            a.values[row] = val;
+          }
+        }
+      }
     }
+    DX_CS_MARK(6)
   }
-  DX_CS_MARK(6)
 #undef DX_CS_MARK
   if (kDiag && a.stamps && tid == 0) {
     tk[7] = __builtin_amdgcn_s_memrealtime();
@@ -307,13 +507,22 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
 
 bool convstack_supported(int in_h, int in_w, int in_c) { return in_h == kIn && in_w == kIn && in_c == 4; }
 
-// obs (B, 84, 84, 4) uint8 -> y2 (B, 7, 7, 64) in ONE launch (rollout only: y0 / y1 are not kept)
-int launch_convstack_image(const uint8_t *obs, const uint16_t *Wb0, const float *bias0, const float *W1,
-                           const float *bias1, const float *W2, const float *bias2, float *y2, int B,
-                           hipStream_t stream) {
-  DX_REQUIRE(obs && Wb0 && bias0 && W1 && bias1 && W2 && bias2 && y2 && B >= 1, "convstack: bad arguments");
-  DX_REQUIRE(aligned(obs, 16) && aligned(Wb0, 16) && aligned(W1, 16) && aligned(W2, 16),
-             "convstack: frames and packed weights must be 16-byte aligned");
+// One launch of the conv-stack kernel (igemm.hpp: ConvStackArgs): y2 only, a whole act step (policy tail and
+// sampling in the kernel), or T steps against the synthetic device env.
+int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
+  ConvStackArgs a = args;
+  DX_REQUIRE(a.obs && a.Wb0 && a.bias0 && a.Wb1 && a.bias1 && a.Wb2 && a.bias2 && a.B >= 1 && a.T >= 1, "convstack: bad arguments");
+  DX_REQUIRE(aligned(a.obs, 16) && aligned(a.Wb0, 16) && aligned(a.Wb1, 16) && aligned(a.Wb2, 16) && aligned(a.bias0, 16) &&
+                 aligned(a.bias1, 16) && aligned(a.bias2, 16) && (a.y2 == nullptr || aligned(a.y2, 16)) &&
+                 (a.Wc == nullptr || aligned(a.Wc, 16)),
+             "convstack: frames, weight planes, biases, Wc and y2 must be 16-byte aligned");
+  DX_REQUIRE(a.y2 != nullptr || a.Wc != nullptr, "convstack: neither y2 nor the tail requested");
+  DX_REQUIRE(a.Wc == nullptr || (a.beff && a.actions && a.log_prob && a.values && a.A >= 1 && a.A + 1 <= 8),
+             "convstack: the in-kernel tail needs beff, the three outputs and <= 7 actions");
+  DX_REQUIRE(a.env == 0 ? a.T == 1 : (a.Wc != nullptr && a.row_stride >= a.B && a.uniforms == nullptr),
+             "convstack: T > 1 only against the synthetic env, with the tail in the kernel");
+  if (a.row_stride < a.B) a.row_stride = a.B;
+  a.stamps = nullptr;
   static int configured_device = -1;
   int dev = 0;
   DX_HIP(hipGetDevice(&dev));
@@ -322,24 +531,24 @@ int launch_convstack_image(const uint8_t *obs, const uint16_t *Wb0, const float 
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     configured_device = dev;
   }
-  ConvStackArgs a{obs, Wb0, bias0, W1, bias1, W2, bias2, y2, B, nullptr};
+  const int B = a.B;
 #if DX_DIAG
-  if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles (wave 0 of every workgroup), summarised on stderr (synchronous)
-    unsigned long long *dev = nullptr;
-    DX_HIP(hipMalloc(&dev, static_cast<size_t>(B) * 64));
-    a.stamps = dev;
+  if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of step 0 (wave 0 of every workgroup), summarised on stderr (synchronous)
+    unsigned long long *dev_stamps = nullptr;
+    DX_HIP(hipMalloc(&dev_stamps, static_cast<size_t>(B) * 64));
+    a.stamps = dev_stamps;
     hipLaunchKernelGGL(convstack_image_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
     DX_LAUNCH_CHECK();
     DX_HIP(hipStreamSynchronize(stream));
     std::vector<unsigned long long> h(static_cast<size_t>(B) * 8);
-    DX_HIP(hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost));
-    DX_HIP(hipFree(dev));
+    DX_HIP(hipMemcpy(h.data(), dev_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    DX_HIP(hipFree(dev_stamps));
     double ph[6] = {0, 0, 0, 0, 0, 0};
     for (int b = 0; b < B; ++b)
       for (int i = 0; i < 6; ++i) ph[i] += static_cast<double>(h[b * 8 + i + 1] - h[b * 8 + i]) / B;
-    fprintf(stderr, "[convstack B=%d] cycles per workgroup (wave 0): loads + LDS fill %.0f, conv0 %.0f, conv1 loop %.0f, "
-            "conv1 reduce + y1 %.0f, conv2 loop %.0f, conv2 reduce + store %.0f, total %.0f\n", B, ph[0], ph[1], ph[2], ph[3],
-            ph[4], ph[5], ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]);
+    fprintf(stderr, "[convstack B=%d T=%d] cycles of step 0 per workgroup (wave 0): loads + LDS fill %.0f, conv0 %.0f, conv1 loop "
+            "%.0f, conv1 exchange + y1 %.0f, next frame + conv2 loop %.0f, conv2 exchange + tail %.0f, total %.0f\n", B, a.T,
+            ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]);
     return DX_OK;
   }
 #endif

@@ -10,6 +10,7 @@
 //             (derl/alg/ppo.py:45-64,82-98,104; derl/alg/a2c.py:32-33,57,74; closed forms
 //             in SURVEY.md Appendix A.1-A.5)
 // Diagonal-Gaussian head for the MLP policy: thread per row (derl/policies.py:40-42,66).
+#include "heads_dev.hpp"
 #include "synth_dev.hpp"
 
 namespace {
@@ -25,16 +26,6 @@ __device__ __forceinline__ float half_sum(float v) {
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
-}
-
-// counter-based uniform in [0,1): 2 rounds of a 64-bit mix (splitmix64 finaliser) of
-// (seed, counter, row); 24 random bits -> exactly representable float
-__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t counter, uint64_t row) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter * 0x100000001B3ull + row + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return static_cast<float>(z >> 40) * (1.0f / 16777216.0f);
 }
 
 struct Softmax {
@@ -91,27 +82,6 @@ __global__ __launch_bounds__(256) void categorical_act_kernel(
 // head dot products (policy logits, value) and samples.  Replaces two GEMM launches (reduce +
 // heads) and the act launch of the rollout step.  Cross-lane sums use DPP row operations and
 // v_readlane (uniform lane indices), not LDS permutes: the kernel is a dependent chain.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
-  return v + __builtin_bit_cast(float, moved);  // rows masked off receive 0
-}
-
-// sum over the 64 lanes, returned in every lane (gfx9 wave64 DPP reduction + readlane 63)
-__device__ __forceinline__ float wave_sum_all(float v) {
-  v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
-  v = dpp_add<0x140, 0xf>(v);   // row_mirror: every lane holds its row's (16 lanes) total
-  v = dpp_add<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
-  v = dpp_add<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3: lane 63 holds the total
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-__device__ __forceinline__ float lane_value(float v, int lane_uniform) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_uniform));
-}
-
 struct HeadsActArgs {
   const float *hid_slabs;
   int nslab;

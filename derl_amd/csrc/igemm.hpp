@@ -206,11 +206,38 @@ int launch_conv0_fwd_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t str
 int launch_conv0_wgrad_b16(const Conv0Args &a, int nblocks, hipStream_t stream);
 // rollout-sized batches: 32x32 tile per workgroup, pre-split weight planes Wb [3][32][256] bf16
 int launch_conv0_lat_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t stream);
-// the rollout's whole conv stack, one workgroup per 84 x 84 x 4 uint8 frame (convstack.hip): y0 / y1 stay in LDS
+// the rollout's whole conv stack -- optionally the whole act step, or T steps against the synthetic device
+// env -- in ONE launch, one workgroup per 84 x 84 x 4 uint8 frame (convstack.hip): y0 / y1 stay in LDS
+struct ConvStackArgs {
+  uint8_t *obs;          // frames of this launch's envs at step 0: (B, 84, 84, 4) uint8; with `env` the whole rollout
+                         // buffer (T + 1, row_stride envs, 84, 84, 4) from this launch's first env on: steps 1 .. T are WRITTEN
+  const uint16_t *Wb0;   // conv0 weights, three bf16 planes [3][32][256] (k = (kh, kw, c))
+  const float *bias0;
+  const uint16_t *Wb1;   // conv1 weights, planes [3][64][512] (k = (kh, kw, ic))
+  const float *bias1;
+  const uint16_t *Wb2;   // conv2 weights, planes [3][64][576]
+  const float *bias2;
+  float *y2;             // (B, 7, 7, 64) NHWC, or NULL when the tail runs in here
+  int B;
+  // ---- the policy's tail in the same kernel (NULL Wc: the caller runs its own): out = y2 Wc^T + beff, sampling ----
+  const float *Wc, *beff;  // [8][3136] (rows 0 .. A - 1 policy, row A value, the rest ZERO), [8]
+  int A;
+  const float *uniforms;   // optional (B): the uniforms to sample with (T = 1)
+  uint64_t seed, counter;  // else uniform01(seed, counter + t, env0 + e)
+  int env0;                // position of env 0 of this launch in the whole batch
+  int64_t *actions;        // (T, row_stride): rows of this launch's envs
+  float *log_prob, *values;
+  // ---- T steps against the synthetic device env (synth_dev.hpp) in ONE launch: every env's chain
+  // frame -> policy -> sample -> next frame is local to its workgroup ----
+  int env, T, row_stride;
+  float *rewards;
+  uint8_t *resets;
+  uint64_t env_seed, env_counter;
+  float p_reward, p_reset;
+  unsigned long long *stamps;  // DX_DIAG only (DX_CS_DIAG=1): [B][8] shader-clock stamps of wave 0 (step 0), else NULL
+};
 bool convstack_supported(int in_h, int in_w, int in_c);
-int launch_convstack_image(const uint8_t *obs, const uint16_t *Wb0, const float *bias0, const float *W1,
-                           const float *bias1, const float *W2, const float *bias2, float *y2, int B,
-                           hipStream_t stream);
+int launch_convstack(const ConvStackArgs &args, hipStream_t stream);
 // the rollout's linear layer, weight-stationary split-K (fc_rollout.hip): slabs [parts][M][512], bias on slab 0
 int fc_rollout_parts();
 bool fc_rollout_supported(int M, int N, int K);
