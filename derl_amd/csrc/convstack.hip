@@ -22,8 +22,8 @@
 //     matrix time than v_mfma_f32_16x16x4_f32 (the first version of this kernel: 30 us per launch,
 //     its conv1 + conv2 loops AT the fp32 matrix rate; stamps in the diag flavour, DX_CS_DIAG).
 // Operands: the activations are read by the matrix instructions straight from the LDS planes (a lane's
-// address is its pixel's base + a compile-time tap offset: one ds_read_b128 per plane, pixel pitches of
-// 80 / 144 bytes keep the 16-lane read groups on distinct banks); the weights of conv1 / conv2 never
+// address is its pixel's base + a compile-time tap offset: one ds_read_b128 per plane, pixel and row
+// pitches keep the 16-lane read groups on distinct banks); the weights of conv1 / conv2 never
 // touch LDS: wave (16-channel tile, K half) is the ONLY reader of its slice of the three planes and
 // loads it straight into the A-fragment layout (lane (channel, k group) = 8 consecutive k of one row),
 // all loads of a layer issued while the previous layer computes (L2-resident: every workgroup reads
@@ -51,14 +51,19 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int kTerms = 6;  // products per fp32 x fp32 (6: everything above 2^-23 of the product; 9: all)
 constexpr int kIn = 84, kFrameB = kIn * kIn * 4, kRowB = kIn * 4;  // uint8 NHWC frame, 4 stacked channels
 constexpr int kP0 = 400, kP1 = 81, kP2 = 49;                       // output pixels of the three layers
-constexpr int kY0P = 80, kY0Plane = kP0 * kY0P;                    // bytes per y0 pixel / plane in LDS (32 bf16 + pad)
-constexpr int kY1P = 144, kY1Plane = kP1 * kY1P;                   // bytes per y1 pixel / plane (64 bf16 + pad)
+// LDS images of the activations: pixel pitch and ROW pitch chosen (exhaustive search over paddings) so that
+// every ds_read_b128 of a B fragment -- 16 consecutive output pixels of a 9- / 7-wide image, i.e. with a
+// row wrap inside the tile, x 4 k groups -- puts its four 16-lane groups on 16 distinct 16-byte bank
+// units: unpadded rows gave 2- and 3-way conflicts on a third of the reads (conv1 1.8x, conv2 2.5x the
+// LDS cycles, and the LDS pipe is what these loops lean on)
+constexpr int kY0P = 80, kY0R = 20 * kY0P + 16, kY0Plane = 20 * kY0R;    // bytes per y0 pixel / row / plane (32 bf16 + pad)
+constexpr int kY1P = 160, kY1R = 9 * kY1P + 192, kY1Plane = 9 * kY1R;    // bytes per y1 pixel / row / plane (64 bf16 + pad)
 constexpr int kWRowB = 528, kWPlaneB = 32 * kWRowB;                // conv0 weight planes in LDS: 256 bf16 + 16 B pad
 // LDS: [conv0 weight planes][region B].  Region B holds, in turn: the frame (at its end) while conv0
 // multiplies, the three y0 planes, then the three y1 planes (at its start) + the K halves' exchange.
-constexpr int oW0 = 0, oB = oW0 + 3 * kWPlaneB, kRegionB = 3 * kY0Plane, kLdsBytes = oB + kRegionB;
+constexpr int oW0 = 0, oB = oW0 + 3 * kWPlaneB, kRegionB = 3 * kY0Plane, oTail = oB + kRegionB, kLdsBytes = oTail + 2 * 8 * 8 * 4;
 constexpr int oFrame = oB + kRegionB - kFrameB, oY0 = oB, oY1 = oB, oRed = oB + 3 * kY1Plane;
-constexpr int kRedBytes = 8 * 12 * 64 * 4;  // every wave hands 12 accumulator registers to its partner
+constexpr int kRedBytes = 8 * 3 * 64 * 16;  // every wave hands up to three accumulator tiles (16 bytes per lane each) to its partner
 static_assert(oB % 16 == 0 && oFrame % 16 == 0 && oRed % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS layout");
 static_assert(oRed + kRedBytes <= kLdsBytes, "exchange scratch inside region B");
 
@@ -144,6 +149,7 @@ __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int l
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) wfn[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB + 32 * (c + 1));
     }
+    __builtin_amdgcn_sched_barrier(0);  // (the reads above stay ahead of this chunk's MFMAs)
     bf16x8 pf[NT_];
 #pragma unroll
     for (int t = 0; t < NT_; ++t) pf[t] = cs_expand8(px[t]);
@@ -151,6 +157,7 @@ __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int l
     for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
       for (int t = 0; t < NT_; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[pl]), pf[t], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < 16) {
 #pragma unroll
       for (int t = 0; t < NT_; ++t) px[t] = pxn[t];
@@ -178,63 +185,74 @@ __device__ __forceinline__ void conv0_store(uint8_t *smem, int tile0, int lane, 
         const float x = cs_div255(acc[t][4 * q + j]) + bias[q][j];
         v[j] = x > 0.f ? x : 0.f;
       }
-      store_planes4(smem, oY0 + p * kY0P + (8 * q + 4 * kg) * 2, kY0Plane, v);
+      store_planes4(smem, oY0 + (p / 20) * kY0R + (p % 20) * kY0P + (8 * q + 4 * kg) * 2, kY0Plane, v);
     }
   }
 }
 
 // the products of one 16x16 tile and one K step: weight fragment planes w (hi, mid, lo) x activation
-// fragment planes x, smallest terms first
-__device__ __forceinline__ f32x4 mac_terms(f32x4 acc, const u32x4 (&w)[3], const u32x4 (&x)[3]) {
+// fragment planes x, smallest terms first -- in two parts, so that the next tile's LDS reads can be pinned
+// between the first product and the rest (left alone, hipcc sinks every read to just before its use and
+// waits for it at once: 3 exposed LDS round trips per 6 MFMAs, the first build's conv1 at 38 % of the pipe)
 #define DX_CS_T(a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w[a]), as_bf16x8(x[b]), acc, 0, 0, 0);
-  if (kTerms == 9) { DX_CS_T(2, 2) DX_CS_T(2, 1) DX_CS_T(1, 2) }
-  DX_CS_T(2, 0) DX_CS_T(0, 2) DX_CS_T(1, 1) DX_CS_T(1, 0) DX_CS_T(0, 1) DX_CS_T(0, 0)
-#undef DX_CS_T
+__device__ __forceinline__ f32x4 mac_first(f32x4 acc, const u32x4 (&w)[3], const u32x4 (&x)[3]) {
+  if (kTerms == 9) { DX_CS_T(2, 2) } else { DX_CS_T(2, 0) }
   return acc;
 }
+__device__ __forceinline__ f32x4 mac_rest(f32x4 acc, const u32x4 (&w)[3], const u32x4 (&x)[3]) {
+  if (kTerms == 9) { DX_CS_T(2, 1) DX_CS_T(1, 2) DX_CS_T(2, 0) }
+  DX_CS_T(0, 2) DX_CS_T(1, 1) DX_CS_T(1, 0) DX_CS_T(0, 1) DX_CS_T(0, 0)
+  return acc;
+}
+#undef DX_CS_T
 
 // One K half of conv1 (KH: taps 8 KH .. 8 KH + 7) or conv2 (KH: steps 9 KH .. 9 KH + 8 of 18) for this wave's
 // 16 channels: NT pixel tiles, activations from the LDS planes (pb = byte address of the lane's pixel
 // and k group in plane 0), the next tile's fragments read before this tile's MFMAs.
+template <int LAYER, int KH, int S>
+__device__ __forceinline__ constexpr int step_offset() {
+  if (LAYER == 1) return ((8 * KH + S) >> 2) * kY0R + (S & 3) * kY0P;  // tap (kh, kw) = ((8 KH + s) / 4, s % 4): 32 input channels = one K step
+  return (((9 * KH + S) >> 1) / 3) * kY1R + (((9 * KH + S) >> 1) % 3) * kY1P + ((9 * KH + S) & 1) * 64;  // step g = 9 KH + s: tap g / 2, channels 32 (g % 2) ..
+}
+
+// the activation fragments (three planes) of tile pair PR at K step S
+template <int LAYER, int KH, int S, int PR, int NT>
+__device__ __forceinline__ void load_pair(const uint8_t *smem, const int (&pb)[NT], u32x4 (&x)[2][3]) {
+  constexpr int plane = LAYER == 1 ? kY0Plane : kY1Plane;
+  constexpr int off = step_offset<LAYER, KH, S>();
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) x[h][pl] = *reinterpret_cast<const u32x4 *>(smem + pb[2 * PR + h] + off + pl * plane);
+}
+
+template <int LAYER, int KH, int NT, int NS, int S, int PR>
+__device__ __forceinline__ void conv_half_from(const uint8_t *smem, const int (&pb)[NT], const u32x4 (&w)[NS][3], f32x4 (&acc)[NT],
+                                               u32x4 (&x)[2][3]) {
+  constexpr bool last = S == NS - 1 && PR == NT / 2 - 1;
+  constexpr int SN = PR + 1 < NT / 2 ? S : S + 1, PN = PR + 1 < NT / 2 ? PR + 1 : 0;
+  u32x4 xn[2][3];
+  acc[2 * PR] = mac_first(acc[2 * PR], w[S], x[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  // the NEXT pair's six fragment reads travel under this pair's eleven remaining MFMAs (one tile ahead left a
+  // wave waiting for LDS after every five: 40 cycles per MFMA where the pipe needs 16, and the older wave of a
+  // SIMD kept the pipe from the younger -- the halves of conv1 finished 7,000 cycles apart)
+  if constexpr (!last) load_pair<LAYER, KH, SN, PN, NT>(smem, pb, xn);
+  __builtin_amdgcn_sched_barrier(0);
+  acc[2 * PR] = mac_rest(acc[2 * PR], w[S], x[0]);
+  acc[2 * PR + 1] = mac_rest(mac_first(acc[2 * PR + 1], w[S], x[1]), w[S], x[1]);
+  if constexpr (!last) conv_half_from<LAYER, KH, NT, NS, SN, PN>(smem, pb, w, acc, xn);
+}
+
+// One K half of conv1 (KH: taps 8 KH .. 8 KH + 7) or conv2 (KH: steps 9 KH .. 9 KH + 8 of 18) for this wave's
+// 16 channels: NT pixel tiles two at a time, activations from the LDS planes (pb = byte address of the
+// lane's pixel and k group in plane 0).
 template <int LAYER, int KH, int NT, int NS>
 __device__ __forceinline__ void conv_half(const uint8_t *smem, const int (&pb)[NT], const u32x4 (&w)[NS][3], f32x4 (&acc)[NT]) {
-  constexpr int plane = LAYER == 1 ? kY0Plane : kY1Plane;
-  u32x4 x[3], xn[3];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    int off;
-    if (LAYER == 1) {  // tap (kh, kw) = ((8 KH + s) / 4, s % 4): 32 input channels = one K step
-      off = (((8 * KH + s) >> 2) * 20 + (s & 3)) * kY0P;
-    } else {           // step g = 9 KH + s: tap g / 2, input channels 32 (g % 2) ..
-      const int g = 9 * KH + s, tap = g >> 1;
-      off = ((tap / 3) * 9 + tap % 3) * kY1P + (g & 1) * 64;
-    }
-    if (s == 0) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) x[pl] = *reinterpret_cast<const u32x4 *>(smem + pb[0] + off + pl * plane);
-    }
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) {
-      // the fragments of the next tile (or of the next step's first tile) travel while this tile multiplies
-      if (mt + 1 < NT) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) xn[pl] = *reinterpret_cast<const u32x4 *>(smem + pb[mt + 1] + off + pl * plane);
-      } else if (s + 1 < NS) {
-        int offn;
-        if (LAYER == 1) {
-          offn = (((8 * KH + s + 1) >> 2) * 20 + ((s + 1) & 3)) * kY0P;
-        } else {
-          const int g = 9 * KH + s + 1, tap = g >> 1;
-          offn = ((tap / 3) * 9 + tap % 3) * kY1P + (g & 1) * 64;
-        }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) xn[pl] = *reinterpret_cast<const u32x4 *>(smem + pb[0] + offn + pl * plane);
-      }
-      acc[mt] = mac_terms(acc[mt], w[s], x);
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) x[pl] = xn[pl];
-    }
-  }
+  static_assert(NT % 2 == 0, "tiles go in pairs");
+  u32x4 x[2][3];
+  load_pair<LAYER, KH, 0, 0, NT>(smem, pb, x);
+  conv_half_from<LAYER, KH, NT, NS, 0, 0>(smem, pb, w, acc, x);
 }
 
 // the K halves' exchange: tiles FROM .. FROM + N - 1 of this wave's accumulators go to its partner
@@ -242,23 +260,58 @@ __device__ __forceinline__ void conv_half(const uint8_t *smem, const int (&pb)[N
 template <int FROM, int N, int NT>
 __device__ __forceinline__ void give_tiles(float *red, int wave, int lane, const f32x4 (&acc)[NT]) {
 #pragma unroll
-  for (int m = 0; m < N; ++m)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) red[(wave * 12 + 4 * m + j) * 64 + lane] = acc[FROM + m][j];
+  for (int m = 0; m < N; ++m) reinterpret_cast<f32x4 *>(red)[(wave * 3 + m) * 64 + lane] = acc[FROM + m];  // 16 bytes per lane
 }
 // tile KEEP + m of this wave + what its partner handed over + bias, ReLU
 template <int KEEP, int NT>
 __device__ __forceinline__ f32x4 finish_tile(const float *red, int partner, int lane, const f32x4 (&acc)[NT], int m, f32x4 bias) {
+  const f32x4 theirs = reinterpret_cast<const f32x4 *>(red)[(partner * 3 + m) * 64 + lane];
   f32x4 v;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float mine = 0.f;
 #pragma unroll
     for (int t = 0; t < NT - KEEP; ++t) mine = t == m ? acc[KEEP + t][j] : mine;  // m is a constant after unrolling
-    const float x = (mine + red[(partner * 12 + 4 * m + j) * 64 + lane]) + bias[j];
+    const float x = (mine + theirs[j]) + bias[j];
     v[j] = x > 0.f ? x : 0.f;
   }
   return v;
+}
+
+// The sample of step t from the eight waves' partial outputs (one wave; heads.hip: tail_act_block's rule):
+// out[j] = the waves' sums in wave order + beff[j]; softmax over the A logits, inverse-CDF draw, log-prob, value.
+__device__ __forceinline__ void sample_step(const ConvStackArgs &a, const float *tailred, int t, int e, int lane) {
+  const int A = a.A, col = lane & 31;
+  const float *part = tailred + (t & 1) * 64;
+  float x = 0.f;
+  if (lane < 8) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) x += part[w * 8 + lane];
+    x += a.beff[lane];
+  }
+  float mx = -INFINITY;
+  for (int k = 0; k < A; ++k) mx = fmaxf(mx, lane_value(x, k));
+  const bool is_logit = col < A;
+  const float ex = is_logit ? expf(x - mx) : 0.f;
+  float accs = 0.f, cdf = 0.f;
+  for (int k = 0; k < A; ++k) {  // sequential float32 running sum in column order
+    accs += lane_value(ex, k);
+    if (k == col) cdf = accs;
+  }
+  const float u = a.uniforms ? a.uniforms[e] : uniform01(a.seed, a.counter + t, a.env0 + e);
+  const float thresh = u * accs;
+  const unsigned long long below = __ballot(is_logit && cdf <= thresh);
+  int act = __popcll(below & 0xffffffffull);
+  if (act > A - 1) act = A - 1;
+  const float lse = mx + logf(accs);
+  const float la = lane_value(x, act) - lse;
+  const float val = lane_value(x, A);
+  if (lane == 0) {
+    const long long row = static_cast<long long>(t) * a.row_stride + e;
+    a.actions[row] = act;
+    a.log_prob[row] = la;
+    a.values[row] = val;
+  }
 }
 
 __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArgs a) {
@@ -268,8 +321,9 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   const int n16 = lane & 15, kq = lane >> 4;
   const int e = blockIdx.x;
   const long long step_bytes = static_cast<long long>(a.row_stride) * kFrameB;  // frames of one step of the whole batch
-  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DX_CS_MARK(i) if (kDiag && a.stamps && t == 0) tk[i] = __builtin_amdgcn_s_memtime();
+  const int stamp_wave = kDiag ? a.env0 >> 24 : 0;  // (diag: DX_CS_DIAG=<wave> picks the stamping wave)
   int t = 0;
   DX_CS_MARK(0)
 
@@ -297,7 +351,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   float *red = reinterpret_cast<float *>(smem + oRed);
-  float *tailred = reinterpret_cast<float *>(smem + oRed + kRedBytes);  // [8 waves][8 outputs]
+  float *tailred = reinterpret_cast<float *>(smem + oTail);  // [step parity][8 waves][8 outputs]
   // this lane's byte offsets into a plane of the conv1 / conv2 weights: row (channel) 16 nt + n16, K half, k group kq
   const unsigned off1 = static_cast<unsigned>(((16 * nt + n16) * 512 + (8 * kh2) * 32 + 8 * kq) * 2);
   const unsigned off2 = static_cast<unsigned>(((16 * nt + n16) * 576 + (9 * kh2) * 32 + 8 * kq) * 2);
@@ -306,10 +360,10 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
     // conv1's weight fragments travel while conv0 runs: A fragment of v_mfma_f32_16x16x32_bf16 = 8 consecutive k
     // of row (channel) 16 nt + n16: plane pl, tap 8 kh2 + s, k group kq
     u32x4 w1[8][3];
-    {
+    {  // (the last two taps' fragments after conv0, whose two-tile waves need the registers)
       const unsigned o1 = static_cast<unsigned>(opaque(static_cast<int>(off1)));
 #pragma unroll
-      for (int s = 0; s < 8; ++s)
+      for (int s = 0; s < 6; ++s)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load16(a.Wb1 + pl * (64 * 512) + 32 * s, o1);
     }
@@ -322,9 +376,12 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       f32x16 acc0[2];  // (waves 5-7 use the first only)
       if (wave < 5) conv0_mfma<2>(smem, wave, lane0, acc0);
       else conv0_mfma<1>(smem, wave, lane0, acc0);
+      // wave 7 has one conv0 tile where waves 0-4 have two: the PREVIOUS step's sample fits in that slack
+      if (a.Wc && t > 0 && wave == 7) sample_step(a, tailred, t - 1, e, lane0);
       f32x4 bias0[4];  // conv0's bias for this lane's 16 accumulator rows (channels 8 q + 4 (lane >> 5) + j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (lane0 >> 5));
+      DX_CS_MARK(11)
       lds_barrier();  // every wave has read the frame: the y0 planes may overwrite it
       if (wave < 5) conv0_store<2>(smem, wave, lane0, acc0, bias0);
       else conv0_store<1>(smem, wave, lane0, acc0, bias0);
@@ -334,42 +391,48 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
 
     u32x4 w2[9][3];  // conv2's weight fragments: steps 9 kh2 + s
     {  // ---- conv1 ----
+      {
+        const unsigned o1 = static_cast<unsigned>(opaque(static_cast<int>(off1)));
+#pragma unroll
+        for (int s = 6; s < 8; ++s)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load16(a.Wb1 + pl * (64 * 512) + 32 * s, o1);
+      }
       const int lane1 = opaque(lane), n16 = lane1 & 15, kq = lane1 >> 4;
       int pb[6];
 #pragma unroll
       for (int mt = 0; mt < 6; ++mt) {
         const int p = min(16 * mt + n16, kP1 - 1), oy = p / 9, ox = p - 9 * oy;
-        pb[mt] = oY0 + (2 * oy * 20 + 2 * ox) * kY0P + 16 * kq;
+        pb[mt] = oY0 + 2 * oy * kY0R + 2 * ox * kY0P + 16 * kq;
       }
-      // the first of conv2's fragments now, the others once conv1 has freed registers
-      const unsigned o2 = static_cast<unsigned>(opaque(static_cast<int>(off2)));
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w2[s][pl] = load16(a.Wb2 + pl * (64 * 576) + 32 * s, o2);
       f32x4 acc[6] = {zero4, zero4, zero4, zero4, zero4, zero4};
       if (kh2 == 0) conv_half<1, 0, 6, 8>(smem, pb, w1, acc);
       else conv_half<1, 1, 6, 8>(smem, pb, w1, acc);
+      const int oc0 = 16 * nt + 4 * kq;  // the four channels of this lane's D rows
+      const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);  // (ahead of the 27 loads below: vmcnt returns in order)
       __builtin_amdgcn_sched_barrier(0);
+      // conv2's fragments travel under the exchange (conv1's have just freed their registers)
+      const unsigned o2 = static_cast<unsigned>(opaque(static_cast<int>(off2)));
 #pragma unroll
-      for (int s = 2; s < 9; ++s)
+      for (int s = 0; s < 9; ++s)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) w2[s][pl] = load16(a.Wb2 + pl * (64 * 576) + 32 * s, o2);
       DX_CS_MARK(3)
       lds_barrier();  // every wave has read y0: the exchange scratch and the y1 planes may overwrite it
       // the K halves swap: half 0 finishes tiles 0-2, half 1 tiles 3-5; each hands the other's three over
+      DX_CS_MARK(8)
       if (kh2 == 0) give_tiles<3, 3>(red, wave, lane, acc);
       else give_tiles<0, 3>(red, wave, lane, acc);
-      const int oc0 = 16 * nt + 4 * kq;  // the four channels of this lane's D rows
-      const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);
       lds_barrier();
+      DX_CS_MARK(9)
       const int partner = wave ^ 4;
 #pragma unroll
       for (int m = 0; m < 3; ++m) {  // C/D layout: column (pixel) = lane & 15, rows (channels) 4 (lane >> 4) + j
         const int p = 16 * ((kh2 == 0 ? 0 : 3) + m) + n16;
         const f32x4 v = kh2 == 0 ? finish_tile<0>(red, partner, lane, acc, m, bias1) : finish_tile<3>(red, partner, lane, acc, m, bias1);
-        if (p < kP1) store_planes4(smem, oY1 + p * kY1P + oc0 * 2, kY1Plane, v);
+        if (p < kP1) store_planes4(smem, oY1 + (p / 9) * kY1R + (p % 9) * kY1P + oc0 * 2, kY1Plane, v);
       }
+      DX_CS_MARK(10)
       lds_barrier();
       DX_CS_MARK(4)
     }
@@ -403,25 +466,27 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int p = min(16 * mt + n16, kP2 - 1), oy = p / 7, ox = p - 7 * oy;
-        pb[mt] = oY1 + (oy * 9 + ox) * kY1P + 16 * kq;
+        pb[mt] = oY1 + oy * kY1R + ox * kY1P + 16 * kq;
       }
       f32x4 acc[4] = {zero4, zero4, zero4, zero4};
       if (kh2 == 0) conv_half<2, 0, 4, 9>(smem, pb, w2, acc);
       else conv_half<2, 1, 4, 9>(smem, pb, w2, acc);
       DX_CS_MARK(5)
       __builtin_amdgcn_sched_barrier(0);  // (conv2's fragments are dead from here: room for the tail's weights)
-      // the tail's weights for this lane's two pixels x four channels: rows of Wc beyond A + 1 are zero
       const int p_keep0 = 16 * (kh2 == 0 ? 0 : 2) + n16;
       const int oc0 = 16 * nt + 4 * kq;
       const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
-      f32x4 wc[8][2];
+      // the tail's weights for outputs 0-3 now (under the exchange), for 4-7 after these are used
+      f32x4 wc[4][2];
+      unsigned ow[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) ow[m] = static_cast<unsigned>((min(p_keep0 + 16 * m, kP2 - 1) * 64 + oc0) * 4);
       if (a.Wc) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const unsigned ow = static_cast<unsigned>((min(p_keep0 + 16 * m, kP2 - 1) * 64 + oc0) * 4);
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) wc[j][m] = __builtin_bit_cast(f32x4, load16(a.Wc + j * (kP2 * 64), ow));
-        }
+          for (int j = 0; j < 4; ++j)
+            wc[j][m] = j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + j * (kP2 * 64), ow[m])) : zero4;
       }
       // (the exchange scratch lies behind the y1 planes: no wave is still reading what it overwrites)
       if (kh2 == 0) give_tiles<2, 2>(red, wave, lane, acc);
@@ -443,63 +508,46 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
         // (DPP), the eight waves' sums meet in LDS in wave order, wave 0 samples (heads.hip: tail_act_block) ----
         float mine = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float part = 0.f;
+        for (int half = 0; half < 2; ++half) {
+          if (half == 1) {
+            if (a.A < 4) break;  // uniform
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const bool ok = p_keep0 + 16 * m < kP2;
-            float d = v2[m][0] * wc[j][m][0];
-            d = __builtin_fmaf(v2[m][1], wc[j][m][1], d);
-            d = __builtin_fmaf(v2[m][2], wc[j][m][2], d);
-            d = __builtin_fmaf(v2[m][3], wc[j][m][3], d);
-            part += ok ? d : 0.f;
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                wc[j][m] = 4 + j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + (4 + j) * (kP2 * 64), ow[m])) : zero4;
           }
-          const float tot = wave_sum_all(part);
-          mine = lane == j ? tot : mine;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (4 * half + j > a.A) continue;  // uniform: rows beyond A + 1 are zero
+            float part = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              const bool ok = p_keep0 + 16 * m < kP2;
+              float d = v2[m][0] * wc[j][m][0];
+              d = __builtin_fmaf(v2[m][1], wc[j][m][1], d);
+              d = __builtin_fmaf(v2[m][2], wc[j][m][2], d);
+              d = __builtin_fmaf(v2[m][3], wc[j][m][3], d);
+              part += ok ? d : 0.f;
+            }
+            const float tot = wave_sum_all(part);
+            mine = lane == 4 * half + j ? tot : mine;
+          }
         }
         const int lane3 = opaque(lane);
-        if (lane3 < 8) tailred[wave * 8 + lane3] = mine;
-        lds_barrier();
-        if (wave == 0) {
-          const int A = a.A, col = lane3 & 31;
-          float x = 0.f;
-          if (lane3 < 8) {
-#pragma unroll
-            for (int w = 0; w < 8; ++w) x += tailred[w * 8 + lane3];
-            x += a.beff[lane3];
-          }
-          float mx = -INFINITY;
-          for (int k = 0; k < A; ++k) mx = fmaxf(mx, lane_value(x, k));
-          const bool is_logit = col < A;
-          const float ex = is_logit ? expf(x - mx) : 0.f;
-          float accs = 0.f, cdf = 0.f;
-          for (int k = 0; k < A; ++k) {  // sequential float32 running sum in column order
-            accs += lane_value(ex, k);
-            if (k == col) cdf = accs;
-          }
-          const float u = a.uniforms ? a.uniforms[e] : uniform01(a.seed, a.counter + t, a.env0 + e);
-          const float thresh = u * accs;
-          const unsigned long long below = __ballot(is_logit && cdf <= thresh);
-          int act = __popcll(below & 0xffffffffull);
-          if (act > A - 1) act = A - 1;
-          const float lse = mx + logf(accs);
-          const float la = lane_value(x, act) - lse;
-          const float val = lane_value(x, A);
-          if (lane3 == 0) {
-            const long long row = static_cast<long long>(t) * a.row_stride + e;
-            a.actions[row] = act;
-            a.log_prob[row] = la;
-            a.values[row] = val;
-          }
-        }
+        if (lane3 < 8) tailred[(t & 1) * 64 + wave * 8 + lane3] = mine;  // sampled by wave 7 under the next step's conv0
       }
     }
     DX_CS_MARK(6)
   }
+  if (a.Wc) {  // the last step's sample
+    lds_barrier();
+    if (wave == 7) sample_step(a, tailred, a.T - 1, e, lane);
+  }
 #undef DX_CS_MARK
-  if (kDiag && a.stamps && tid == 0) {
+  if (kDiag && a.stamps && tid == 64 * stamp_wave) {
     tk[7] = __builtin_amdgcn_s_memrealtime();
-    for (int i = 0; i < 8; ++i) a.stamps[blockIdx.x * 8 + i] = tk[i];
+    for (int i = 0; i < 12; ++i) a.stamps[blockIdx.x * 12 + i] = tk[i];
   }
 }
 
@@ -535,17 +583,26 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
 #if DX_DIAG
   if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of step 0 (wave 0 of every workgroup), summarised on stderr (synchronous)
     unsigned long long *dev_stamps = nullptr;
-    DX_HIP(hipMalloc(&dev_stamps, static_cast<size_t>(B) * 64));
+    DX_HIP(hipMalloc(&dev_stamps, static_cast<size_t>(B) * 96));
     a.stamps = dev_stamps;
+    const int stamp_wave = atoi(getenv("DX_CS_DIAG")) & 7;
+    a.env0 |= stamp_wave << 24;  // (timing build only: sampling positions are not what is looked at)
     hipLaunchKernelGGL(convstack_image_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
     DX_LAUNCH_CHECK();
     DX_HIP(hipStreamSynchronize(stream));
-    std::vector<unsigned long long> h(static_cast<size_t>(B) * 8);
+    std::vector<unsigned long long> h(static_cast<size_t>(B) * 12);
     DX_HIP(hipMemcpy(h.data(), dev_stamps, h.size() * 8, hipMemcpyDeviceToHost));
     DX_HIP(hipFree(dev_stamps));
-    double ph[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < B; ++b)
-      for (int i = 0; i < 6; ++i) ph[i] += static_cast<double>(h[b * 8 + i + 1] - h[b * 8 + i]) / B;
+    double ph[6] = {0, 0, 0, 0, 0, 0}, fine[4] = {0, 0, 0, 0};
+    for (int b = 0; b < B; ++b) {
+      for (int i = 0; i < 6; ++i) ph[i] += static_cast<double>(h[b * 12 + i + 1] - h[b * 12 + i]) / B;
+      fine[0] += static_cast<double>(h[b * 12 + 11] - h[b * 12 + 1]) / B;   // conv0: its MFMA loop (wave 0: two tiles)
+      fine[1] += static_cast<double>(h[b * 12 + 8] - h[b * 12 + 3]) / B;    // conv1: waiting for the other waves' loops
+      fine[2] += static_cast<double>(h[b * 12 + 9] - h[b * 12 + 8]) / B;    // conv1: hand-over + barrier
+      fine[3] += static_cast<double>(h[b * 12 + 10] - h[b * 12 + 9]) / B;   // conv1: finish + split + y1 stores
+    }
+    fprintf(stderr, "[convstack wave %d] conv0 MFMA loop %.0f | conv1: wait for all loops %.0f, hand-over %.0f, finish + y1 %.0f\n",
+            stamp_wave, fine[0], fine[1], fine[2], fine[3]);
     fprintf(stderr, "[convstack B=%d T=%d] cycles of step 0 per workgroup (wave 0): loads + LDS fill %.0f, conv0 %.0f, conv1 loop "
             "%.0f, conv1 exchange + y1 %.0f, next frame + conv2 loop %.0f, conv2 exchange + tail %.0f, total %.0f\n", B, a.T,
             ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]);

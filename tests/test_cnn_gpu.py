@@ -342,6 +342,20 @@ def test_image_resident_conv_stack_matches_layer_by_layer_kernels(batch):
   assert not bool(flipped.any())
   _, vals = oracle.nature_cnn_forward(weights, obs_np)
   nt.assert_allclose(values.cpu().numpy(), vals.numpy()[:, 0], rtol=1e-4, atol=2e-5)
+  # fp32 ACCURACY of the bf16-split layers, measured: the conv stack in float64 (the dequantisation
+  # x / 255 in float32 as the reference does it) against the fp32-MFMA kernels' error and this
+  # kernel's.  conv1 / conv2 multiply six of the nine exact bf16 x bf16 products of every fp32 x fp32:
+  # its error must stay at the level of the fp32 chain's own rounding.
+  import torch.nn.functional as F
+  n = min(batch, 32)
+  x = (torch.from_numpy(obs_np[:n]).permute(0, 3, 1, 2).float() / 255).double()
+  for i, stride in enumerate((4, 2, 1)):
+    x = F.relu(F.conv2d(x, torch.from_numpy(weights[f"base.conv-{i}.weight"]).double(),
+                        torch.from_numpy(weights[f"base.conv-{i}.bias"]).double(), stride=stride))
+  exact = x.permute(0, 2, 3, 1).reshape(n, 3136).numpy()  # NHWC like the device buffers
+  err_stack = np.abs(got[:n * 3136].cpu().numpy().reshape(n, 3136) - exact).max()
+  err_fp32 = np.abs(want[:n * 3136].cpu().numpy().reshape(n, 3136) - exact).max()
+  assert err_stack <= max(2.0 * err_fp32, 2e-6 * scale), (err_stack, err_fp32, scale)
 
 
 def test_backward_in_two_parts_equals_whole_backward():

@@ -3,7 +3,7 @@ import os
 import sys
 
 os.environ["DERL_AMD_LIBRARY"] = "diag"
-os.environ["DX_CS_DIAG"] = "1"
+os.environ.setdefault("DX_CS_DIAG", "0")  # the wave whose stamps are reported (0-7)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from derl_amd.cnn_engine import CnnEngine  # noqa: E402
