@@ -109,10 +109,27 @@ def test_forward_with_sample_index_gather():
   nt.assert_array_equal(head.cpu().numpy(), direct.cpu().numpy())
 
 
-def run_loss_and_backward(eng, data, mode, cliprange, vcoef, ecoef, num_actions, sample_idx=None):
+def run_loss_and_backward(eng, data, mode, cliprange, vcoef, ecoef, num_actions, sample_idx=None, route="layers"):
+  """``route`` "layers": dx_cnn_forward + dx_categorical_loss_f32 + dx_cnn_backward (every layer its own GEMM
+  stages); "update": what a training update launches -- dx_cnn_forward_trunk + dx_cnn_heads_loss_f32 +
+  dx_cnn_backward_part(3), i.e. with <= 7 actions the FACTORED tail (csrc/tail.hip: linear layer + heads as
+  one affine map of y2)."""
   from derl_amd import ops
   t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
   obs = t(data["observations"])
+  if route == "update":
+    B = sample_idx.numel() if sample_idx is not None else obs.shape[0]
+    eng.reserve(B)
+    eng._ensure_backward()
+    eng.forward_trunk(obs, sample_idx)
+    partials = torch.empty(8 * ((B + 7) // 8), dtype=torch.float64, device=DEV)
+    loss = torch.empty(8, dtype=torch.float32, device=DEV)
+    eng.heads_loss(B, t(data["actions"]), t(data["log_prob"]) if mode == 0 else None, t(data["advantages"]),
+                   t(data["values"].reshape(-1)) if mode == 0 else None, t(data["value_targets"].reshape(-1)), mode,
+                   cliprange, vcoef, ecoef, B, partials, loss)
+    eng.backward(obs, sample_idx, part=3)
+    torch.cuda.synchronize()
+    return loss.cpu().numpy(), eng.named_views(eng.grads)
   head = eng.forward(obs, sample_idx)
   eng._ensure_backward()
   B = head.shape[0]
@@ -126,14 +143,15 @@ def run_loss_and_backward(eng, data, mode, cliprange, vcoef, ecoef, num_actions,
   return loss.cpu().numpy(), eng.named_views(eng.grads)
 
 
+@pytest.mark.parametrize("route", ["layers", "update"])
 @pytest.mark.parametrize("name", ["ppo_step_cnn", "a2c_step_cnn", "a2c_step_cnn_late"])
-def test_loss_and_gradients_match_reference_golden(name):
+def test_loss_and_gradients_match_reference_golden(name, route):
   from tests.test_oracle_golden import oracle_step_case, _check_summary
   cfg, g, params, names, data = oracle_step_case(name)
   eng = make_engine(cfg["num_actions"], params)
   mode = 0 if cfg["alg"] == "ppo" else 1
   loss, grads = run_loss_and_backward(eng, data, mode, cfg.get("cliprange"), cfg["value_loss_coef"],
-                                      cfg["entropy_coef"], cfg["num_actions"])
+                                      cfg["entropy_coef"], cfg["num_actions"], route=route)
   nt.assert_allclose(loss[0], g["loss0"], rtol=1e-5, atol=1e-5)  # alg/ppo_test.py:28 tolerance
   for k in names:
     _check_summary(grads[k].cpu().numpy(), g, f"grad0.{k}", rtol=1e-4, atol=1e-5)
@@ -157,8 +175,9 @@ def test_loss_and_gradients_match_reference_golden(name):
 # XCD-aware block numbering from 64 reduction slices, pixel-group dgrads with a ragged last group)
 # 2048: the persistent ring kernels with few tiles per workgroup + nt_dma for the linear layer
 # 1152 = 9 groups of 128 images: the ring kernels with one XCD holding two image groups, the others one
+@pytest.mark.parametrize("route", ["layers", "update"])
 @pytest.mark.parametrize("batch", [1, 5, 37, 130, 1024, 1152, 2048, 2100, 2560, 8192])  # 8192 = BASELINE minibatch; 2560 = config 5's shard (K-split linear forward, uneven row groups per XCD)
-def test_backward_ragged_batches_with_gather(batch):
+def test_backward_ragged_batches_with_gather(batch, route):
   rs = np.random.RandomState(batch)
   A = 6
   weights = gi.nature_cnn_weights(A, 31)
@@ -171,7 +190,7 @@ def test_backward_ragged_batches_with_gather(batch):
               value_targets=rs.standard_normal((batch, 1)).astype(np.float32))
   eng = make_engine(A, weights, max_batch=max(256, batch))
   loss, grads = run_loss_and_backward(eng, data, 0, 0.1, 0.25, 0.01, A,
-                                      torch.from_numpy(idx).to(DEV))
+                                      torch.from_numpy(idx).to(DEV), route=route)
   odata = dict(data, observations=pool[idx])
   # float64 evaluation of the oracle ON THE ReLU BRANCH THE ENGINE TOOK.  A pre-activation that
   # lies within float32 rounding of zero may fall on either side of the ReLU depending on the
@@ -430,6 +449,8 @@ def test_side_stream_routes_are_bit_identical_to_the_serial_ones():
 
 @pytest.mark.parametrize("switch", ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_TN_SWIZZLE=0", "DX_LAT_MAX_TILES=0", "DX_WGRAD_DIRECT=0",
                                     "DX_WGRAD_DIRECT_MIN_B=1", "DX_NT_DMA=0", "DX_NTP=0",
+                                    "DX_FC_FACTORED=0",                           # linear layer + heads layer by layer in updates and rollouts
+                                    "DX_CONVSTACK=0", "DX_CONVSTACK=0 DX_FC_FACTORED=0 DX_FC_ROLLOUT=0",  # the rollout's layer-by-layer kernels
                                     "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
                                     "DX_BWD_OVERLAP=0 DX_C0_WAVES=4 DX_C0_GROUP4=0"])  # and their serial / round-2 twins
 def test_diagnostic_switches_keep_parity(switch):
