@@ -225,9 +225,11 @@ class IterateWithMinibatches(RunnerWrapper):
       elif isinstance(val, torch.Tensor) and val.is_cuda:
         pending[key] = lambda v=val: GatheredRows(v, order_dev[start:stop])
       elif isinstance(val, torch.Tensor):
-        pending[key] = lambda v=val: v[torch.from_numpy(order[start:stop].astype(np.int64))]
+        # (host arrays: the slice of `order` is taken NOW -- it may be a view of a pinned staging buffer that
+        # the permutation worker rewrites two rollouts later, and a minibatch may be kept that long)
+        pending[key] = lambda v=val, rows=order[start:stop].astype(np.int64): v[torch.from_numpy(rows)]
       elif isinstance(val, np.ndarray):
-        pending[key] = lambda v=val: v[order[start:stop]]
+        pending[key] = lambda v=val, rows=order[start:stop].copy(): v[rows]
       else:
         plain[key] = val
     out = LazyMinibatch(pending, rows=(start, stop))

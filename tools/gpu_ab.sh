@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B on ONE box, alternating: bench.py with two environment settings.
 # usage: bash tools/gpu_ab.sh "<env A>" "<env B>" [reps] [extra bench args]
-A=$1; B=$2; REPS=${3:-3}; shift 3
+A=$1; B=$2; REPS=${3:-3}; shift $(( $# < 3 ? $# : 3 ))
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 for rep in $(seq 1 $REPS); do
