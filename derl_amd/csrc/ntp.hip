@@ -106,6 +106,13 @@ struct NtpArgs {
 // Epilogue accesses in the SGPR-base form too: a uniform 64-bit base (tensor + the row's offset, scalar
 // adds) plus ONE per-lane 32-bit byte offset per column block, instead of a 64-bit per-lane
 // address per element (two VALU instructions and two registers each).
+// this lane's index in its wave, as a value the compiler neither hoists nor merges with another call's
+__device__ __forceinline__ int fresh_lane() {
+  int l = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+  asm volatile("" : "+v"(l));
+  return l;
+}
+
 __device__ __forceinline__ float load_at(const float *tensor, long long uniform_bytes, uint32_t lane_bytes) {
   asm volatile("" : "+v"(lane_bytes));
   return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(tensor) + uniform_bytes + lane_bytes);
@@ -200,8 +207,11 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
   const unsigned long long t_entry = (kDiag && stamps) ? __builtin_amdgcn_s_memrealtime() : 0;
   const NTArgs &a = p.nt;
   const Gather &g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The lane index is formed where each role needs it (mbcnt: two instructions), not carried from
+  // threadIdx.x across the role branch: at the 128-register cap of the 128x128 shape (conv1's data
+  // gradient, the dominant kernel) that one live value and its copy were spilled -- a 12-byte private
+  // segment for a kernel that otherwise needs none.
+  const int wave8 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   Cursor first;
   first.i = 0;
   open_tile<MODE, BM>(first, p);
@@ -211,6 +221,7 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
     // ================= loader waves: fills only =================
     // loader l fills A pieces l, l + NLOAD, ... (8 rows each) and W pieces l, l + NLOAD, ... of every stage
     const int wave = wave8 - S::NCONS;
+    const int lane = fresh_lane();
     const int lrow = lane >> 3;
     // Addresses are a UNIFORM 64-bit base (tensor + the step's offset: scalar adds) plus a per-lane
     // 32-bit byte offset that changes only with the tile: the fill then issues no vector ALU
@@ -294,6 +305,7 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
 
   // ================= consumer waves: fragment reads, MFMAs, epilogues =================
   const int wave = wave8;
+  const int lane = fresh_lane();
   const int hi = lane >> 5, l31 = lane & 31;
   const int wm = wave / S::WN, wn = wave % S::WN;  // waves of (32 TM) x (32 TN)
   const char *lds = reinterpret_cast<const char *>(smem);

@@ -4,7 +4,8 @@ launch of every network stage.  Counter unit: KiB; FETCH_SIZE is doubled (gfx950
 requests of wide streaming reads at 64 B).
 
   bash tools/pmc_passes.sh <tag>pmc 8192 "FETCH_SIZE" "WRITE_SIZE"
-  python3 tools/pmc_traffic.py gpurun_out/<tag>pmc_0 gpurun_out/<tag>pmc_1 profiles/<tag>_pmc_traffic.json"""
+  python3 tools/pmc_traffic.py gpurun_out/<tag>pmc_0 gpurun_out/<tag>pmc_1 profiles/<tag>_pmc_traffic.json \
+      [commit [gpurun_out/<tag>act_0 gpurun_out/<tag>act_1]]     (the last two: bash tools/gpu_actpmc.sh <tag>act 256 FETCH_SIZE WRITE_SIZE)"""
 import collections
 import csv
 import glob
@@ -23,6 +24,9 @@ STAGE_OF = [  # substring of the kernel name -> stage
     ("igemm_tn_kernel<11,", "conv1_wgrad"), ("igemm_nt_pix_kernel<12,", "conv1_dgrad"),
     ("conv0_wgrad_b16", "conv0_wgrad"), ("finalize_fused_kernel", "finalize"), ("permute_reduce_kernel", "finalize"),
     ("fc_row_unpermute_reduce", "finalize_fc"),
+    # the factored tail (csrc/tail.hip, heads.hip) and the rollout's one-kernel step (csrc/convstack.hip)
+    ("tail_loss_kernel", "tail_loss"), ("tail_bwd_kernel", "tail_bwd"), ("tail_greduce_kernel", "tail_greduce"),
+    ("tail_grads_kernel", "tail_grads"), ("convstack_image_kernel", "rollout_step (convstack, 256 images, one step)"),
 ]
 
 
@@ -38,9 +42,16 @@ def mean_per_kernel(root, counter):
   return {k: v[1] / v[0] for k, v in acc.items()}
 
 
-def main(fetch_dir, write_dir, out_path):
+def main(fetch_dir, write_dir, out_path, commit=None, act_fetch_dir=None, act_write_dir=None):
   fetch = mean_per_kernel(fetch_dir, "FETCH_SIZE")
   write = mean_per_kernel(write_dir, "WRITE_SIZE")
+  if act_fetch_dir and act_write_dir:  # the passes over tools/act_bench.py 256 (the rollout's act step)
+    for k, v in mean_per_kernel(act_fetch_dir, "FETCH_SIZE").items():
+      if "convstack" in k:
+        fetch[k] = v
+    for k, v in mean_per_kernel(act_write_dir, "WRITE_SIZE").items():
+      if "convstack" in k:
+        write[k] = v
   stages = {}
   for kernel in sorted(set(fetch) | set(write)):
     stage = next((s for key, s in STAGE_OF if key in kernel), None)
@@ -53,6 +64,7 @@ def main(fetch_dir, write_dir, out_path):
   doc = {"what": "HBM-side traffic per launch at minibatch 8192 (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
                  "separate passes over tools/stage_bench.py 8192; counter unit KiB; FETCH_SIZE doubled per "
                  "MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B)",
+         "commit": commit,
          "stages": stages}
   with open(out_path, "w") as f:
     json.dump(doc, f, indent=1)
@@ -61,4 +73,4 @@ def main(fetch_dir, write_dir, out_path):
 
 
 if __name__ == "__main__":
-  main(*sys.argv[1:4])
+  main(*sys.argv[1:7])

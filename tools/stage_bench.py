@@ -30,7 +30,7 @@ class M:
 
 
 times = bench.time_stages(M, obs, idx, batch, iters=iters)
-for stage, name in enumerate(bench.STAGES):
+for stage, name in enumerate(bench.time_stages.names):  # the stages an update really launches (factored tail or layer by layer)
   if only and stage not in only:
     continue
   fl = bench.stage_flops(name, batch, 4)
