@@ -276,9 +276,11 @@ def main():
                  "allreduce_bytes_per_update": allreduce_bytes,
                  "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 3),
                  "host_enqueue_ms_unblocked": round(host_unblocked_s * 1e3, 3),
-                 "arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32); first conv layer on bf16 MFMA with "
-                               "exact operands (uint8 pixels, 3-term bf16 split of the fp32 side), "
-                               "fp32 accumulation everywhere",
+                 "arithmetic": "updates: conv1 / conv2 stages on fp32 MFMA (v_mfma_f32_32x32x2_f32), first conv layer on bf16 "
+                               "MFMA with exact operands (uint8 pixels, exact 3-term bf16 split of the fp32 side); "
+                               "linear layer + heads as one affine map of y2 (fp32 vector ALU, HBM-bound); rollout: all "
+                               "three conv layers on bf16 MFMA (conv1 / conv2: both operands split exactly into three "
+                               "bf16 terms, the six products above 2^-23 of x w); fp32 accumulation everywhere",
                  "final_loss": float(alg.loss_fn.last_terms[0].item())},
   }
 
@@ -352,6 +354,30 @@ def main():
     ev1.record()
     ev1.synchronize()
     act_us = ev0.elapsed_time(ev1) * 1e3 / 20
+    # the whole horizon as the training loop runs it: dx_cnn_rollout_synth (one persistent launch when the
+    # conv-stack kernel applies)
+    rollout_row = None
+    base = alg.runner.unwrapped
+    if hasattr(base, "_buffers") and hasattr(model.engine, "rollout_synth") and hasattr(env.unwrapped, "seed"):
+      buf = base._buffers
+      try:
+        for _ in range(2):
+          model.engine.rollout_synth(buf, args.nsteps, nenvs, 1, 0, 2, 0, 0.1, 0.01)
+        ev0.record()
+        for _ in range(5):
+          model.engine.rollout_synth(buf, args.nsteps, nenvs, 1, 0, 2, 0, 0.1, 0.01)
+        ev1.record()
+        ev1.synchronize()
+        roll_us = ev0.elapsed_time(ev1) * 1e3 / 5
+        conv_flops = 2.0 * (MACS["conv0"] + MACS["conv1"] + MACS["conv2"]) * nenvs * args.nsteps
+        rollout_row = {"envs": nenvs, "steps": args.nsteps, "us": round(roll_us, 1),
+                       "us_per_step": round(roll_us / args.nsteps, 2),
+                       "conv_TFLOPs_algorithmic": round(conv_flops / (roll_us * 1e-6) / 1e12, 1),
+                       "frac_of_fp32_mfma_peak": round(conv_flops / (roll_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
+                       "note": "conv0 + conv1 + conv2 algorithmic flops of nenvs x nsteps frames / the launch's time; "
+                               "the layers execute on bf16 MFMA (3 and 6 bf16 products per fp32 product)"}
+      except Exception as error:  # a runner / env without the native rollout
+        rollout_row = {"error": str(error)}
     names = time_stages.names
     fwd_flops = sum(stage_flops(n, nenvs, A) for n in STAGE_IDS if n.endswith("_fwd"))
     # dominant kernel = the training stage with the largest share of a PPO iteration
@@ -400,7 +426,12 @@ def main():
                                     "update's stages: with the factored tail this 'fraction' can exceed what the "
                                     "fp32 pipes could do -- see iteration_roofline.composite for the honest ceiling"},
         "rollout_act": {"batch": nenvs, "us": round(act_us, 1),
-                        "achieved": round(fwd_flops / (act_us * 1e-6) / 1e12, 2)},
+                        "achieved": round(fwd_flops / (act_us * 1e-6) / 1e12, 2),
+                        "note": "one dx_cnn_act launch (conv stack + policy tail + sampling, one workgroup per image); "
+                                "`achieved` counts the flops of the reference's association (incl. the 512-wide layer "
+                                "the factored tail does not execute).  The benchmark's rollout is the same kernel with "
+                                "T = nsteps and the synthetic env inside: see native_rollout"},
+        "native_rollout": rollout_row,
         "stages": table}
     gae_local = time_gae(args.nsteps, nenvs)
     gae_big = time_gae(args.nsteps, 1 << 20)
