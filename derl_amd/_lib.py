@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "libderl_amd.so")
 # the in-kernel stamps and bisecting switches that are compiled out of the product library
 if os.environ.get("DERL_AMD_LIBRARY", "") == "diag":
   LIB_PATH = os.path.join(_PKG, "libderl_amd_diag.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_int, c_float, c_void_p, c_char_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p
 c_size_t, c_int64, c_uint64, c_double = ctypes.c_size_t, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
@@ -96,7 +96,8 @@ class CnnCtx(ctypes.Structure):
       + [(n, ctypes.c_longlong) for n in ("pk_c2d", "pk_fcd", "pk_hdd", "packed_count", "slab_count",
                                           "y0_count", "y1_count", "y2_count", "hid_count", "head_count",
                                           "hid_slab_count", "pb_c1f", "pb_c2f", "pb_fcf", "pb_c1d",
-                                          "pb_c2d", "pb_fcd", "pb_c0f", "pk_wc", "pk_beff", "pk_wcs")]
+                                          "pb_c2d", "pb_fcd", "pb_c0f", "pk_wc", "pk_beff", "pk_wcs", "ps_c1f",
+                                          "ps_c2f", "ps_wc")]
       + [(n, c_void_p) for n in ("params", "grads", "packed", "y0", "y1", "y2", "hid", "head",
                                  "dy0", "dy1", "dy2", "dhid", "dhead", "slabs", "hid_slabs")])
 _RESTYPES = {"dx_last_error": c_char_p, "dx_launch_count": c_longlong, "dx_cnn_last_route": c_char_p}

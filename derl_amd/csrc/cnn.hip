@@ -290,6 +290,8 @@ int dx_cnn_init(dx_cnn_ctx *c) {
   c->pb_c0f = take_planes(wsz[0]);
   c->pk_wc = take(8LL * d.flat); c->pk_beff = take(64);
   c->pk_wcs = take(tail_supported(d.flat, A) ? tail_pack_scratch_floats() : 0);
+  c->ps_c1f = take(convstack_pack_elems(0) / 2); c->ps_c2f = take(convstack_pack_elems(1) / 2);
+  c->ps_wc = take(convstack_pack_elems(2));
   c->packed_count = po;
   c->slab_count = make_plan(c, c->max_batch).total;
   const long long mb = c->max_batch;
@@ -391,7 +393,12 @@ static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s, bool light = 
   const long long cnt[7] = {wsz0, wsz1, wsz2, wsz3, wsz1, wsz2, wsz3};
   // (conv0 / conv1 / conv2: operands of the rollout's one-launch conv stack, convstack.hip)
   const int first = (part & 1) ? 0 : 1, count = (use_b3() ? 7 : 3) - first;
-  return count > 0 ? launch_split_planes(src + first, dst + first, cnt + first, count, s) : DX_OK;
+  if (int rc = launch_split_planes(src + first, dst + first, cnt + first, count, s)) return rc;
+  // the conv-stack kernel's fragment-order copies (only the rollout reads them: not between an epoch's updates)
+  if (!light && convstack_supported(c->in_h, c->in_w, c->in_c))
+    return launch_convstack_pack(planes(c, c->pb_c1f), planes(c, c->pb_c2f), fc_factored(c) ? pk + c->pk_wc : nullptr,
+                                 planes(c, c->ps_c1f), planes(c, c->ps_c2f), pk + c->ps_wc, s);
+  return DX_OK;
 }
 
 // canonical parameters -> packed mirrors (call after every parameter change)
@@ -950,8 +957,8 @@ static ConvStackArgs convstack_args(const dx_cnn_ctx *c, uint8_t *obs, int B) {
   std::memset(&a, 0, sizeof(a));
   a.obs = obs;
   a.Wb0 = planes(c, c->pb_c0f); a.bias0 = c->params + c->off_b[0];
-  a.Wb1 = planes(c, c->pb_c1f); a.bias1 = c->params + c->off_b[1];
-  a.Wb2 = planes(c, c->pb_c2f); a.bias2 = c->params + c->off_b[2];
+  a.Wf1 = planes(c, c->ps_c1f); a.bias1 = c->params + c->off_b[1];
+  a.Wf2 = planes(c, c->ps_c2f); a.bias2 = c->params + c->off_b[2];
   a.B = B; a.T = 1; a.row_stride = B;
   return a;
 }
@@ -961,7 +968,7 @@ static bool convstack_usable(const dx_cnn_ctx *c, int obs_is_u8, int B) {
 // the tail of the policy inside the conv-stack launch: out = y2 Wc^T + beff and the sampling rule
 static void convstack_tail(const dx_cnn_ctx *c, ConvStackArgs *a, const float *uniforms, uint64_t seed, uint64_t counter,
                            int env0, int64_t *actions, float *log_prob, float *values) {
-  a->Wc = c->packed + c->pk_wc; a->beff = c->packed + c->pk_beff; a->A = c->num_actions;
+  a->Wc = c->packed + c->ps_wc; a->beff = c->packed + c->pk_beff; a->A = c->num_actions;
   a->uniforms = uniforms; a->seed = seed; a->counter = counter; a->env0 = env0;
   a->actions = actions; a->log_prob = log_prob; a->values = values;
 }

@@ -318,14 +318,14 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave & 3, kh2 = wave >> 2;  // conv1 / conv2: output-channel tile and K half of this wave
-  const int n16 = lane & 15, kq = lane >> 4;
   const int e = blockIdx.x;
   const long long step_bytes = static_cast<long long>(a.row_stride) * kFrameB;  // frames of one step of the whole batch
-  unsigned long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define DX_CS_MARK(i) if (kDiag && a.stamps && t == 0) tk[i] = __builtin_amdgcn_s_memtime();
-  const int stamp_wave = kDiag ? a.env0 >> 24 : 0;  // (diag: DX_CS_DIAG=<wave> picks the stamping wave)
+  unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DX_CS_MARK(i) if (kDiag && a.stamps && t == stamp_step) tk[i] = __builtin_amdgcn_s_memtime();
+  const int stamp_wave = kDiag ? (a.env0 >> 24) & 7 : 0;  // (diag: DX_CS_DIAG=<wave> picks the stamping wave)
+  const int stamp_step = kDiag ? a.stamp_step : 0;              // (diag: DX_CS_STEP=<t> picks the stamped step)
   int t = 0;
-  DX_CS_MARK(0)
+  if (kDiag && a.stamps && stamp_step == 0) tk[0] = __builtin_amdgcn_s_memtime();
 
   // ---- step 0's frame and conv0's weight planes (resident for the whole launch): issued at once ----
   {
@@ -352,11 +352,12 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   float *red = reinterpret_cast<float *>(smem + oRed);
   float *tailred = reinterpret_cast<float *>(smem + oTail);  // [step parity][8 waves][8 outputs]
-  // this lane's byte offsets into a plane of the conv1 / conv2 weights: row (channel) 16 nt + n16, K half, k group kq
-  const unsigned off1 = static_cast<unsigned>(((16 * nt + n16) * 512 + (8 * kh2) * 32 + 8 * kq) * 2);
-  const unsigned off2 = static_cast<unsigned>(((16 * nt + n16) * 576 + (9 * kh2) * 32 + 8 * kq) * 2);
+  // the weights come in fragment order (launch_convstack_pack): piece (wave, step, plane) is one KB, 16 bytes per lane
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned off1 = static_cast<unsigned>(lane * 16), off2 = off1;
 
   for (t = 0; t < a.T; ++t) {
+    if (t > 0) { DX_CS_MARK(0) }
     // conv1's weight fragments travel while conv0 runs: A fragment of v_mfma_f32_16x16x32_bf16 = 8 consecutive k
     // of row (channel) 16 nt + n16: plane pl, tap 8 kh2 + s, k group kq
     u32x4 w1[8][3];
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
 #pragma unroll
       for (int s = 0; s < 6; ++s)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load16(a.Wb1 + pl * (64 * 512) + 32 * s, o1);
+        for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load16(a.Wf1 + ((wave_s * 8 + s) * 3 + pl) * 512, o1);
     }
     lds_barrier();  // this step's frame (and, at step 0, conv0's planes) are in LDS
     DX_CS_MARK(1)
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
 #pragma unroll
         for (int s = 6; s < 8; ++s)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load16(a.Wb1 + pl * (64 * 512) + 32 * s, o1);
+          for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load16(a.Wf1 + ((wave_s * 8 + s) * 3 + pl) * 512, o1);
       }
       const int lane1 = opaque(lane), n16 = lane1 & 15, kq = lane1 >> 4;
       int pb[6];
@@ -406,8 +407,10 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
         pb[mt] = oY0 + 2 * oy * kY0R + 2 * ox * kY0P + 16 * kq;
       }
       f32x4 acc[6] = {zero4, zero4, zero4, zero4, zero4, zero4};
+      DX_CS_MARK(12)
       if (kh2 == 0) conv_half<1, 0, 6, 8>(smem, pb, w1, acc);
       else conv_half<1, 1, 6, 8>(smem, pb, w1, acc);
+      DX_CS_MARK(13)
       const int oc0 = 16 * nt + 4 * kq;  // the four channels of this lane's D rows
       const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);  // (ahead of the 27 loads below: vmcnt returns in order)
       __builtin_amdgcn_sched_barrier(0);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
 #pragma unroll
       for (int s = 0; s < 9; ++s)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w2[s][pl] = load16(a.Wb2 + pl * (64 * 576) + 32 * s, o2);
+        for (int pl = 0; pl < 3; ++pl) w2[s][pl] = load16(a.Wf2 + ((wave_s * 9 + s) * 3 + pl) * 512, o2);
       DX_CS_MARK(3)
       lds_barrier();  // every wave has read y0: the exchange scratch and the y1 planes may overwrite it
       // the K halves swap: half 0 finishes tiles 0-2, half 1 tiles 3-5; each hands the other's three over
@@ -478,15 +481,13 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
       // the tail's weights for outputs 0-3 now (under the exchange), for 4-7 after these are used
       f32x4 wc[4][2];
-      unsigned ow[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) ow[m] = static_cast<unsigned>((min(p_keep0 + 16 * m, kP2 - 1) * 64 + oc0) * 4);
+      const unsigned ow = static_cast<unsigned>(lane2 * 16);  // (fragment order: rows of pixels past the image are zero)
       if (a.Wc) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            wc[j][m] = j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + j * (kP2 * 64), ow[m])) : zero4;
+            wc[j][m] = j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + ((wave_s * 2 + m) * 8 + j) * 256, ow)) : zero4;
       }
       // (the exchange scratch lies behind the y1 planes: no wave is still reading what it overwrites)
       if (kh2 == 0) give_tiles<2, 2>(red, wave, lane, acc);
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
             for (int m = 0; m < 2; ++m)
 #pragma unroll
               for (int j = 0; j < 4; ++j)
-                wc[j][m] = 4 + j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + (4 + j) * (kP2 * 64), ow[m])) : zero4;
+                wc[j][m] = 4 + j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + ((wave_s * 2 + m) * 8 + 4 + j) * 256, ow)) : zero4;
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -547,11 +548,54 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
 #undef DX_CS_MARK
   if (kDiag && a.stamps && tid == 64 * stamp_wave) {
     tk[7] = __builtin_amdgcn_s_memrealtime();
-    for (int i = 0; i < 12; ++i) a.stamps[blockIdx.x * 12 + i] = tk[i];
+    for (int i = 0; i < 16; ++i) a.stamps[blockIdx.x * 16 + i] = tk[i];
   }
 }
 
+// conv1 / conv2's bf16 planes and the tail's Wc in the order the kernel's waves read them: one thread per
+// 16-byte piece.  Wave (nt = wave & 3: 16 output channels, kh2 = wave >> 2: K half); lane (n16 = row of the
+// tile, kq = k group): the A fragment of v_mfma_f32_16x16x32_bf16 at K step s is 8 consecutive k of row n16.
+constexpr int kPieces1 = 8 * 8 * 3 * 64, kPieces2 = 8 * 9 * 3 * 64, kPiecesC = 8 * 2 * 8 * 64;
+__global__ __launch_bounds__(256) void convstack_pack_kernel(const uint16_t *Wb1, const uint16_t *Wb2, const float *Wc, uint16_t *Wf1,
+                                                             uint16_t *Wf2, float *Wcf) {
+  int q = blockIdx.x * 256 + threadIdx.x;
+  const int lane = q & 63, n16 = lane & 15, kq = lane >> 4;
+  if (q < kPieces1 + kPieces2) {
+    const bool second = q >= kPieces1;
+    if (second) q -= kPieces1;
+    const int ns = second ? 9 : 8, K = second ? 576 : 512;
+    int r = q >> 6;
+    const int pl = r % 3;
+    r /= 3;
+    const int s = r % ns, wave = r / ns, nt = wave & 3, kh2 = wave >> 2;
+    const uint16_t *src = (second ? Wb2 : Wb1) + pl * (64 * K) + (16 * nt + n16) * K + (ns * kh2 + s) * 32 + 8 * kq;
+    reinterpret_cast<u32x4 *>(second ? Wf2 : Wf1)[q] = *reinterpret_cast<const u32x4 *>(src);
+    return;
+  }
+  q -= kPieces1 + kPieces2;
+  if (q >= kPiecesC || Wc == nullptr) return;
+  // the tail: lane holds channels oc0 .. oc0 + 3 of pixel 16 (2 kh2 + m) + n16 of y2; output row j
+  const int r = q >> 6, j = r & 7, m = (r >> 3) & 1, wave = r >> 4, nt = wave & 3, kh2 = wave >> 2;
+  const int p = 16 * (2 * kh2 + m) + n16, oc0 = 16 * nt + 4 * kq;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (p < kP2) v = *reinterpret_cast<const f32x4 *>(Wc + j * (kP2 * 64) + p * 64 + oc0);
+  reinterpret_cast<f32x4 *>(Wcf)[q] = v;
+}
+
 }  // namespace
+
+long long convstack_pack_elems(int which) { return which == 0 ? kPieces1 * 8LL : which == 1 ? kPieces2 * 8LL : kPiecesC * 4LL; }
+
+int launch_convstack_pack(const uint16_t *Wb1, const uint16_t *Wb2, const float *Wc, uint16_t *Wf1, uint16_t *Wf2, float *Wcf,
+                          hipStream_t stream) {
+  DX_REQUIRE(Wb1 && Wb2 && Wf1 && Wf2 && (Wc == nullptr || Wcf), "convstack_pack: bad arguments");
+  DX_REQUIRE(aligned(Wb1, 16) && aligned(Wb2, 16) && aligned(Wf1, 16) && aligned(Wf2, 16) && aligned(Wc, 16) && aligned(Wcf, 16),
+             "convstack_pack: operands must be 16-byte aligned");
+  const int pieces = kPieces1 + kPieces2 + (Wc ? kPiecesC : 0);
+  hipLaunchKernelGGL(convstack_pack_kernel, dim3((pieces + 255) / 256), dim3(256), 0, stream, Wb1, Wb2, Wc, Wf1, Wf2, Wcf);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
 
 bool convstack_supported(int in_h, int in_w, int in_c) { return in_h == kIn && in_w == kIn && in_c == 4; }
 
@@ -559,8 +603,8 @@ bool convstack_supported(int in_h, int in_w, int in_c) { return in_h == kIn && i
 // sampling in the kernel), or T steps against the synthetic device env.
 int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
   ConvStackArgs a = args;
-  DX_REQUIRE(a.obs && a.Wb0 && a.bias0 && a.Wb1 && a.bias1 && a.Wb2 && a.bias2 && a.B >= 1 && a.T >= 1, "convstack: bad arguments");
-  DX_REQUIRE(aligned(a.obs, 16) && aligned(a.Wb0, 16) && aligned(a.Wb1, 16) && aligned(a.Wb2, 16) && aligned(a.bias0, 16) &&
+  DX_REQUIRE(a.obs && a.Wb0 && a.bias0 && a.Wf1 && a.bias1 && a.Wf2 && a.bias2 && a.B >= 1 && a.T >= 1, "convstack: bad arguments");
+  DX_REQUIRE(aligned(a.obs, 16) && aligned(a.Wb0, 16) && aligned(a.Wf1, 16) && aligned(a.Wf2, 16) && aligned(a.bias0, 16) &&
                  aligned(a.bias1, 16) && aligned(a.bias2, 16) && (a.y2 == nullptr || aligned(a.y2, 16)) &&
                  (a.Wc == nullptr || aligned(a.Wc, 16)),
              "convstack: frames, weight planes, biases, Wc and y2 must be 16-byte aligned");
@@ -571,6 +615,7 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
              "convstack: T > 1 only against the synthetic env, with the tail in the kernel");
   if (a.row_stride < a.B) a.row_stride = a.B;
   a.stamps = nullptr;
+  a.stamp_step = 0;
   static int configured_device = -1;
   int dev = 0;
   DX_HIP(hipGetDevice(&dev));
@@ -581,31 +626,34 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
   }
   const int B = a.B;
 #if DX_DIAG
-  if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of step 0 (wave 0 of every workgroup), summarised on stderr (synchronous)
+  if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one step (DX_CS_STEP, default 0) of wave DX_CS_DIAG, on stderr (synchronous)
     unsigned long long *dev_stamps = nullptr;
-    DX_HIP(hipMalloc(&dev_stamps, static_cast<size_t>(B) * 96));
+    DX_HIP(hipMalloc(&dev_stamps, static_cast<size_t>(B) * 128));
     a.stamps = dev_stamps;
     const int stamp_wave = atoi(getenv("DX_CS_DIAG")) & 7;
     a.env0 |= stamp_wave << 24;  // (timing build only: sampling positions are not what is looked at)
+    a.stamp_step = getenv("DX_CS_STEP") ? atoi(getenv("DX_CS_STEP")) : 0;
+    if (a.stamp_step >= a.T) a.stamp_step = a.T - 1;
     hipLaunchKernelGGL(convstack_image_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
     DX_LAUNCH_CHECK();
     DX_HIP(hipStreamSynchronize(stream));
-    std::vector<unsigned long long> h(static_cast<size_t>(B) * 12);
+    std::vector<unsigned long long> h(static_cast<size_t>(B) * 16);
     DX_HIP(hipMemcpy(h.data(), dev_stamps, h.size() * 8, hipMemcpyDeviceToHost));
     DX_HIP(hipFree(dev_stamps));
-    double ph[6] = {0, 0, 0, 0, 0, 0}, fine[4] = {0, 0, 0, 0};
-    for (int b = 0; b < B; ++b) {
-      for (int i = 0; i < 6; ++i) ph[i] += static_cast<double>(h[b * 12 + i + 1] - h[b * 12 + i]) / B;
-      fine[0] += static_cast<double>(h[b * 12 + 11] - h[b * 12 + 1]) / B;   // conv0: its MFMA loop (wave 0: two tiles)
-      fine[1] += static_cast<double>(h[b * 12 + 8] - h[b * 12 + 3]) / B;    // conv1: waiting for the other waves' loops
-      fine[2] += static_cast<double>(h[b * 12 + 9] - h[b * 12 + 8]) / B;    // conv1: hand-over + barrier
-      fine[3] += static_cast<double>(h[b * 12 + 10] - h[b * 12 + 9]) / B;   // conv1: finish + split + y1 stores
+    static const int order[13] = {0, 1, 11, 2, 12, 13, 3, 8, 9, 10, 4, 5, 6};
+    static const char *what[12] = {"step top: w1 loads (6 taps) + barrier", "conv0 MFMA loop (+ deferred sample)", "conv0 bias, barrier, y0 stores, barrier",
+                                   "w1 loads (2 taps) + addresses", "conv1 loop", "bias1 + w2 loads issued", "barrier (all conv1 loops done)",
+                                   "hand-over + barrier", "finish + y1 stores", "barrier (y1 complete)", "next frame + conv2 loop",
+                                   "conv2 exchange + tail"};
+    double total = 0;
+    fprintf(stderr, "[convstack B=%d T=%d step %d wave %d] cycles per workgroup (mean):\n", B, a.T, a.stamp_step, stamp_wave);
+    for (int i = 0; i < 12; ++i) {
+      double d = 0;
+      for (int b = 0; b < B; ++b) d += static_cast<double>(h[b * 16 + order[i + 1]] - h[b * 16 + order[i]]) / B;
+      total += d;
+      fprintf(stderr, "  %-44s %8.0f\n", what[i], d);
     }
-    fprintf(stderr, "[convstack wave %d] conv0 MFMA loop %.0f | conv1: wait for all loops %.0f, hand-over %.0f, finish + y1 %.0f\n",
-            stamp_wave, fine[0], fine[1], fine[2], fine[3]);
-    fprintf(stderr, "[convstack B=%d T=%d] cycles of step 0 per workgroup (wave 0): loads + LDS fill %.0f, conv0 %.0f, conv1 loop "
-            "%.0f, conv1 exchange + y1 %.0f, next frame + conv2 loop %.0f, conv2 exchange + tail %.0f, total %.0f\n", B, a.T,
-            ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]);
+    fprintf(stderr, "  %-44s %8.0f\n", "total", total);
     return DX_OK;
   }
 #endif

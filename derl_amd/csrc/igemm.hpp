@@ -213,14 +213,15 @@ struct ConvStackArgs {
                          // buffer (T + 1, row_stride envs, 84, 84, 4) from this launch's first env on: steps 1 .. T are WRITTEN
   const uint16_t *Wb0;   // conv0 weights, three bf16 planes [3][32][256] (k = (kh, kw, c))
   const float *bias0;
-  const uint16_t *Wb1;   // conv1 weights, planes [3][64][512] (k = (kh, kw, ic))
+  const uint16_t *Wf1;   // conv1 weights in FRAGMENT order (launch_convstack_pack): [wave][8 steps][3 planes][64 lanes][8]
   const float *bias1;
-  const uint16_t *Wb2;   // conv2 weights, planes [3][64][576]
+  const uint16_t *Wf2;   // conv2 weights in fragment order: [wave][9 steps][3 planes][64 lanes][8]
   const float *bias2;
   float *y2;             // (B, 7, 7, 64) NHWC, or NULL when the tail runs in here
   int B;
   // ---- the policy's tail in the same kernel (NULL Wc: the caller runs its own): out = y2 Wc^T + beff, sampling ----
-  const float *Wc, *beff;  // [8][3136] (rows 0 .. A - 1 policy, row A value, the rest ZERO), [8]
+  const float *Wc, *beff;  // Wc (rows 0 .. A - 1 policy, row A value, the rest ZERO) in fragment order
+                           // (launch_convstack_pack): [wave][2 tiles][8 rows][64 lanes][4]; beff [8]
   int A;
   const float *uniforms;   // optional (B): the uniforms to sample with (T = 1)
   uint64_t seed, counter;  // else uniform01(seed, counter + t, env0 + e)
@@ -234,10 +235,17 @@ struct ConvStackArgs {
   uint8_t *resets;
   uint64_t env_seed, env_counter;
   float p_reward, p_reset;
+  int stamp_step;              // DX_DIAG only: the step whose phases are stamped
   unsigned long long *stamps;  // DX_DIAG only (DX_CS_DIAG=1): [B][8] shader-clock stamps of wave 0 (step 0), else NULL
 };
 bool convstack_supported(int in_h, int in_w, int in_c);
 int launch_convstack(const ConvStackArgs &args, hipStream_t stream);
+// The conv-stack kernel's copies of conv1 / conv2's bf16 planes ([3][64][512], [3][64][576]) and of the
+// factored tail's Wc ([8][3136], may be NULL) in the order its waves read them: every fragment load of the
+// kernel is then ONE contiguous KB per wave (the planes' own layout made each a gather of 16 x 64 bytes).
+long long convstack_pack_elems(int which);  // 0 / 1: uint16 elements of Wf1 / Wf2, 2: floats of the Wc copy
+int launch_convstack_pack(const uint16_t *Wb1, const uint16_t *Wb2, const float *Wc, uint16_t *Wf1, uint16_t *Wf2, float *Wcf,
+                          hipStream_t stream);
 // the rollout's linear layer, weight-stationary split-K (fc_rollout.hip): slabs [parts][M][512], bias on slab 0
 int fc_rollout_parts();
 bool fc_rollout_supported(int M, int N, int K);

@@ -40,7 +40,7 @@ extern "C" {
 #define DX_EWS (-4)      /* workspace too small                                     */
 #define DX_ETIMEOUT (-5) /* a persistent kernel's grid barrier gave up (dx_mlp_ppo_epoch) */
 
-#define DX_ABI_VERSION 3
+#define DX_ABI_VERSION 4
 
 int dx_abi_version(void);
 const char *dx_last_error(void);
@@ -240,6 +240,9 @@ typedef struct dx_cnn_ctx {
   /* the factored tail (csrc/tail.hip): Wc = Wh Wfc as [8][flat] in y2's column order, beff [8],
    * and the scratch of their product -- offsets in floats inside `packed` */
   long long pk_wc, pk_beff, pk_wcs;
+  /* the rollout's conv-stack kernel (csrc/convstack.hip) reads conv1 / conv2's bf16 planes and Wc from
+   * copies in ITS waves' fragment order (one contiguous KB per wave load) -- offsets in floats */
+  long long ps_c1f, ps_c2f, ps_wc;
   /* ---- device buffers (caller-allocated, fp32) ---- */
   float *params, *grads;            /* param_count */
   float *packed;                    /* packed_count; ZERO-FILLED once by the owner: dx_cnn_pack

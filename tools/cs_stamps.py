@@ -1,4 +1,5 @@
-"""In-kernel phase stamps of the rollout's conv-stack kernel (diag flavour): python3 tools/cs_stamps.py [batch ...]"""
+"""In-kernel phase stamps of the rollout's conv-stack kernel (diag flavour).
+usage: [DX_CS_DIAG=<wave>] [DX_CS_STEP=<t>] python3 tools/cs_stamps.py [batch [horizon]]   (horizon > 1: the native rollout)"""
 import os
 import sys
 
@@ -9,14 +10,24 @@ import torch  # noqa: E402
 from derl_amd.cnn_engine import CnnEngine  # noqa: E402
 
 dev = torch.device("cuda:0")
-for batch in [int(b) for b in sys.argv[1:]] or [128, 256]:
-  eng = CnnEngine(4, max_batch=max(batch, 64), device=dev)
-  with torch.no_grad():
-    eng.params.normal_(0, 0.02)
-  eng.mark_dirty()
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+horizon = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+eng = CnnEngine(4, max_batch=max(batch, 64), device=dev)
+with torch.no_grad():
+  eng.params.normal_(0, 0.02)
+eng.mark_dirty()
+if horizon == 1:
   obs = torch.randint(0, 256, (batch, 84, 84, 4), dtype=torch.uint8, device=dev)
   actions = torch.empty(batch, dtype=torch.int64, device=dev)
   log_prob, values = torch.empty(batch, device=dev), torch.empty(batch, device=dev)
-  for _ in range(4):
+  for _ in range(3):
     eng.act(obs, actions, log_prob, values)
-  torch.cuda.synchronize()
+else:
+  buffers = dict(obs=torch.randint(0, 256, (horizon + 1, batch, 84, 84, 4), dtype=torch.uint8, device=dev),
+                 actions=torch.empty(horizon, batch, dtype=torch.int64, device=dev),
+                 log_prob=torch.empty(horizon, batch, device=dev), values=torch.empty(horizon, batch, device=dev),
+                 rewards=torch.empty(horizon, batch, device=dev),
+                 resets=torch.empty(horizon, batch, dtype=torch.uint8, device=dev))
+  for i in range(3):
+    eng.rollout_synth(buffers, horizon, batch, 7, i * horizon, 11, i * horizon, 0.05, 0.01)
+torch.cuda.synchronize()
