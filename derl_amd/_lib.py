@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_PKG, "libderl_amd.so")
 # the in-kernel stamps and bisecting switches that are compiled out of the product library
 if os.environ.get("DERL_AMD_LIBRARY", "") == "diag":
   LIB_PATH = os.path.join(_PKG, "libderl_amd_diag.so")
+elif os.environ.get("DERL_AMD_LIBRARY", "").endswith(".so"):  # another build of the library (tools/: A/B on one box)
+  LIB_PATH = os.path.join(_PKG, os.path.basename(os.environ["DERL_AMD_LIBRARY"]))
 ABI_VERSION = 4
 
 c_int, c_float, c_void_p, c_char_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   const int stamp_step = kDiag ? a.stamp_step : 0;              // (diag: DX_CS_STEP=<t> picks the stamped step)
   int t = 0;
   if (kDiag && a.stamps && stamp_step == 0) tk[0] = __builtin_amdgcn_s_memtime();
+  if (kDiag && a.stamps) { tk[14] = __builtin_amdgcn_s_memrealtime(); tk[15] = __builtin_amdgcn_s_memtime(); }
 
   // ---- step 0's frame and conv0's weight planes (resident for the whole launch): issued at once ----
   {
@@ -548,6 +549,8 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
 #undef DX_CS_MARK
   if (kDiag && a.stamps && tid == 64 * stamp_wave) {
     tk[7] = __builtin_amdgcn_s_memrealtime();
+    tk[15] = __builtin_amdgcn_s_memtime() - tk[15];  // the whole launch in shader cycles,
+    tk[14] = tk[7] - tk[14];                         // and in ticks of the constant 100 MHz clock
     for (int i = 0; i < 16; ++i) a.stamps[blockIdx.x * 16 + i] = tk[i];
   }
 }
@@ -654,6 +657,9 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
       fprintf(stderr, "  %-44s %8.0f\n", what[i], d);
     }
     fprintf(stderr, "  %-44s %8.0f\n", "total", total);
+    double cyc = 0, ticks = 0;
+    for (int b = 0; b < B; ++b) { cyc += static_cast<double>(h[b * 16 + 15]); ticks += static_cast<double>(h[b * 16 + 14]); }
+    fprintf(stderr, "  whole launch: %.0f cycles per workgroup in %.2f us: shader clock %.0f MHz\n", cyc / B, ticks / B / 100.0, cyc / ticks * 100.0);
     return DX_OK;
   }
 #endif

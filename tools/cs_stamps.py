@@ -3,7 +3,7 @@ usage: [DX_CS_DIAG=<wave>] [DX_CS_STEP=<t>] python3 tools/cs_stamps.py [batch [h
 import os
 import sys
 
-os.environ["DERL_AMD_LIBRARY"] = "diag"
+os.environ.setdefault("DERL_AMD_LIBRARY", "diag")
 os.environ.setdefault("DX_CS_DIAG", "0")  # the wave whose stamps are reported (0-7)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
