@@ -331,6 +331,14 @@ static uint16_t *planes(const dx_cnn_ctx *c, long long off) {
 // canonical parameters -> packed mirrors.  part 1 = what the FIRST conv layer's forward reads (its
 // forward mirror and the bf16 planes of it), part 2 = every other mirror, 3 = both.  The split lets
 // dx_cnn_ppo_epoch start the next minibatch's first layer while the rest is still being packed.
+static bool convstack_train_env() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("DX_CONVSTACK_TRAIN");
+    on = e ? atoi(e) : 1;
+  }
+  return on != 0;
+}
 static bool fc_factored(const dx_cnn_ctx *c) { return fc_factored_env() && tail_supported(c->flat, c->num_actions); }
 
 // `light`: without the mirrors only the layer-by-layer linear layer / heads read (pk_fcf, pk_fcd and their
@@ -395,7 +403,7 @@ static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s, bool light = 
   const int first = (part & 1) ? 0 : 1, count = (use_b3() ? 7 : 3) - first;
   if (int rc = launch_split_planes(src + first, dst + first, cnt + first, count, s)) return rc;
   // the conv-stack kernel's fragment-order copies (only the rollout reads them: not between an epoch's updates)
-  if (!light && convstack_supported(c->in_h, c->in_w, c->in_c))
+  if ((!light || convstack_train_env()) && convstack_supported(c->in_h, c->in_w, c->in_c))
     return launch_convstack_pack(planes(c, c->pb_c1f), planes(c, c->pb_c2f), fc_factored(c) ? pk + c->pk_wc : nullptr,
                                  planes(c, c->ps_c1f), planes(c, c->ps_c2f), pk + c->ps_wc, s);
   return DX_OK;
@@ -702,9 +710,30 @@ static bool fwd_lanes(int B) {
   return B >= 2 && B % 2 == 0 && (mode == 1 || (mode == -1 && B >= limit));
 }
 
+// The conv stack of a training minibatch as ONE launch of the image-resident kernel (convstack.hip, `train`):
+// all three layers on the bf16 matrix cores, y0 / y1 / y2 stored for the backward.  DX_CONVSTACK_TRAIN=0: the
+// three layer-by-layer stages.
+static bool convstack_train_usable(const dx_cnn_ctx *c, int obs_is_u8) {
+  return convstack_train_env() && obs_is_u8 && !conv0_f32() && convstack_supported(c->in_h, c->in_w, c->in_c);
+}
+static ConvStackArgs convstack_args(const dx_cnn_ctx *c, uint8_t *obs, int B);
+static int convstack_train_forward(const dx_cnn_ctx *c, const void *obs, const int32_t *sample_idx, int B, hipStream_t s) {
+  ConvStackArgs cs = convstack_args(c, static_cast<uint8_t *>(const_cast<void *>(obs)), B);
+  cs.train = 1; cs.sample_idx = sample_idx;
+  cs.y0 = c->y0; cs.y1 = c->y1; cs.y2 = c->y2;
+  if (int rc = launch_convstack(cs, s)) return rc;
+  g_route[ST_CONV0_FWD] = g_route[ST_CONV1_FWD] = g_route[ST_CONV2_FWD] = "convstack_train";
+  return DX_OK;
+}
+
 // forward stages first .. last on `s` (as one chain, or as two half-batch chains joined at the end)
 static int forward_stages(const dx_cnn_ctx *c, int first, int last, const void *obs, int obs_is_u8,
                           const int32_t *sample_idx, int B, hipStream_t s) {
+  if (first == ST_CONV0_FWD && last >= ST_CONV2_FWD && convstack_train_usable(c, obs_is_u8)) {
+    if (int rc = convstack_train_forward(c, obs, sample_idx, B, s)) return rc;
+    first = ST_CONV2_FWD + 1;
+    if (first > last) return DX_OK;
+  }
   SideStream *side = fwd_lanes(B) ? side_stream() : nullptr;
   if (side == nullptr) {
     const Plan plan = make_plan(c, B);
@@ -1172,6 +1201,8 @@ int cnn_pack_between_updates(const dx_cnn_ctx *c, bool last_update, hipStream_t 
   return pack_part(c, 3, s, fc_factored(c) && !last_update);
 }
 bool cnn_fc_factored(const dx_cnn_ctx *c) { return fc_factored(c); }
+// the whole conv stack of a training minibatch is one launch: no first layer to start ahead of the other mirrors
+bool cnn_forward_fused(const dx_cnn_ctx *c, int obs_is_u8) { return convstack_train_usable(c, obs_is_u8); }
 
 // the library's side stream, ordered after everything enqueued on `s` so far (NULL: unavailable)
 hipStream_t cnn_side_begin(hipStream_t s) {

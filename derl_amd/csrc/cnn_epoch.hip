@@ -26,6 +26,7 @@ int cnn_forward_range(const dx_cnn_ctx *c, int first, int last, const void *obs,
 int cnn_pack_part(const dx_cnn_ctx *c, int part, hipStream_t s);
 int cnn_pack_between_updates(const dx_cnn_ctx *c, bool last_update, hipStream_t s);
 bool cnn_fc_factored(const dx_cnn_ctx *c);
+bool cnn_forward_fused(const dx_cnn_ctx *c, int obs_is_u8);
 hipStream_t cnn_side_begin(hipStream_t s);
 int cnn_side_end(hipStream_t s);
 }  // namespace dx
@@ -150,7 +151,7 @@ static int epoch_body(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream, 
     if (int rc = dx_grad_sumsq_f32(c->grads, c->param_count, e->sumsq_partials, e->npartials, stream)) return rc;
     float *norm_out = e->grad_norm_out ? e->grad_norm_out + static_cast<long long>(e->grad_norm_stride) * k : nullptr;
     const bool more = start + e->mbsize < e->samples;
-    if (e->optimizer == 0 && more && tail_overlap) {
+    if (e->optimizer == 0 && more && tail_overlap && !cnn_forward_fused(c, e->obs_is_u8)) {
       // Another minibatch follows: the first conv layer's parameters (weight + bias: the head of the
       // parameter vector) are stepped and re-packed FIRST, on this stream; the other 99.5 % of the
       // parameters and their mirrors follow on the side stream, beside the next minibatch's first

@@ -171,7 +171,8 @@ __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int l
 // lane & 31, rows (channels) of register i = (i & 3) + 8 (i >> 2) + 4 (lane >> 5): registers 4q .. 4q + 3
 // are four consecutive channels
 template <int NT_>
-__device__ __forceinline__ void conv0_store(uint8_t *smem, int tile0, int lane, const f32x16 (&acc)[2], const f32x4 (&bias)[4]) {
+__device__ __forceinline__ void conv0_store(uint8_t *smem, int tile0, int lane, const f32x16 (&acc)[2], const f32x4 (&bias)[4],
+                                            float *gy0) {
   const int r = lane & 31, kg = lane >> 5;
 #pragma unroll
   for (int t = 0; t < NT_; ++t) {
@@ -186,6 +187,7 @@ __device__ __forceinline__ void conv0_store(uint8_t *smem, int tile0, int lane, 
         v[j] = x > 0.f ? x : 0.f;
       }
       store_planes4(smem, oY0 + (p / 20) * kY0R + (p % 20) * kY0P + (8 * q + 4 * kg) * 2, kY0Plane, v);
+      if (gy0) *reinterpret_cast<f32x4 *>(gy0 + p * 32 + 8 * q + 4 * kg) = v;  // (training: kept for the backward)
     }
   }
 }
@@ -318,7 +320,8 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave & 3, kh2 = wave >> 2;  // conv1 / conv2: output-channel tile and K half of this wave
-  const int e = blockIdx.x;
+  int e = blockIdx.x;  // the env (rollout) or, in a training forward, the image: blockIdx + t grid
+  const int steps = a.train ? (a.B - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x) : a.T;
   const long long step_bytes = static_cast<long long>(a.row_stride) * kFrameB;  // frames of one step of the whole batch
   unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DX_CS_MARK(i) if (kDiag && a.stamps && t == stamp_step) tk[i] = __builtin_amdgcn_s_memtime();
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
 
   // ---- step 0's frame and conv0's weight planes (resident for the whole launch): issued at once ----
   {
-    const uint8_t *src = a.obs + static_cast<long long>(e) * kFrameB;
+    const uint8_t *src = a.obs + static_cast<long long>(a.sample_idx ? a.sample_idx[e] : e) * kFrameB;
     u32x4 fr[4];  // the frame: 1,764 pieces of 16 bytes
 #pragma unroll
     for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const u32x4 *>(src + 16 * min(tid + 512 * u, kFrameB / 16 - 1));
@@ -357,8 +360,12 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const unsigned off1 = static_cast<unsigned>(lane * 16), off2 = off1;
 
-  for (t = 0; t < a.T; ++t) {
+  for (t = 0; t < steps; ++t) {
     if (t > 0) { DX_CS_MARK(0) }
+    if (a.train && t > 0) {
+      e += gridDim.x;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the image's frame (LDS-DMA, below) have landed
+    }
     // conv1's weight fragments travel while conv0 runs: A fragment of v_mfma_f32_16x16x32_bf16 = 8 consecutive k
     // of row (channel) 16 nt + n16: plane pl, tap 8 kh2 + s, k group kq
     u32x4 w1[8][3];
@@ -385,8 +392,9 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (lane0 >> 5));
       DX_CS_MARK(11)
       lds_barrier();  // every wave has read the frame: the y0 planes may overwrite it
-      if (wave < 5) conv0_store<2>(smem, wave, lane0, acc0, bias0);
-      else conv0_store<1>(smem, wave, lane0, acc0, bias0);
+      float *gy0 = a.y0 ? a.y0 + static_cast<long long>(e) * (kP0 * 32) : nullptr;
+      if (wave < 5) conv0_store<2>(smem, wave, lane0, acc0, bias0, gy0);
+      else conv0_store<1>(smem, wave, lane0, acc0, bias0, gy0);
     }
     lds_barrier();  // y0 complete
     DX_CS_MARK(2)
@@ -435,6 +443,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
         const int p = 16 * ((kh2 == 0 ? 0 : 3) + m) + n16;
         const f32x4 v = kh2 == 0 ? finish_tile<0>(red, partner, lane, acc, m, bias1) : finish_tile<3>(red, partner, lane, acc, m, bias1);
         if (p < kP1) store_planes4(smem, oY1 + (p / 9) * kY1R + (p % 9) * kY1P + oc0 * 2, kY1Plane, v);
+        if (a.y1 && p < kP1) *reinterpret_cast<f32x4 *>(a.y1 + static_cast<long long>(e) * (kP1 * 64) + p * 64 + oc0) = v;
       }
       DX_CS_MARK(10)
       lds_barrier();
@@ -479,7 +488,22 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       __builtin_amdgcn_sched_barrier(0);  // (conv2's fragments are dead from here: room for the tail's weights)
       const int p_keep0 = 16 * (kh2 == 0 ? 0 : 2) + n16;
       const int oc0 = 16 * nt + 4 * kq;
-      const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
+      f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
+      if (a.train && t + 1 < steps) {
+        // The NEXT image's frame, straight into the LDS slot conv0 reads (free since y0 died), by LDS-DMA: piece
+        // wave + 8 u is one KB of both.  Nothing this wave loaded is waited for between here and the next step's
+        // top (the compiler would drain the DMA with it): the bias is made to arrive first.
+        asm volatile("" : "+v"(bias2));
+        const int next = e + static_cast<int>(gridDim.x);
+        const uint8_t *src = a.obs + static_cast<long long>(a.sample_idx ? a.sample_idx[next] : next) * kFrameB;
+        const int lane3 = opaque(lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int piece = wave_s + 8 * u;
+          if (piece < 28 && piece * 64 + lane3 < kFrameB / 16)
+            __builtin_amdgcn_global_load_lds(src + 1024 * piece + 16 * lane3, smem + oFrame + 1024 * piece, 16, 0, 0);
+        }
+      }
       // the tail's weights for outputs 0-3 now (under the exchange), for 4-7 after these are used
       f32x4 wc[4][2];
       const unsigned ow = static_cast<unsigned>(lane2 * 16);  // (fragment order: rows of pixels past the image are zero)
@@ -616,6 +640,9 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
              "convstack: the in-kernel tail needs beff, the three outputs and <= 7 actions");
   DX_REQUIRE(a.env == 0 ? a.T == 1 : (a.Wc != nullptr && a.row_stride >= a.B && a.uniforms == nullptr),
              "convstack: T > 1 only against the synthetic env, with the tail in the kernel");
+  DX_REQUIRE(a.train ? (a.env == 0 && a.Wc == nullptr && a.y0 && a.y1 && a.y2 && aligned(a.y0, 16) && aligned(a.y1, 16))
+                     : (a.sample_idx == nullptr && a.y0 == nullptr && a.y1 == nullptr),
+             "convstack: a training forward stores y0, y1 and y2 and has no tail; a rollout step takes no gather");
   if (a.row_stride < a.B) a.row_stride = a.B;
   a.stamps = nullptr;
   a.stamp_step = 0;
@@ -627,7 +654,10 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     configured_device = dev;
   }
-  const int B = a.B;
+  static int cus = 0;
+  if (cus == 0) DX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // a training forward: one workgroup per CU (the LDS holds one image), each walks its share of the minibatch
+  const int B = a.train ? (a.B < cus ? a.B : cus) : a.B;  // workgroups
 #if DX_DIAG
   if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one step (DX_CS_STEP, default 0) of wave DX_CS_DIAG, on stderr (synchronous)
     unsigned long long *dev_stamps = nullptr;

@@ -235,6 +235,11 @@ struct ConvStackArgs {
   uint8_t *resets;
   uint64_t env_seed, env_counter;
   float p_reward, p_reset;
+  // ---- the forward of a TRAINING minibatch: `train` = 1, B images (obs[sample_idx[i]] when sample_idx is given), every
+  // workgroup takes images blockIdx, blockIdx + grid, ...; y0 / y1 (fp32 NHWC, kept for the backward) are stored too ----
+  int train;
+  const int32_t *sample_idx;
+  float *y0, *y1;              // (B, 20, 20, 32), (B, 9, 9, 64)
   int stamp_step;              // DX_DIAG only: the step whose phases are stamped
   unsigned long long *stamps;  // DX_DIAG only (DX_CS_DIAG=1): [B][8] shader-clock stamps of wave 0 (step 0), else NULL
 };
