@@ -228,7 +228,9 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
     }
     if (layer_direct_supported(c, l)) {
       const int st = l == L_C1 ? ST_CONV1_WGRAD : ST_CONV2_WGRAD;
-      const int nwg = wgrad_direct_workgroups(st, B), cap = wgrad_direct_workgroups(st, c->max_batch);
+      // (the bf16 x6 kernels of wgrad_b6.hip hold one image per CU: 256 workgroups; capacity for either family)
+      const int nwg = wgrad_b6_on() ? 256 : wgrad_direct_workgroups(st, B);
+      const int cap = wgrad_direct_workgroups(st, c->max_batch) > 256 ? wgrad_direct_workgroups(st, c->max_batch) : 256;
       if (ms_cap < cap) ms_cap = cap;
       if (B >= wgrad_direct_min_batch()) {
         p.s[l].direct = 1;
@@ -632,6 +634,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       if (plan.s[L_C2].direct) {
         const WgradDirectArgs d{c->y1, c->dy2, c->slabs + plan.s[L_C2].w_off, c->slabs + plan.s[L_C2].b_off,
                                 B, c->h1, c->w1, c->h2, c->w2, 0};
+        if (wgrad_b6_on()) return took("wgrad_b6", launch_wgrad_b6(d, stage, plan.s[L_C2].msplit, s));
         return took("wgrad_direct", launch_wgrad_direct(d, stage, plan.s[L_C2].msplit, s));
       }
       return took("igemm_tn", tn(L_C2, conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), c->dy2, kC2, M2,
@@ -648,6 +651,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       if (plan.s[L_C1].direct) {
         const WgradDirectArgs d{c->y0, c->dy1, c->slabs + plan.s[L_C1].w_off, c->slabs + plan.s[L_C1].b_off,
                                 B, c->h0, c->w0, c->h1, c->w1, 0};
+        if (wgrad_b6_on()) return took("wgrad_b6", launch_wgrad_b6(d, stage, plan.s[L_C1].msplit, s));
         return took("wgrad_direct", launch_wgrad_direct(d, stage, plan.s[L_C1].msplit, s));
       }
       return took("igemm_tn", tn(L_C1, conv_gather(c->y0, nullptr, c->h0, c->w0, kC0, c->h1, c->w1, 2, 4, 4), c->dy1, kC1, M1,

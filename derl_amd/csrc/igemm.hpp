@@ -169,6 +169,9 @@ struct WgradDirectArgs {
 bool wgrad_direct_supported(int IH, int IW, int IC, int OH, int OW, int OC, int KH, int KW, int S);
 int launch_wgrad_direct(const WgradDirectArgs &a, int stage, int nwg, hipStream_t stream);
 int wgrad_direct_workgroups(int stage, long long batch);  // persistent workgroups that fill the chip for this layer
+// the same two weight gradients on the bf16 matrix cores, six exact products per fp32 x fp32 (wgrad_b6.hip)
+bool wgrad_b6_on();
+int launch_wgrad_b6(const WgradDirectArgs &a, int stage, int nwg, hipStream_t stream);
 
 // weight gradient of the 512-wide linear layer (wgrad_fc.hip): slab[slice][512][K] partial sums
 // over `msplit` row slices; the bias gradient partials come from launch_colsum

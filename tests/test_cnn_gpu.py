@@ -27,6 +27,19 @@ def make_engine(num_actions, weights, max_batch=64):
   return eng
 
 
+def layer_by_layer_conv_stack(eng, obs, batch, idx=None):
+  """conv0 / conv1 / conv2 forward as three separate stage launches (dx_cnn_stage: the fp32-MFMA / conv0_b16
+  kernels, whatever route dx_cnn_forward takes): copies of y0, y1, y2."""
+  import ctypes
+  from derl_amd import _lib
+  eng.pack()
+  for stage in range(3):
+    _lib.call("dx_cnn_stage", ctypes.byref(eng.ctx), stage, _lib.ptr(obs), 1, _lib.ptr(idx), batch,
+              _lib.stream_ptr(eng.device))
+  torch.cuda.synchronize()
+  return (eng.y0[:batch * 12800].clone(), eng.y1[:batch * 5184].clone(), eng.y2[:batch * 3136].clone())
+
+
 @pytest.mark.parametrize("num_actions,seed", [(4, 21), (6, 22)])
 def test_forward_matches_reference_golden(num_actions, seed):
   weights = gi.nature_cnn_weights(num_actions, seed)
@@ -344,8 +357,7 @@ def test_image_resident_conv_stack_matches_layer_by_layer_kernels(batch):
   obs_np[-1, -5:] = 0
   obs = torch.from_numpy(obs_np).to(DEV)
   eng = make_engine(4, weights, max_batch=max(batch, 64))
-  eng.forward(obs)
-  want = eng.y2[:batch * 3136].clone()
+  want = layer_by_layer_conv_stack(eng, obs, batch)[2]
   eng.y2.fill_(float("nan"))
   actions = torch.empty(batch, dtype=torch.int64, device=DEV)
   log_prob, values = torch.empty(batch, device=DEV), torch.empty(batch, device=DEV)
@@ -375,6 +387,96 @@ def test_image_resident_conv_stack_matches_layer_by_layer_kernels(batch):
   err_stack = np.abs(got[:n * 3136].cpu().numpy().reshape(n, 3136) - exact).max()
   err_fp32 = np.abs(want[:n * 3136].cpu().numpy().reshape(n, 3136) - exact).max()
   assert err_stack <= max(2.0 * err_fp32, 2e-6 * scale), (err_stack, err_fp32, scale)
+
+
+@pytest.mark.parametrize("batch", [3, 300, 1024])
+def test_training_forward_in_one_launch_matches_the_layer_by_layer_stages(batch):
+  """dx_cnn_forward_trunk on uint8 frames runs the conv stack of the whole minibatch as ONE launch of the
+  image-resident kernel (convstack.hip, `train`: every workgroup walks its share of the images, the next
+  frame arrives by LDS-DMA): y0, y1, y2 -- what the backward reads -- against the three layer-by-layer
+  stages, with the minibatch's gather, more images than workgroups and a ragged share."""
+  from derl_amd import _lib
+  weights = gi.nature_cnn_weights(4, 78)
+  pool = batch + 7
+  obs_np = gi.frames(pool, 41 + batch)
+  obs_np[1, :3] = 255
+  obs_np[-2, -5:] = 0
+  obs = torch.from_numpy(obs_np).to(DEV)
+  idx = torch.randperm(pool, device=DEV)[:batch].to(torch.int32)
+  eng = make_engine(4, weights, max_batch=batch)
+  want = layer_by_layer_conv_stack(eng, obs, batch, idx)
+  for buf in (eng.y0, eng.y1, eng.y2):
+    buf.fill_(float("nan"))
+  eng.forward_trunk(obs, idx)
+  torch.cuda.synchronize()
+  lib = _lib.load()
+  assert [lib.dx_cnn_last_route(i).decode() for i in range(3)] == ["convstack_train"] * 3
+  for got, ref, n in zip((eng.y0, eng.y1, eng.y2), want, (12800, 5184, 3136)):
+    got = got[:batch * n]
+    scale = float(ref.abs().max())
+    nt.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+    flipped = ((got > 0) != (ref > 0)) & (torch.maximum(got, ref) > 1e-4 * scale)
+    assert not bool(flipped.any())
+
+
+_WGRAD_PROBE = """
+import sys, torch
+import torch.nn.functional as F
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/tests/golden")
+import inputs as gi
+from derl_amd.cnn_engine import CnnEngine
+dev = torch.device("cuda")
+torch.manual_seed(11)
+B = 300
+eng = CnnEngine(4, max_batch=B, device=dev)
+eng.load_state_dict(gi.nature_cnn_weights(4, 3))
+obs = torch.from_numpy(gi.frames(B, 9)).to(dev)
+eng.forward(obs)
+eng._ensure_backward()
+eng.dhead[:B * 32].normal_()
+grads = eng.backward(obs).double()
+torch.cuda.synchronize()
+# the same two weight gradients in float64 from the buffers the kernels read (NHWC)
+y0 = eng.y0[:B * 12800].view(B, 20, 20, 32).permute(0, 3, 1, 2).double()
+y1 = eng.y1[:B * 5184].view(B, 9, 9, 64).permute(0, 3, 1, 2).double()
+dy1 = eng.dy1[:B * 5184].view(B, 9, 9, 64).permute(0, 3, 1, 2).double()
+dy2 = eng.dy2[:B * 3136].view(B, 7, 7, 64).permute(0, 3, 1, 2).double()
+w1 = torch.nn.grad.conv2d_weight(y0, (64, 32, 4, 4), dy1, stride=2)
+w2 = torch.nn.grad.conv2d_weight(y1, (64, 64, 3, 3), dy2, stride=1)
+ctx = eng.ctx
+for name, ref, off in (("conv1", w1, ctx.off_w[1]), ("conv2", w2, ctx.off_w[2])):
+  got = grads[off:off + ref.numel()].view_as(ref)
+  print("ERR", name, float((got - ref).abs().max()), float(ref.abs().max()))
+for name, ref, off in (("bias1", dy1.sum((0, 2, 3)), ctx.off_b[1]), ("bias2", dy2.sum((0, 2, 3)), ctx.off_b[2])):
+  got = grads[off:off + 64]
+  print("ERR", name, float((got - ref).abs().max()), float(ref.abs().max()))
+"""
+
+
+def test_bf16_split_weight_gradients_are_as_accurate_as_the_fp32_kernels():
+  """conv1 / conv2 weight gradients on the bf16 matrix cores (wgrad_b6.hip: both operands split exactly into
+  three bf16 terms, six of the nine products) against float64 sums over the very buffers the kernels read:
+  the error must stay at the level of the fp32-MFMA kernels' own (DX_WGRAD_B6=0; the switch is read once
+  per process: one child process per setting)."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  errs = {}
+  for setting in ("0", "1"):
+    env = dict(os.environ)
+    env["DX_WGRAD_B6"] = setting
+    out = subprocess.run([sys.executable, "-c", _WGRAD_PROBE.format(root=root)], env=env, capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    for line in out.stdout.splitlines():
+      if line.startswith("ERR"):
+        _, name, err, scale = line.split()
+        errs[(setting, name)] = (float(err), float(scale))
+  for name in ("conv1", "conv2", "bias1", "bias2"):
+    err_b6, scale = errs[("1", name)]
+    err_fp32 = errs[("0", name)][0]
+    assert err_b6 <= max(2.0 * err_fp32, 2e-6 * scale), (name, err_b6, err_fp32, scale)
 
 
 def test_backward_in_two_parts_equals_whole_backward():
@@ -451,6 +553,7 @@ def test_side_stream_routes_are_bit_identical_to_the_serial_ones():
                                     "DX_WGRAD_DIRECT_MIN_B=1", "DX_NT_DMA=0", "DX_NTP=0",
                                     "DX_FC_FACTORED=0",                           # linear layer + heads layer by layer in updates and rollouts
                                     "DX_CONVSTACK=0", "DX_CONVSTACK=0 DX_FC_FACTORED=0 DX_FC_ROLLOUT=0",  # the rollout's layer-by-layer kernels
+                                    "DX_CONVSTACK_TRAIN=0 DX_WGRAD_B6=0",         # the update's fp32-MFMA conv stages
                                     "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
                                     "DX_BWD_OVERLAP=0 DX_C0_WAVES=4 DX_C0_GROUP4=0"])  # and their serial / round-2 twins
 def test_diagnostic_switches_keep_parity(switch):
@@ -504,7 +607,7 @@ def test_baseline_minibatches_take_the_fast_kernel_families():
     got = routes(batch)
     for name in ring:
       assert got[name] == "ntp", (batch, name, got)
-    assert got["conv2_wgrad"] == got["conv1_wgrad"] == "wgrad_direct", (batch, got)
+    assert got["conv2_wgrad"] == got["conv1_wgrad"] == "wgrad_b6", (batch, got)
     assert got["fc_wgrad"] == "wgrad_fc", (batch, got)
     assert got["conv0_fwd"] == got["conv0_wgrad"] == "conv0_b16", (batch, got)
   assert routes(8192)["fc_fwd"] == "ntp"
