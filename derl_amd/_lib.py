@@ -15,7 +15,7 @@ if os.environ.get("DERL_AMD_LIBRARY", "") == "diag":
   LIB_PATH = os.path.join(_PKG, "libderl_amd_diag.so")
 elif os.environ.get("DERL_AMD_LIBRARY", "").endswith(".so"):  # another build of the library (tools/: A/B on one box)
   LIB_PATH = os.path.join(_PKG, os.path.basename(os.environ["DERL_AMD_LIBRARY"]))
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_int, c_float, c_void_p, c_char_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p
 c_size_t, c_int64, c_uint64, c_double = ctypes.c_size_t, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
@@ -99,7 +99,7 @@ class CnnCtx(ctypes.Structure):
                                           "y0_count", "y1_count", "y2_count", "hid_count", "head_count",
                                           "hid_slab_count", "pb_c1f", "pb_c2f", "pb_fcf", "pb_c1d",
                                           "pb_c2d", "pb_fcd", "pb_c0f", "pk_wc", "pk_beff", "pk_wcs", "ps_c1f",
-                                          "ps_c2f", "ps_wc")]
+                                          "ps_c2f", "ps_wc", "ps_c1d", "ps_c2d")]
       + [(n, c_void_p) for n in ("params", "grads", "packed", "y0", "y1", "y2", "hid", "head",
                                  "dy0", "dy1", "dy2", "dhid", "dhead", "slabs", "hid_slabs")])
 _RESTYPES = {"dx_last_error": c_char_p, "dx_launch_count": c_longlong, "dx_cnn_last_route": c_char_p}

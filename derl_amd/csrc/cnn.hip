@@ -294,6 +294,7 @@ int dx_cnn_init(dx_cnn_ctx *c) {
   c->pk_wcs = take(tail_supported(d.flat, A) ? tail_pack_scratch_floats() : 0);
   c->ps_c1f = take(convstack_pack_elems(0) / 2); c->ps_c2f = take(convstack_pack_elems(1) / 2);
   c->ps_wc = take(convstack_pack_elems(2));
+  c->ps_c1d = take(dgrad_b6_pack_elems(1) / 2); c->ps_c2d = take(dgrad_b6_pack_elems(2) / 2);
   c->packed_count = po;
   c->slab_count = make_plan(c, c->max_batch).total;
   const long long mb = c->max_batch;
@@ -340,6 +341,9 @@ static bool convstack_train_env() {
     on = e ? atoi(e) : 1;
   }
   return on != 0;
+}
+static bool dgrad_b6_usable(const dx_cnn_ctx *c) {  // (the kernels are built for the conv stack of an 84 x 84 observation)
+  return dgrad_b6_on() && c->h0 == 20 && c->w0 == 20 && c->h1 == 9 && c->w1 == 9 && c->h2 == 7 && c->w2 == 7;
 }
 static bool fc_factored(const dx_cnn_ctx *c) { return fc_factored_env() && tail_supported(c->flat, c->num_actions); }
 
@@ -404,6 +408,10 @@ static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s, bool light = 
   // (conv0 / conv1 / conv2: operands of the rollout's one-launch conv stack, convstack.hip)
   const int first = (part & 1) ? 0 : 1, count = (use_b3() ? 7 : 3) - first;
   if (int rc = launch_split_planes(src + first, dst + first, cnt + first, count, s)) return rc;
+  if (dgrad_b6_usable(c)) {  // the data-gradient kernels' fragment-order planes, from the fp32 mirrors packed above
+    const float *c1d[4] = {pk + c->pk_c1d[0], pk + c->pk_c1d[1], pk + c->pk_c1d[2], pk + c->pk_c1d[3]};
+    if (int rc = launch_dgrad_b6_pack(c1d, pk + c->pk_c2d, planes(c, c->ps_c1d), planes(c, c->ps_c2d), s)) return rc;
+  }
   // the conv-stack kernel's fragment-order copies (only the rollout reads them: not between an epoch's updates)
   if ((!light || convstack_train_env()) && convstack_supported(c->in_h, c->in_w, c->in_c))
     return launch_convstack_pack(planes(c, c->pb_c1f), planes(c, c->pb_c2f), fc_factored(c) ? pk + c->pk_wc : nullptr,
@@ -640,6 +648,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       return took("igemm_tn", tn(L_C2, conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), c->dy2, kC2, M2,
                                   kC2, 9 * kC1, false));
     case ST_CONV2_DGRAD:
+      if (dgrad_b6_usable(c)) return took("dgrad_b6", launch_dgrad_b6(2, c->dy2, planes(c, c->ps_c2d), c->y1, c->dy1, B, s));
       a = nt_args(dgrad_gather(c->dy2, c->h2, c->w2, kC2, c->h1, c->w1, 3, 3), pk + c->pk_c2d, nullptr,
                   c->dy1, kC1, M1, kC1, 9 * kC2);
       a.Wb = planes(c, c->pb_c2d); a.wb_plane = kC2 * 9LL * kC1;
@@ -662,6 +671,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       // share one gathered A matrix: one GEMM with N = 4 x 32 columns [(py,px)][ic], scattered
       // to the 2x2 pixel block by the output map.
       const int OHp = (c->h0 + 1) / 2, OWp = (c->w0 + 1) / 2;
+      if (dgrad_b6_usable(c)) return took("dgrad_b6", launch_dgrad_b6(1, c->dy1, planes(c, c->ps_c1d), c->y0, c->dy0, B, s));
       a = nt_args(dgrad_gather(c->dy1, c->h1, c->w1, kC1, OHp, OWp, 2, 2), pk + c->pk_c1d[0], nullptr,
                   c->dy0, kC0, static_cast<long long>(B) * OHp * OWp, 4 * kC0, 4 * kC1);
       a.Wb = planes(c, c->pb_c1d); a.wb_plane = kC1 * 16LL * kC0;

@@ -170,6 +170,11 @@ bool wgrad_direct_supported(int IH, int IW, int IC, int OH, int OW, int OC, int 
 int launch_wgrad_direct(const WgradDirectArgs &a, int stage, int nwg, hipStream_t stream);
 int wgrad_direct_workgroups(int stage, long long batch);  // persistent workgroups that fill the chip for this layer
 // the same two weight gradients on the bf16 matrix cores, six exact products per fp32 x fp32 (wgrad_b6.hip)
+// conv1 / conv2 data gradients the same way, image-resident (dgrad_b6.hip)
+bool dgrad_b6_on();
+long long dgrad_b6_pack_elems(int layer);
+int launch_dgrad_b6_pack(const float *const c1d[4], const float *c2d, uint16_t *Wf1, uint16_t *Wf2, hipStream_t stream);
+int launch_dgrad_b6(int layer, const float *g, const uint16_t *Wf, const float *mask_src, float *out, int B, hipStream_t stream);
 bool wgrad_b6_on();
 int launch_wgrad_b6(const WgradDirectArgs &a, int stage, int nwg, hipStream_t stream);
 

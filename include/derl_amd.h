@@ -40,7 +40,7 @@ extern "C" {
 #define DX_EWS (-4)      /* workspace too small                                     */
 #define DX_ETIMEOUT (-5) /* a persistent kernel's grid barrier gave up (dx_mlp_ppo_epoch) */
 
-#define DX_ABI_VERSION 4
+#define DX_ABI_VERSION 5
 
 int dx_abi_version(void);
 const char *dx_last_error(void);
@@ -243,6 +243,8 @@ typedef struct dx_cnn_ctx {
   /* the rollout's conv-stack kernel (csrc/convstack.hip) reads conv1 / conv2's bf16 planes and Wc from
    * copies in ITS waves' fragment order (one contiguous KB per wave load) -- offsets in floats */
   long long ps_c1f, ps_c2f, ps_wc;
+  /* conv1 / conv2 data-gradient weights, three bf16 planes in the fragment order of csrc/dgrad_b6.hip */
+  long long ps_c1d, ps_c2d;
   /* ---- device buffers (caller-allocated, fp32) ---- */
   float *params, *grads;            /* param_count */
   float *packed;                    /* packed_count; ZERO-FILLED once by the owner: dx_cnn_pack
