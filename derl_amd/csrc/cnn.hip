@@ -846,7 +846,10 @@ int dx_cnn_heads_loss_f32(const dx_cnn_ctx *c, const int64_t *actions, const flo
 // (minibatch 1024) 11.53 -> 11.61 ms -- there a stage is a single short round of tiles and the
 // extra event traffic costs more than the overlap returns.  -1 (default) = for minibatches of at
 // least DX_BWD_OVERLAP_MIN (2048) samples; 0 = never, 1 = always.  The kernels and their results
-// are the same either way.
+// are the same either way.  Round 4: with the image-resident bf16 kernels (wgrad_b6.hip, dgrad_b6.hip) every conv
+// stage of the backward holds one workgroup per CU with most of its LDS -- two of them cannot share a CU, and
+// the side stream returned nothing (23.8 vs 23.6-23.8 ms per iteration, alternating): the default then is
+// the serial order.
 static bool bwd_overlap(int B) {
   static int mode = -2, limit = 0;
   if (mode == -2) {
@@ -855,7 +858,7 @@ static bool bwd_overlap(int B) {
     limit = m ? atoi(m) : 2048;
     mode = e ? atoi(e) : -1;
   }
-  return mode == 1 || (mode == -1 && B >= limit);
+  return mode == 1 || (mode == -1 && B >= limit && !(wgrad_b6_on() && dgrad_b6_on()));
 }
 
 // Stages first .. last of the backward on `s`, the overlapped ones on the side stream, then the

@@ -442,30 +442,38 @@ y0 = eng.y0[:B * 12800].view(B, 20, 20, 32).permute(0, 3, 1, 2).double()
 y1 = eng.y1[:B * 5184].view(B, 9, 9, 64).permute(0, 3, 1, 2).double()
 dy1 = eng.dy1[:B * 5184].view(B, 9, 9, 64).permute(0, 3, 1, 2).double()
 dy2 = eng.dy2[:B * 3136].view(B, 7, 7, 64).permute(0, 3, 1, 2).double()
-w1 = torch.nn.grad.conv2d_weight(y0, (64, 32, 4, 4), dy1, stride=2)
-w2 = torch.nn.grad.conv2d_weight(y1, (64, 64, 3, 3), dy2, stride=1)
+gw1 = torch.nn.grad.conv2d_weight(y0, (64, 32, 4, 4), dy1, stride=2)
+gw2 = torch.nn.grad.conv2d_weight(y1, (64, 64, 3, 3), dy2, stride=1)
 ctx = eng.ctx
-for name, ref, off in (("conv1", w1, ctx.off_w[1]), ("conv2", w2, ctx.off_w[2])):
+for name, ref, off in (("conv1", gw1, ctx.off_w[1]), ("conv2", gw2, ctx.off_w[2])):
   got = grads[off:off + ref.numel()].view_as(ref)
   print("ERR", name, float((got - ref).abs().max()), float(ref.abs().max()))
 for name, ref, off in (("bias1", dy1.sum((0, 2, 3)), ctx.off_b[1]), ("bias2", dy2.sum((0, 2, 3)), ctx.off_b[2])):
   got = grads[off:off + 64]
   print("ERR", name, float((got - ref).abs().max()), float(ref.abs().max()))
+# the two data gradients: float64 transposed convolutions of the gradient buffers, masked by the layer inputs
+sd = gi.nature_cnn_weights(4, 3)
+w1, w2 = (torch.from_numpy(sd["base.conv-%d.weight" % i]).double().to(dev) for i in (1, 2))
+ref1 = torch.nn.grad.conv2d_input((B, 64, 9, 9), w2, dy2, stride=1) * (y1 > 0)
+ref0 = torch.nn.grad.conv2d_input((B, 32, 20, 20), w1, dy1, stride=2) * (y0 > 0)
+got0 = eng.dy0[:B * 12800].view(B, 20, 20, 32).permute(0, 3, 1, 2).double()
+print("ERR", "dgrad2", float((dy1 - ref1).abs().max()), float(ref1.abs().max()))
+print("ERR", "dgrad1", float((got0 - ref0).abs().max()), float(ref0.abs().max()))
 """
 
 
-def test_bf16_split_weight_gradients_are_as_accurate_as_the_fp32_kernels():
-  """conv1 / conv2 weight gradients on the bf16 matrix cores (wgrad_b6.hip: both operands split exactly into
-  three bf16 terms, six of the nine products) against float64 sums over the very buffers the kernels read:
-  the error must stay at the level of the fp32-MFMA kernels' own (DX_WGRAD_B6=0; the switch is read once
-  per process: one child process per setting)."""
+def test_bf16_split_gradients_are_as_accurate_as_the_fp32_kernels():
+  """conv1 / conv2 weight and data gradients on the bf16 matrix cores (wgrad_b6.hip, dgrad_b6.hip: both
+  operands split exactly into three bf16 terms, six of the nine products) against float64 sums over the very
+  buffers the kernels read: the error must stay at the level of the fp32-MFMA kernels' own (DX_WGRAD_B6=0
+  DX_DGRAD_B6=0; the switches are read once per process: one child process per setting)."""
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   errs = {}
   for setting in ("0", "1"):
     env = dict(os.environ)
-    env["DX_WGRAD_B6"] = setting
+    env["DX_WGRAD_B6"] = env["DX_DGRAD_B6"] = setting
     out = subprocess.run([sys.executable, "-c", _WGRAD_PROBE.format(root=root)], env=env, capture_output=True,
                          text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -473,7 +481,7 @@ def test_bf16_split_weight_gradients_are_as_accurate_as_the_fp32_kernels():
       if line.startswith("ERR"):
         _, name, err, scale = line.split()
         errs[(setting, name)] = (float(err), float(scale))
-  for name in ("conv1", "conv2", "bias1", "bias2"):
+  for name in ("conv1", "conv2", "bias1", "bias2", "dgrad1", "dgrad2"):
     err_b6, scale = errs[("1", name)]
     err_fp32 = errs[("0", name)][0]
     assert err_b6 <= max(2.0 * err_fp32, 2e-6 * scale), (name, err_b6, err_fp32, scale)
@@ -553,7 +561,7 @@ def test_side_stream_routes_are_bit_identical_to_the_serial_ones():
                                     "DX_WGRAD_DIRECT_MIN_B=1", "DX_NT_DMA=0", "DX_NTP=0",
                                     "DX_FC_FACTORED=0",                           # linear layer + heads layer by layer in updates and rollouts
                                     "DX_CONVSTACK=0", "DX_CONVSTACK=0 DX_FC_FACTORED=0 DX_FC_ROLLOUT=0",  # the rollout's layer-by-layer kernels
-                                    "DX_CONVSTACK_TRAIN=0 DX_WGRAD_B6=0",         # the update's fp32-MFMA conv stages
+                                    "DX_CONVSTACK_TRAIN=0 DX_WGRAD_B6=0 DX_DGRAD_B6=0",  # the update's fp32-MFMA conv stages
                                     "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
                                     "DX_BWD_OVERLAP=0 DX_C0_WAVES=4 DX_C0_GROUP4=0"])  # and their serial / round-2 twins
 def test_diagnostic_switches_keep_parity(switch):
@@ -602,17 +610,19 @@ def test_baseline_minibatches_take_the_fast_kernel_families():
     torch.cuda.synchronize()
     return {name: lib.dx_cnn_last_route(i).decode() for i, name in enumerate(stages)}
 
-  ring = ("conv1_fwd", "conv2_fwd", "fc_dgrad", "conv2_dgrad", "conv1_dgrad")
+  ring = ("conv1_fwd", "conv2_fwd", "fc_dgrad")
   for batch in (8192, 2048, 1024):
     got = routes(batch)
     for name in ring:
       assert got[name] == "ntp", (batch, name, got)
     assert got["conv2_wgrad"] == got["conv1_wgrad"] == "wgrad_b6", (batch, got)
+    assert got["conv2_dgrad"] == got["conv1_dgrad"] == "dgrad_b6", (batch, got)
     assert got["fc_wgrad"] == "wgrad_fc", (batch, got)
     assert got["conv0_fwd"] == got["conv0_wgrad"] == "conv0_b16", (batch, got)
   assert routes(8192)["fc_fwd"] == "ntp"
-  ragged = routes(8192 - 64)  # 63.5 groups of 128 images: the dgrad tiles (one pixel x 128 images) do not exist
-  assert all(ragged[name] != "ntp" for name in ("fc_dgrad", "conv2_dgrad", "conv1_dgrad")), ragged
+  ragged = routes(8192 - 64)  # 63.5 groups of 128 images: the ring's dgrad tiles (one pixel x 128 images) do not exist
+  assert ragged["fc_dgrad"] != "ntp", ragged
+  assert ragged["conv2_dgrad"] == ragged["conv1_dgrad"] == "dgrad_b6", ragged  # (image-resident: any batch)
   # (the forward stages tile output PIXELS and still find whole 64-row tiles: they stay on the ring)
 
 
