@@ -39,10 +39,25 @@ FACTORED_STAGES = ["conv0_fwd", "conv1_fwd", "conv2_fwd", "tail_loss", "tail_bwd
 MACS = dict(conv0=3_276_800, conv1=2_654_208, conv2=1_806_336, fc=1_605_632)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak
-# stages that run on the bf16 matrix cores: uint8 pixels are exact in bf16 and the fp32 operand is
-# split exactly into three bf16 terms, so they EXECUTE 3 bf16 flops per algorithmic fp32 flop
-BF16X3_STAGES = ("conv0_fwd", "conv0_wgrad")
+# Kernel families that run on the bf16 matrix cores, by the route dx_cnn_last_route reports, with the bf16
+# products they EXECUTE per algorithmic fp32 product: the first conv layer's uint8 pixels are exact in bf16
+# and the fp32 side splits exactly into three bf16 terms (3); conv1 / conv2 split BOTH fp32 operands and
+# multiply the six products above 2^-23 of x w (6).
+BF16_TERMS = {"conv0_b16": 3.0, "wgrad_b6": 6.0, "dgrad_b6": 6.0}
+CONV_STACK_FWD = "conv_stack_fwd"  # the training forward's three conv layers as ONE launch (route convstack_train)
 PEAK_HBM_GBPS = 8000.0
+
+
+def executed_flops(name, route, batch, num_actions):
+  """(flops the matrix cores execute for `name` on `route`, the peak they are priced at, a description)."""
+  if name == CONV_STACK_FWD:
+    fl = 2.0 * batch * (3.0 * MACS["conv0"] + 6.0 * (MACS["conv1"] + MACS["conv2"]))
+    return fl, PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA: conv0 x3 (exact split), conv1 / conv2 x6 (both operands split)"
+  terms = BF16_TERMS.get(route)
+  fl = stage_flops(name, batch, num_actions)
+  if terms and fl:
+    return terms * fl, PEAK_BF16_MFMA_TFLOPS, f"bf16 MFMA x{terms:g} (exact 3-term split{'s of both operands' if terms == 6 else ''})"
+  return fl, PEAK_F32_MFMA_TFLOPS, "fp32 MFMA" if fl else ""
 
 
 PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
@@ -64,6 +79,8 @@ def pmc_traffic(stage, minibatch):
 
 
 def stage_flops(name, batch, num_actions):
+  if name == CONV_STACK_FWD:
+    return 2.0 * (MACS["conv0"] + MACS["conv1"] + MACS["conv2"]) * batch
   layer = name.split("_")[0]
   if layer == "heads":
     return 2.0 * (num_actions + 1) * 512 * batch
@@ -87,7 +104,10 @@ def time_stages(model, obs, idx, batch, iters=10):
   stream = _lib.stream_ptr(eng.device)
   lib = _lib.load()
   factored = bool(lib.dx_cnn_tail_factored(ctypes.byref(eng.ctx)))
-  names = FACTORED_STAGES if factored else STAGES
+  names = list(FACTORED_STAGES if factored else STAGES)
+  eng.forward_trunk(obs, idx)
+  if factored and lib.dx_cnn_last_route(0).decode() == "convstack_train":  # conv0 / conv1 / conv2 forward are one launch
+    names = [CONV_STACK_FWD] + names[3:]
   dev = eng.device
   actions = torch.randint(0, eng.num_actions, (batch,), dtype=torch.int64, device=dev)
   zeros = torch.zeros(batch, device=dev)
@@ -96,7 +116,9 @@ def time_stages(model, obs, idx, batch, iters=10):
   terms = torch.empty(8, device=dev)
 
   def launch(name):
-    if name == "tail_loss":
+    if name == CONV_STACK_FWD:
+      _lib.call("dx_cnn_forward_trunk", ctypes.byref(eng.ctx), _lib.ptr(obs), is_u8, _lib.ptr(idx), batch, stream)
+    elif name == "tail_loss":
       eng.heads_loss(batch, actions, zeros, adv, zeros, zeros, 0, 0.1, 0.25, 0.01, batch, partials, terms)
     elif name == "tail_bwd":
       _lib.call("dx_cnn_backward_part", ctypes.byref(eng.ctx), _lib.ptr(obs), is_u8, _lib.ptr(idx), batch, 2, stream)
@@ -125,8 +147,8 @@ def time_stages(model, obs, idx, batch, iters=10):
       marks[it][k + 1].record()
   torch.cuda.synchronize()
   time_stages.names = names
-  time_stages.routes = {name: lib.dx_cnn_last_route(STAGE_IDS.index(name)).decode() if name in STAGE_IDS else "tail_factored"
-                        for name in names}
+  time_stages.routes = {name: lib.dx_cnn_last_route(STAGE_IDS.index(name)).decode() if name in STAGE_IDS
+                        else "convstack_train" if name == CONV_STACK_FWD else "tail_factored" for name in names}
   return {name: sum(marks[it][k].elapsed_time(marks[it][k + 1]) for it in range(iters)) * 1e3 / iters
           for k, name in enumerate(names)}
 
@@ -276,11 +298,11 @@ def main():
                  "allreduce_bytes_per_update": allreduce_bytes,
                  "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 3),
                  "host_enqueue_ms_unblocked": round(host_unblocked_s * 1e3, 3),
-                 "arithmetic": "updates: conv1 / conv2 stages on fp32 MFMA (v_mfma_f32_32x32x2_f32), first conv layer on bf16 "
-                               "MFMA with exact operands (uint8 pixels, exact 3-term bf16 split of the fp32 side); "
-                               "linear layer + heads as one affine map of y2 (fp32 vector ALU, HBM-bound); rollout: all "
-                               "three conv layers on bf16 MFMA (conv1 / conv2: both operands split exactly into three "
-                               "bf16 terms, the six products above 2^-23 of x w); fp32 accumulation everywhere",
+                 "arithmetic": "every conv stage of updates and rollouts on bf16 MFMA at fp32 accuracy: first conv layer with "
+                               "exact operands (uint8 pixels, exact 3-term bf16 split of the fp32 side: 3 products), conv1 / "
+                               "conv2 forward, data and weight gradients with BOTH fp32 operands split exactly into three "
+                               "bf16 terms and the six products above 2^-23 of x w (v_mfma_f32_16x16x32_bf16); linear layer "
+                               "+ heads as one affine map of y2 (fp32 vector ALU, HBM-bound); fp32 accumulation everywhere",
                  "final_loss": float(alg.loss_fn.last_terms[0].item())},
   }
 
@@ -301,7 +323,15 @@ def main():
   # loss pass, read again and dy2 written by the backward pass)
   roll = 1.0 + 1.0 / args.nsteps
   epochs = kwargs["num_epochs"]
-  f32_mflop = 2e-6 * (MACS["conv1"] + MACS["conv2"]) * (roll + 3.0 * epochs)
+  lib_ = _lib.load()
+  route = {n: lib_.dx_cnn_last_route(i).decode() for i, n in enumerate(STAGE_IDS)}  # what the timed loop's last update took
+  # conv1 / conv2: the rollout forward always on bf16 x6 (conv-stack kernel); per epoch the forward, the data
+  # gradient and the weight gradient each on bf16 x6 or on fp32 MFMA, by route
+  c12 = 2e-6 * (MACS["conv1"] + MACS["conv2"])
+  b6_parts = sum(1.0 for fam in ("fwd", "dgrad", "wgrad")
+                 if route.get(f"conv1_{fam}", "") in ("convstack_train", "dgrad_b6", "wgrad_b6"))
+  f32_mflop = c12 * epochs * (3.0 - b6_parts)
+  bf16x6_mflop = 6.0 * c12 * (roll + epochs * b6_parts)
   bf16_mflop = 3.0 * 2e-6 * MACS["conv0"] * (roll + 2.0 * epochs)
   tail_mflop = 2e-6 * (MACS["fc"] + A1 * 512) * (roll + 3.0 * epochs)
   hbm_bytes = 0.0
@@ -312,21 +342,23 @@ def main():
   else:
     executed_tail_mflop = tail_mflop
     f32_s = (f32_mflop + tail_mflop) / (PEAK_F32_MFMA_TFLOPS * 1e6)
-  floor_s = f32_s + bf16_mflop / (PEAK_BF16_MFMA_TFLOPS * 1e6) + hbm_bytes / (PEAK_HBM_GBPS * 1e9)
+  floor_s = f32_s + (bf16_mflop + bf16x6_mflop) / (PEAK_BF16_MFMA_TFLOPS * 1e6) + hbm_bytes / (PEAK_HBM_GBPS * 1e9)
   composite = 1.0 / floor_s * world
   result["iteration_roofline"] = {
       "bound": "mfma", "algorithmic_mflop_per_env_step": round(per_step_mflop, 1),
       "bound_env_steps_per_s": round(bound, 1), "frac": round(value / bound, 4),
       "note": "fp32-MFMA peak x n_gpus / the flops per env step of the reference's layer-by-layer association "
-              "(SURVEY.md 8d); a reference line, NOT a ceiling: the first conv layer runs on bf16 MFMA and, "
-              "when `linear_layer_and_heads` says factored, the linear layer + heads cost (A + 1) x 3136 "
-              "multiplies per sample instead of 512 x 3136 -- `composite` prices what is executed",
+              "(SURVEY.md 8d); a reference line, NOT a ceiling: the conv layers run on bf16 MFMA (3 resp. 6 exact "
+              "bf16 products per fp32 product) and, when `linear_layer_and_heads` says factored, the linear layer + "
+              "heads cost (A + 1) x 3136 multiplies per sample instead of 512 x 3136 -- `composite` prices what is "
+              "executed, each part at the nameplate peak of the unit it runs on",
       "linear_layer_and_heads": ("factored: ONE affine map of y2 (derl/models.py:112-115 has no activation behind "
                                  "the linear layer), Wc = Wh Wfc; same outputs and gradients, other association"
                                  if factored else "layer by layer"),
       "composite": {
           "executed_mflop_per_env_step": {"fp32_mfma": round(f32_mflop + (0.0 if factored else tail_mflop), 2),
                                           "bf16_mfma_3x": round(bf16_mflop, 2),
+                                          "bf16_mfma_6x": round(bf16x6_mflop, 2),
                                           "linear_layer_and_heads": round(executed_tail_mflop, 3)},
           "hbm_bytes_per_env_step_of_the_factored_tail": round(hbm_bytes, 1),
           "peaks": {"fp32_mfma_TFLOPs": PEAK_F32_MFMA_TFLOPS, "bf16_mfma_TFLOPs": PEAK_BF16_MFMA_TFLOPS,
@@ -382,21 +414,22 @@ def main():
     fwd_flops = sum(stage_flops(n, nenvs, A) for n in STAGE_IDS if n.endswith("_fwd"))
     # dominant kernel = the training stage with the largest share of a PPO iteration
     # (updates take ~80 % of the iteration; every stage is its own kernel symbol)
+    routes = getattr(time_stages, "routes", {})
     flop_stages = [n for n in names if stage_flops(n, 1, A) > 0 and not n.startswith("heads")]
     dominant = max(flop_stages, key=lambda n: train[n])
-    tf = stage_flops(dominant, mb, A) / (train[dominant] * 1e-6) / 1e12
-    peak = PEAK_F32_MFMA_TFLOPS
-    if dominant in BF16X3_STAGES:  # priced on what the matrix cores execute
-      tf, peak = 3.0 * tf, PEAK_BF16_MFMA_TFLOPS
+    dom_fl, peak, dom_how = executed_flops(dominant, routes.get(dominant, ""), mb, A)
+    tf = dom_fl / (train[dominant] * 1e-6) / 1e12
 
     def stage_row(n):
       fl = stage_flops(n, mb, A)
-      row = {"route": getattr(time_stages, "routes", {}).get(n, ""),
+      row = {"route": routes.get(n, ""),
              "train_us": round(train[n], 1),
              "train_TFLOPs": round(fl / (train[n] * 1e-6) / 1e12, 2) if fl else None,
              "us_per_iteration": round(train[n] * updates_per_iter, 1)}
-      if n in BF16X3_STAGES:
-        row["mfma"] = "bf16 x3 (exact split); train_TFLOPs counts algorithmic fp32 flops"
+      ex, pk, how = executed_flops(n, routes.get(n, ""), mb, A)
+      if fl:  # train_TFLOPs counts algorithmic fp32 flops; executed = what the matrix cores multiply
+        row.update(mfma=how, executed_TFLOPs=round(ex / (train[n] * 1e-6) / 1e12, 1), peak_TFLOPs=pk,
+                   frac=round(ex / (train[n] * 1e-6) / 1e12 / pk, 4))
       if n in ("tail_loss", "tail_bwd"):  # HBM passes over y2 (+ dy2 and the partial G slabs for tail_bwd)
         nbytes = mb * 3136 * 4 * (1 if n == "tail_loss" else 2) + (0 if n == "tail_loss" else 2 * 256 * (A + 1) * 3136 * 4)
         row.update(bound="hbm", algorithmic_bytes=nbytes, GBps=round(nbytes / (train[n] * 1e-6) / 1e9, 1),
@@ -408,17 +441,19 @@ def main():
     total_flops = sum(stage_flops(n, mb, A) for n in STAGE_IDS)
     total_us = sum(train[n] for n in names)
     result["roofline"] = {
-        "bound": "mfma", "kernel": f"{dominant} (minibatch {mb})",
+        "bound": "mfma", "kernel": f"{dominant} (minibatch {mb}; {dom_how})",
         "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(tf / peak, 4), "traffic": pmc_traffic(dominant, mb)[0],
         "traffic_source": f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes) taken at "
                           f"commit {pmc_traffic(dominant, mb)[1]}",
-        "timing": "HIP events around each stage launched alone (the stage table below).  In the training loop "
-                  "the weight-gradient stages of the linear layer / conv2 / conv1 run on a side stream beside "
-                  "the data-gradient chain (DX_BWD_OVERLAP, minibatches >= 2048), so rocprofv3's per-kernel "
-                  "averages of the default command contain launches that shared the chip; the same command "
-                  "with DX_BWD_OVERLAP=0 gives the stand-alone averages "
-                  "(profiles/r04_*_bench_kernel_stats.csv / r04_*_bench_kernel_stats_serial.csv)",
+        "power": "every bf16 stage of the update runs AT the 1.4 kW package limit (tools/power_probe.py): bare "
+                 "v_mfma_f32_16x16x32_bf16 loops with operands in registers sustain 2.15 PFLOP/s at 1.3 kW and 2.05 GHz "
+                 "on this part (tools/ubench/mfma_power.hip: 1.22 pJ per bf16 multiply-add against 14.7 pJ for "
+                 "v_mfma_f32_32x32x2_f32), so `frac` of the 2.5 PFLOP/s nameplate cannot exceed ~0.88",
+        "timing": "HIP events around each stage launched in pipeline order (the stage table below); the training "
+                  "loop launches the same kernels on one stream (the weight-gradient side stream is off while the "
+                  "image-resident bf16 stages hold one workgroup per CU), so rocprofv3's per-kernel averages of the "
+                  "default command are stand-alone averages (profiles/r04_*_bench_kernel_stats.csv)",
         "network_fwd_bwd": {"us": round(total_us, 1),
                             "achieved": round(total_flops / (total_us * 1e-6) / 1e12, 2),
                             "frac": round(total_flops / (total_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

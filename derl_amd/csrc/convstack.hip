@@ -666,7 +666,8 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
     const int stamp_wave = atoi(getenv("DX_CS_DIAG")) & 7;
     a.env0 |= stamp_wave << 24;  // (timing build only: sampling positions are not what is looked at)
     a.stamp_step = getenv("DX_CS_STEP") ? atoi(getenv("DX_CS_STEP")) : 0;
-    if (a.stamp_step >= a.T) a.stamp_step = a.T - 1;
+    const int steps = a.train ? a.B / B : a.T;  // (training: images per workgroup)
+    if (a.stamp_step >= steps) a.stamp_step = steps - 1;
     hipLaunchKernelGGL(convstack_image_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
     DX_LAUNCH_CHECK();
     DX_HIP(hipStreamSynchronize(stream));

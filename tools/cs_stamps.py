@@ -1,5 +1,6 @@
 """In-kernel phase stamps of the rollout's conv-stack kernel (diag flavour).
-usage: [DX_CS_DIAG=<wave>] [DX_CS_STEP=<t>] python3 tools/cs_stamps.py [batch [horizon]]   (horizon > 1: the native rollout)"""
+usage: [DX_CS_DIAG=<wave>] [DX_CS_STEP=<t>] python3 tools/cs_stamps.py [batch [horizon]]   (horizon > 1: the native rollout;
+horizon 0: the forward of a training minibatch of `batch` images, step = the workgroup's t-th image)"""
 import os
 import sys
 
@@ -16,7 +17,12 @@ eng = CnnEngine(4, max_batch=max(batch, 64), device=dev)
 with torch.no_grad():
   eng.params.normal_(0, 0.02)
 eng.mark_dirty()
-if horizon == 1:
+if horizon == 0:
+  obs = torch.randint(0, 256, (batch, 84, 84, 4), dtype=torch.uint8, device=dev)
+  idx = torch.randperm(batch, device=dev).to(torch.int32)
+  for _ in range(3):
+    eng.forward_trunk(obs, idx)
+elif horizon == 1:
   obs = torch.randint(0, 256, (batch, 84, 84, 4), dtype=torch.uint8, device=dev)
   actions = torch.empty(batch, dtype=torch.int64, device=dev)
   log_prob, values = torch.empty(batch, device=dev), torch.empty(batch, device=dev)

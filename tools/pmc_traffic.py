@@ -26,8 +26,13 @@ STAGE_OF = [  # substring of the kernel name -> stage
     ("fc_row_unpermute_reduce", "finalize_fc"),
     # the factored tail (csrc/tail.hip, heads.hip) and the rollout's one-kernel step (csrc/convstack.hip)
     ("tail_loss_kernel", "tail_loss"), ("tail_bwd_kernel", "tail_bwd"), ("tail_greduce_kernel", "tail_greduce"),
-    ("tail_grads_kernel", "tail_grads"), ("convstack_image_kernel", "rollout_step (convstack, 256 images, one step)"),
+    ("tail_grads_kernel", "tail_grads"),
+    # round 4: the update's conv stages on the bf16 matrix cores (convstack.hip `train`, wgrad_b6.hip, dgrad_b6.hip)
+    ("convstack_image_kernel", "conv_stack_fwd"),
+    ("conv_wgrad_b6_kernel<1>", "conv1_wgrad"), ("conv_wgrad_b6_kernel<2>", "conv2_wgrad"),
+    ("conv_dgrad_b6_kernel<1>", "conv1_dgrad"), ("conv_dgrad_b6_kernel<2>", "conv2_dgrad"),
 ]
+ROLLOUT_STEP = "rollout_step (convstack, 256 images, one step)"
 
 
 def mean_per_kernel(root, counter):
@@ -45,14 +50,14 @@ def mean_per_kernel(root, counter):
 def main(fetch_dir, write_dir, out_path, commit=None, act_fetch_dir=None, act_write_dir=None):
   fetch = mean_per_kernel(fetch_dir, "FETCH_SIZE")
   write = mean_per_kernel(write_dir, "WRITE_SIZE")
-  if act_fetch_dir and act_write_dir:  # the passes over tools/act_bench.py 256 (the rollout's act step)
-    for k, v in mean_per_kernel(act_fetch_dir, "FETCH_SIZE").items():
-      if "convstack" in k:
-        fetch[k] = v
-    for k, v in mean_per_kernel(act_write_dir, "WRITE_SIZE").items():
-      if "convstack" in k:
-        write[k] = v
   stages = {}
+  if act_fetch_dir and act_write_dir:  # the passes over tools/act_bench.py 256 (the rollout's act step: the same kernel symbol)
+    af = {k: v for k, v in mean_per_kernel(act_fetch_dir, "FETCH_SIZE").items() if "convstack_image" in k}
+    aw = {k: v for k, v in mean_per_kernel(act_write_dir, "WRITE_SIZE").items() if "convstack_image" in k}
+    for kernel in af:
+      raw, wr = af[kernel] * 1024, aw.get(kernel, 0.0) * 1024
+      stages[ROLLOUT_STEP] = {"kernel": kernel, "FETCH_SIZE_bytes_raw": int(raw), "FETCH_SIZE_bytes_x2_gfx950": int(2 * raw),
+                              "WRITE_SIZE_bytes": int(wr), "hbm_bytes": int(2 * raw + wr)}
   for kernel in sorted(set(fetch) | set(write)):
     stage = next((s for key, s in STAGE_OF if key in kernel), None)
     if stage is None:
