@@ -349,10 +349,18 @@ static bool fc_factored(const dx_cnn_ctx *c) { return fc_factored_env() && tail_
 
 // `light`: without the mirrors only the layer-by-layer linear layer / heads read (pk_fcf, pk_fcd and their
 // planes): what dx_cnn_ppo_epoch packs between the updates of an epoch when the factored tail is on
-static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s, bool light = false) {
+static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s, bool light = false, bool direct = false) {
   const int A = c->num_actions, IC0 = c->in_c, P = c->h2 * c->w2, flat = c->flat;
   const float *w = c->params;
   float *pk = c->packed;
+  float *wcf = convstack_supported(c->in_h, c->in_w, c->in_c) ? pk + c->ps_wc : nullptr;  // Wc in the conv-stack kernel's order
+  if (direct) {
+    // between two updates of an epoch on the default route nothing reads an fp32 mirror: Wc, and the bf16 planes
+    // of the three conv layers in the orders their kernels read, straight from the parameters (pack_direct.hip)
+    if (int rc = launch_tail_pack(w, c->off_w, c->off_b, A, pk + c->pk_wc, pk + c->pk_beff, pk + c->pk_wcs, wcf, s)) return rc;
+    return launch_pack_direct(w + c->off_w[0], w + c->off_w[1], w + c->off_w[2], planes(c, c->pb_c0f), planes(c, c->ps_c1f),
+                              planes(c, c->ps_c2f), planes(c, c->ps_c1d), planes(c, c->ps_c2d), s);
+  }
   // The padded head rows / columns beyond A + 1 are never written: `packed` must be zero-filled
   // once by its owner (include/derl_amd.h), not on every parameter update.
   PermuteJob j[kMaxJobs];
@@ -392,7 +400,7 @@ static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s, bool light = 
   add(w + c->off_w[5], pk + c->pk_hdd + A, kHid, kHid, 1, 1, 1, kHeadLd, 0, 0, 0);
   j[n - 1].scatter = 1;
   if (fc_factored(c))  // Wc = Wh Wfc and beff: the factored tail's only mirror
-    if (int rc = launch_tail_pack(w, c->off_w, c->off_b, A, pk + c->pk_wc, pk + c->pk_beff, pk + c->pk_wcs, s)) return rc;
+    if (int rc = launch_tail_pack(w, c->off_w, c->off_b, A, pk + c->pk_wc, pk + c->pk_beff, pk + c->pk_wcs, wcf, s)) return rc;
   if (light) {
     if (int rc = launch_permute_reduce(j, n, s)) return rc;
   } else if (int rc = launch_pack_fused(j, n, w + c->off_w[3], pk + c->pk_fcf, pk + c->pk_fcd, kHid, P, kC2, s)) {
@@ -414,7 +422,7 @@ static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s, bool light = 
   }
   // the conv-stack kernel's fragment-order copies (only the rollout reads them: not between an epoch's updates)
   if ((!light || convstack_train_env()) && convstack_supported(c->in_h, c->in_w, c->in_c))
-    return launch_convstack_pack(planes(c, c->pb_c1f), planes(c, c->pb_c2f), fc_factored(c) ? pk + c->pk_wc : nullptr,
+    return launch_convstack_pack(planes(c, c->pb_c1f), planes(c, c->pb_c2f), nullptr,  // (Wc's copy: launch_tail_pack above)
                                  planes(c, c->ps_c1f), planes(c, c->ps_c2f), pk + c->ps_wc, s);
   return DX_OK;
 }
@@ -1214,8 +1222,14 @@ int cnn_pack_part(const dx_cnn_ctx *c, int part, hipStream_t s) { return pack_pa
 
 // the mirrors between two updates of a native epoch: with the factored tail everything but the linear
 // layer's GEMM mirrors (nothing reads them until the epoch's last update has packed them again)
-int cnn_pack_between_updates(const dx_cnn_ctx *c, bool last_update, hipStream_t s) {
-  return pack_part(c, 3, s, fc_factored(c) && !last_update);
+int cnn_pack_between_updates(const dx_cnn_ctx *c, bool last_update, int obs_is_u8, hipStream_t s) {
+  const bool light = fc_factored(c) && !last_update;
+  // (the direct pack: only when the NEXT minibatch's every stage reads the bf16 planes -- uint8 frames through the
+  // one-launch forward, bf16 data gradients, the first layer's bf16 kernels; DX_PACK_DIRECT=0: the general packs)
+  static const bool direct_env = [] { const char *e = getenv("DX_PACK_DIRECT"); return !(e && atoi(e) == 0); }();
+  const bool direct = light && direct_env && convstack_train_usable(c, obs_is_u8) && dgrad_b6_usable(c) && wgrad_b6_on() &&
+                      c->in_c == 4 && conv0_direct_supported(c->in_h, c->in_w, c->in_c, c->h0, c->w0);
+  return pack_part(c, 3, s, light, direct);
 }
 bool cnn_fc_factored(const dx_cnn_ctx *c) { return fc_factored(c); }
 // the whole conv stack of a training minibatch is one launch: no first layer to start ahead of the other mirrors

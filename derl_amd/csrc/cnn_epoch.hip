@@ -24,7 +24,7 @@ int comm_wait(hipStream_t stream);
 int cnn_forward_range(const dx_cnn_ctx *c, int first, int last, const void *obs, int obs_is_u8,
                       const int32_t *sample_idx, int B, hipStream_t s);
 int cnn_pack_part(const dx_cnn_ctx *c, int part, hipStream_t s);
-int cnn_pack_between_updates(const dx_cnn_ctx *c, bool last_update, hipStream_t s);
+int cnn_pack_between_updates(const dx_cnn_ctx *c, bool last_update, int obs_is_u8, hipStream_t s);
 bool cnn_fc_factored(const dx_cnn_ctx *c);
 bool cnn_forward_fused(const dx_cnn_ctx *c, int obs_is_u8);
 hipStream_t cnn_side_begin(hipStream_t s);
@@ -184,7 +184,7 @@ static int epoch_body(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream, 
         return rc;
     }
     // the mirrors follow every update (after the last one: everything, the next rollout can act at once)
-    if (int rc = cnn_pack_between_updates(c, !more || !fused_heads, s)) return rc;
+    if (int rc = cnn_pack_between_updates(c, !more || !fused_heads, e->obs_is_u8, s)) return rc;
   }
   return DX_OK;
 }

@@ -69,7 +69,11 @@ __global__ __launch_bounds__(256) void tail_pack_partial_kernel(const TailWeight
 }
 
 // Wc[j][p * 64 + c] = sum of the chunks' partial[.][j][c * 49 + p]; last block: beff[j] = Wh[j] . bfc + bh[j]
-__global__ __launch_bounds__(256) void tail_pack_finish_kernel(const float *partial, const TailWeights w, float *Wc, float *beff) {
+// (Wcf, optional: the same values in the fragment order of the rollout's conv-stack kernel, convstack.hip --
+// [wave = 4 (p / 32) + c / 16][tile (p % 32) / 16][row j][lane = 16 ((c % 16) / 4) + p % 16][c % 4]; the rows of
+// pixels 49 .. 63 are never written: `packed` is zero-filled once by its owner)
+__global__ __launch_bounds__(256) void tail_pack_finish_kernel(const float *partial, const TailWeights w, float *Wc, float *beff,
+                                                               float *Wcf) {
   const int t = threadIdx.x;
   if (blockIdx.x == gridDim.x - 1) {
     __shared__ float red[4][kJ];
@@ -102,6 +106,10 @@ __global__ __launch_bounds__(256) void tail_pack_finish_kernel(const float *part
 #pragma unroll
   for (int chunk = 0; chunk < kChunks; ++chunk) v += partial[static_cast<long long>(chunk * kJ + j) * kK + kc];
   Wc[i] = v;
+  if (Wcf) {
+    const int wave = 4 * (p >> 5) + (c >> 4), m = (p >> 4) & 1, lane = 16 * ((c >> 2) & 3) + (p & 15);
+    Wcf[((wave * 2 + m) * 8 + j) * 256 + lane * 4 + (c & 3)] = v;
+  }
 }
 
 struct TailBwdArgs {
@@ -294,12 +302,12 @@ long long tail_slab_floats(int B) { return (static_cast<long long>(tail_bwd_work
 
 // Wc [8][3136] (y2's column order), beff [8] from the canonical parameters; scratch: tail_pack_scratch_floats()
 int launch_tail_pack(const float *params, const long long *off_w, const long long *off_b, int A, float *Wc, float *beff,
-                     float *scratch, hipStream_t stream) {
+                     float *scratch, float *Wcf, hipStream_t stream) {
   DX_REQUIRE(params && Wc && beff && scratch && A >= 1 && A + 1 <= kJ, "tail_pack: bad arguments");
   const TailWeights w = tail_weights(params, off_w, off_b, A);
   hipLaunchKernelGGL(tail_pack_partial_kernel, dim3(kP * kChunks), dim3(256), 0, stream, w, scratch);
   DX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tail_pack_finish_kernel, dim3(cdiv(kJ * kK, 256) + 1), dim3(256), 0, stream, scratch, w, Wc, beff);
+  hipLaunchKernelGGL(tail_pack_finish_kernel, dim3(cdiv(kJ * kK, 256) + 1), dim3(256), 0, stream, scratch, w, Wc, beff, Wcf);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
