@@ -272,7 +272,17 @@ int dx_cnn_backward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
  * dx_cnn_backward_part(part = 2 [then 1], or 3).  norm_stats != NULL: `advantages` are raw and
  * normalised here with {sum, sumsq, n} (derl/runners/trajectory_transforms.py:89-92), written to
  * adv_normalized_out if given.  `counter`: one word, zero before the first call (the launch leaves
- * it zero).  `partials`: >= 8 * ceil(B / 64) doubles.  DX_ENOSUP for more than 7 actions. */
+ * it zero).  `partials`: >= 8 * ceil(B / 64) doubles.  DX_ENOSUP for more than 7 actions.
+ *
+ * Routes (same outputs and gradients, other association / arithmetic; csrc/cnn.hip):
+ *  - 84 x 84 uint8 frames: the three conv layers of the whole minibatch are ONE launch of the image-resident
+ *    kernel (csrc/convstack.hip: bf16 matrix cores at fp32 accuracy, ctx->y0 / y1 / y2 written for the backward);
+ *    float32 frames or other sizes: three layer-by-layer launches on fp32 MFMA.
+ *  - 84 x 84 frames and <= 7 actions: derl's linear layer has no activation behind it, so dx_cnn_forward_trunk ends
+ *    at ctx->y2 and dx_cnn_heads_loss_f32 applies linear layer + heads as ONE affine map of y2 (csrc/tail.hip);
+ *    ctx->hid is then not written.  dx_cnn_tail_factored(ctx) says which.
+ *  - the conv layers' backward: data and weight gradients of conv1 / conv2 on the bf16 matrix cores, image-resident
+ *    (csrc/dgrad_b6.hip, csrc/wgrad_b6.hip), for the 84 x 84 geometry; else the fp32 kernels. */
 int dx_cnn_forward_trunk(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
                          const int32_t *sample_idx, int B, void *stream);
 int dx_cnn_heads_loss_f32(const dx_cnn_ctx *ctx, const int64_t *actions, const float *old_log_prob,
@@ -290,16 +300,18 @@ int dx_cnn_heads_loss_f32(const dx_cnn_ctx *ctx, const int64_t *actions, const f
 int dx_cnn_backward_part(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
                          const int32_t *sample_idx, int B, int part, void *stream);
 /* Rollout step of the policy -- replaces derl/policies.py:61-80 for one batch of observations:
- * conv stack, the 3136->512 linear layer as split-K partial slabs (so that a 256-row batch
- * still fills the chip) and ONE fused launch for both heads + Categorical sampling
+ * for 84 x 84 uint8 frames and <= 7 actions ONE launch, one workgroup per observation (csrc/convstack.hip:
+ * conv stack, y2 Wc^T + beff, Categorical sampling; ctx->y2 is written too); otherwise conv stack, the
+ * 3136->512 linear layer as split-K partial slabs and one fused launch for both heads + sampling
  * (uniforms == NULL: counter-based generator keyed by (seed, counter, row)).
  * Outputs: actions int64 (B), log_prob f32 (B), values f32 (B).  ctx->head is not written. */
 int dx_cnn_act(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8, int B,
                const float *uniforms, uint64_t seed, uint64_t counter, int64_t *actions,
                float *log_prob, float *values, void *stream);
 /* T rollout steps against the synthetic device env, enqueued from one call -- the inner loop
- * of derl/runners/env_runner.py:43-65 for the measurement env (same per-step launches as
- * dx_cnn_act + dx_synth_atari_step; only the host interpreter between them is removed).
+ * of derl/runners/env_runner.py:43-65 for the measurement env.  Where dx_cnn_act is one launch the WHOLE
+ * horizon is one launch (every env's chain frame -> policy -> sample -> next frame is local to its workgroup);
+ * otherwise the same per-step launches as dx_cnn_act + dx_synth_atari_step.  Bit-identical buffers either way.
  * obs (T+1, N, H, W, 4) uint8 with obs[0] given; actions (T, N) int64; log_prob, values,
  * rewards (T, N) float32; resets (T, N) bytes. */
 int dx_cnn_rollout_synth(const dx_cnn_ctx *ctx, uint8_t *obs, int T, int N, int64_t *actions,
