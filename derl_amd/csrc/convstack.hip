@@ -316,12 +316,15 @@ __device__ __forceinline__ void sample_step(const ConvStackArgs &a, const float 
   }
 }
 
+// TRAIN: the forward of a training minibatch (its own kernel symbol: a profile tells the update's launches from
+// the rollout's, and the rollout-only parts -- the tail, the sample, the env's frame -- are compiled out of it)
+template <bool TRAIN>
 __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave & 3, kh2 = wave >> 2;  // conv1 / conv2: output-channel tile and K half of this wave
   int e = blockIdx.x;  // the env (rollout) or, in a training forward, the image: blockIdx + t grid
-  const int steps = a.train ? (a.B - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x) : a.T;
+  const int steps = TRAIN ? (a.B - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x) : a.T;
   const long long step_bytes = static_cast<long long>(a.row_stride) * kFrameB;  // frames of one step of the whole batch
   unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DX_CS_MARK(i) if (kDiag && a.stamps && t == stamp_step) tk[i] = __builtin_amdgcn_s_memtime();
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
 
   for (t = 0; t < steps; ++t) {
     if (t > 0) { DX_CS_MARK(0) }
-    if (a.train && t > 0) {
+    if (TRAIN && t > 0) {
       e += gridDim.x;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the image's frame (LDS-DMA, below) have landed
     }
@@ -386,13 +389,13 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       if (wave < 5) conv0_mfma<2>(smem, wave, lane0, acc0);
       else conv0_mfma<1>(smem, wave, lane0, acc0);
       // wave 7 has one conv0 tile where waves 0-4 have two: the PREVIOUS step's sample fits in that slack
-      if (a.Wc && t > 0 && wave == 7) sample_step(a, tailred, t - 1, e, lane0);
+      if (!TRAIN && a.Wc && t > 0 && wave == 7) sample_step(a, tailred, t - 1, e, lane0);
       f32x4 bias0[4];  // conv0's bias for this lane's 16 accumulator rows (channels 8 q + 4 (lane >> 5) + j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (lane0 >> 5));
       DX_CS_MARK(11)
       lds_barrier();  // every wave has read the frame: the y0 planes may overwrite it
-      float *gy0 = a.y0 ? a.y0 + static_cast<long long>(e) * (kP0 * 32) : nullptr;
+      float *gy0 = TRAIN && a.y0 ? a.y0 + static_cast<long long>(e) * (kP0 * 32) : nullptr;
       if (wave < 5) conv0_store<2>(smem, wave, lane0, acc0, bias0, gy0);
       else conv0_store<1>(smem, wave, lane0, acc0, bias0, gy0);
     }
@@ -443,13 +446,13 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
         const int p = 16 * ((kh2 == 0 ? 0 : 3) + m) + n16;
         const f32x4 v = kh2 == 0 ? finish_tile<0>(red, partner, lane, acc, m, bias1) : finish_tile<3>(red, partner, lane, acc, m, bias1);
         if (p < kP1) store_planes4(smem, oY1 + (p / 9) * kY1R + (p % 9) * kY1P + oc0 * 2, kY1Plane, v);
-        if (a.y1 && p < kP1) *reinterpret_cast<f32x4 *>(a.y1 + static_cast<long long>(e) * (kP1 * 64) + p * 64 + oc0) = v;
+        if (TRAIN && a.y1 && p < kP1) *reinterpret_cast<f32x4 *>(a.y1 + static_cast<long long>(e) * (kP1 * 64) + p * 64 + oc0) = v;
       }
       DX_CS_MARK(10)
       lds_barrier();
       DX_CS_MARK(4)
     }
-    if (a.env && t + 1 <= a.T) {
+    if (!TRAIN && a.env && t + 1 <= a.T) {
       // The synthetic env's NEXT frame of this env (synth_atari_block's hash of (seed, counter, position): the
       // measurement env ignores the action, so the frame does not wait for this step's sample): into the
       // rollout buffer and straight into the LDS slot the next step's conv0 reads (free since y0 is dead).
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       const int p_keep0 = 16 * (kh2 == 0 ? 0 : 2) + n16;
       const int oc0 = 16 * nt + 4 * kq;
       f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
-      if (a.train && t + 1 < steps) {
+      if (TRAIN && t + 1 < steps) {
         // The NEXT image's frame, straight into the LDS slot conv0 reads (free since y0 died), by LDS-DMA: piece
         // wave + 8 u is one KB of both.  Nothing this wave loaded is waited for between here and the next step's
         // top (the compiler would drain the DMA with it): the bias is made to arrive first.
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       // the tail's weights for outputs 0-3 now (under the exchange), for 4-7 after these are used
       f32x4 wc[4][2];
       const unsigned ow = static_cast<unsigned>(lane2 * 16);  // (fragment order: rows of pixels past the image are zero)
-      if (a.Wc) {
+      if (!TRAIN && a.Wc) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
         for (int m = 0; m < 2; ++m)
           if (p_keep0 + 16 * m < kP2) *reinterpret_cast<f32x4 *>(out + (p_keep0 + 16 * m) * 64 + oc0) = v2[m];
       }
-      if (a.Wc) {
+      if (!TRAIN && a.Wc) {
         // ---- the policy's tail: out[j] = sum over (pixel, channel) of y2 Wc[j] + beff[j]; lane sums, wave sums
         // (DPP), the eight waves' sums meet in LDS in wave order, wave 0 samples (heads.hip: tail_act_block) ----
         float mine = 0.f;
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
     }
     DX_CS_MARK(6)
   }
-  if (a.Wc) {  // the last step's sample
+  if (!TRAIN && a.Wc) {  // the last step's sample
     lds_barrier();
     if (wave == 7) sample_step(a, tailred, a.T - 1, e, lane);
   }
@@ -650,7 +653,9 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
   int dev = 0;
   DX_HIP(hipGetDevice(&dev));
   if (configured_device != dev) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(convstack_image_kernel),
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(convstack_image_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(convstack_image_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     configured_device = dev;
   }
@@ -668,7 +673,8 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
     a.stamp_step = getenv("DX_CS_STEP") ? atoi(getenv("DX_CS_STEP")) : 0;
     const int steps = a.train ? a.B / B : a.T;  // (training: images per workgroup)
     if (a.stamp_step >= steps) a.stamp_step = steps - 1;
-    hipLaunchKernelGGL(convstack_image_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
+    if (a.train) hipLaunchKernelGGL(convstack_image_kernel<true>, dim3(B), dim3(512), kLdsBytes, stream, a);
+    else hipLaunchKernelGGL(convstack_image_kernel<false>, dim3(B), dim3(512), kLdsBytes, stream, a);
     DX_LAUNCH_CHECK();
     DX_HIP(hipStreamSynchronize(stream));
     std::vector<unsigned long long> h(static_cast<size_t>(B) * 16);
@@ -694,7 +700,8 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
     return DX_OK;
   }
 #endif
-  hipLaunchKernelGGL(convstack_image_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
+  if (a.train) hipLaunchKernelGGL(convstack_image_kernel<true>, dim3(B), dim3(512), kLdsBytes, stream, a);
+  else hipLaunchKernelGGL(convstack_image_kernel<false>, dim3(B), dim3(512), kLdsBytes, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -28,7 +28,7 @@ STAGE_OF = [  # substring of the kernel name -> stage
     ("tail_loss_kernel", "tail_loss"), ("tail_bwd_kernel", "tail_bwd"), ("tail_greduce_kernel", "tail_greduce"),
     ("tail_grads_kernel", "tail_grads"),
     # round 4: the update's conv stages on the bf16 matrix cores (convstack.hip `train`, wgrad_b6.hip, dgrad_b6.hip)
-    ("convstack_image_kernel", "conv_stack_fwd"),
+    ("convstack_image_kernel<true>", "conv_stack_fwd"), ("convstack_image_kernel<(bool)1>", "conv_stack_fwd"),
     ("conv_wgrad_b6_kernel<1>", "conv1_wgrad"), ("conv_wgrad_b6_kernel<2>", "conv2_wgrad"),
     ("conv_dgrad_b6_kernel<1>", "conv1_dgrad"), ("conv_dgrad_b6_kernel<2>", "conv2_dgrad"),
 ]
