@@ -90,29 +90,58 @@ __device__ __forceinline__ void dg_load(const uint8_t *img, int pb, u32x4 (&x)[3
   for (int pl = 0; pl < 3; ++pl) x[pl] = *reinterpret_cast<const u32x4 *>(img + pb + off + pl * DgGeom<L>::PLANE);
 }
 
-// units (K step S, tile T) in order, the fragments of the unit two ahead read behind this unit's first MFMA
+// A (K step, tile) unit whose tap reads nothing but the zero border for EVERY pixel of the tile is not computed:
+// a tile is 16 consecutive pixels of the raster (two or three image rows), a tap shifts them by whole rows.
+//   conv2 (9 x 9 pixels, gradient rows 0 .. 6 at iy - kh): tile 0 (rows 0-1) skips kh = 2, tile 4 (rows 7-8) kh = 0,
+//          tile 5 (row 8) kh = 0 and 1: 24 of the 108 (K half, step, tile) units, 17 % of the busier K half.
+//   conv1 (10 x 10 pixels per parity class, gradient rows 0 .. 8 at y' - a): tile 6 (row 9) skips a = 0.
+template <int L, int KH2, int S, int T>
+__device__ __forceinline__ constexpr bool dg_unit_active() {
+  using G = DgGeom<L>;
+  constexpr int g = (L == 2 ? 9 * KH2 : 0) + S, tap = g >> 1;
+  constexpr int ty = L == 1 ? tap >> 1 : tap / 3;                         // rows the tap shifts by
+  constexpr int r0 = (16 * T) / G::MW;                                     // first and last image row of the tile's pixels
+  constexpr int plast = 16 * T + 15 < G::MPIX - 1 ? 16 * T + 15 : G::MPIX - 1, r1 = plast / G::MW;
+  return r1 - ty >= 0 && r0 - ty <= G::GH - 1;                             // some source row inside the gradient image
+}
+template <int L, int KH2>
+struct DgUnits {  // the active units in (step, tile) order
+  using G = DgGeom<L>;
+  int n = 0;
+  int s[G::NS * G::NT] = {}, t[G::NS * G::NT] = {};
+  template <int S, int T>
+  constexpr void add() {
+    if (dg_unit_active<L, KH2, S, T>()) { s[n] = S; t[n] = T; ++n; }
+    if constexpr (T + 1 < G::NT) add<S, T + 1>();
+    else if constexpr (S + 1 < G::NS) add<S + 1, 0>();
+  }
+  constexpr DgUnits() { add<0, 0>(); }
+};
+
+// units in order, the fragments of the unit two ahead read behind this unit's first MFMA
 // (hipcc otherwise sinks every read to just before its use and waits for it at once)
-template <int L, int KH2, int U>
+template <int L, int KH2, int I>
 __device__ __forceinline__ void dg_units(const uint8_t *img, const int (&pb)[DgGeom<L>::NT], const u32x4 (&w)[DgGeom<L>::NS][3],
                                          f32x4 (&acc)[DgGeom<L>::NT], u32x4 (&x0)[3], u32x4 (&x1)[3]) {
-  using G = DgGeom<L>;
-  constexpr int TOTAL = G::NT * G::NS;
-  constexpr int S = U / G::NT, T = U % G::NT;
+  constexpr DgUnits<L, KH2> units{};
+  constexpr int S = units.s[I], T = units.t[I];
   u32x4 x2[3];
   acc[T] = dg_mac_first(acc[T], w[S], x0);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (U + 2 < TOTAL) dg_load<L, KH2, (U + 2) / G::NT>(img, pb[(U + 2) % G::NT], x2);
+  if constexpr (I + 2 < units.n) dg_load<L, KH2, units.s[I + 2]>(img, pb[units.t[I + 2]], x2);
   __builtin_amdgcn_sched_barrier(0);
   acc[T] = dg_mac_rest(acc[T], w[S], x0);
-  if constexpr (U + 1 < TOTAL) dg_units<L, KH2, U + 1>(img, pb, w, acc, x1, x2);
+  if constexpr (I + 1 < units.n) dg_units<L, KH2, I + 1>(img, pb, w, acc, x1, x2);
 }
 
 template <int L, int KH2>
 __device__ __forceinline__ void dg_loop(const uint8_t *img, const int (&pb)[DgGeom<L>::NT], const u32x4 (&w)[DgGeom<L>::NS][3],
                                         f32x4 (&acc)[DgGeom<L>::NT]) {
+  constexpr DgUnits<L, KH2> units{};
+  static_assert(units.n >= 2, "at least two units");
   u32x4 x0[3], x1[3];
-  dg_load<L, KH2, 0>(img, pb[0], x0);
-  dg_load<L, KH2, 1 / DgGeom<L>::NT>(img, pb[1 % DgGeom<L>::NT], x1);
+  dg_load<L, KH2, units.s[0]>(img, pb[units.t[0]], x0);
+  dg_load<L, KH2, units.s[1]>(img, pb[units.t[1]], x1);
   dg_units<L, KH2, 0>(img, pb, w, acc, x0, x1);
 }
 
