@@ -91,18 +91,21 @@ __device__ __forceinline__ void dg_load(const uint8_t *img, int pb, u32x4 (&x)[3
 }
 
 // A (K step, tile) unit whose tap reads nothing but the zero border for EVERY pixel of the tile is not computed:
-// a tile is 16 consecutive pixels of the raster (two or three image rows), a tap shifts them by whole rows.
-//   conv2 (9 x 9 pixels, gradient rows 0 .. 6 at iy - kh): tile 0 (rows 0-1) skips kh = 2, tile 4 (rows 7-8) kh = 0,
-//          tile 5 (row 8) kh = 0 and 1: 24 of the 108 (K half, step, tile) units, 17 % of the busier K half.
-//   conv1 (10 x 10 pixels per parity class, gradient rows 0 .. 8 at y' - a): tile 6 (row 9) skips a = 0.
+// a tile is 16 consecutive pixels of the raster (two or three image rows), a tap shifts them by whole rows / columns.
+//   conv2 (9 x 9 pixels, gradient pixel (iy - kh, ix - kw) inside 7 x 7): tile 0 (rows 0-1) skips kh = 2, tile 4 (rows
+//          7-8) kh = 0, tile 5 (the one pixel (8, 8)) everything but tap (2, 2): 28 of the 108 (K half, step, tile)
+//          units, a quarter of the busier K half.
+//   conv1 (10 x 10 pixels per parity class, gradient pixel (y' - a, x' - b) inside 9 x 9): tile 6 (row 9) skips a = 0.
 template <int L, int KH2, int S, int T>
 __device__ __forceinline__ constexpr bool dg_unit_active() {
   using G = DgGeom<L>;
   constexpr int g = (L == 2 ? 9 * KH2 : 0) + S, tap = g >> 1;
-  constexpr int ty = L == 1 ? tap >> 1 : tap / 3;                         // rows the tap shifts by
-  constexpr int r0 = (16 * T) / G::MW;                                     // first and last image row of the tile's pixels
-  constexpr int plast = 16 * T + 15 < G::MPIX - 1 ? 16 * T + 15 : G::MPIX - 1, r1 = plast / G::MW;
-  return r1 - ty >= 0 && r0 - ty <= G::GH - 1;                             // some source row inside the gradient image
+  constexpr int ty = L == 1 ? tap >> 1 : tap / 3, tx = L == 1 ? tap & 1 : tap % 3;  // rows / columns the tap shifts by
+  for (int p = 16 * T; p < 16 * T + 16 && p < G::MPIX; ++p) {                        // any pixel of the tile with its source inside?
+    const int y = p / G::MW - ty, x = p % G::MW - tx;
+    if (y >= 0 && y < G::GH && x >= 0 && x < G::GW) return true;
+  }
+  return false;
 }
 template <int L, int KH2>
 struct DgUnits {  // the active units in (step, tile) order
