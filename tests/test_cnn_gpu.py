@@ -225,6 +225,39 @@ def test_backward_ragged_batches_with_gather(batch, route):
     nt.assert_allclose(grads[k].cpu().numpy(), og, rtol=1e-4, atol=1e-5 + 1e-5 * scale, err_msg=k)
 
 
+@pytest.mark.parametrize("route", ["layers", "update"])
+@pytest.mark.parametrize("batch", [37, 300])
+def test_backward_with_float_observations(batch, route):
+  """float32 observations (derl/models.py:117-124 divides only uint8 by 255) take the layer-by-layer fp32 forward
+  -- the one-launch conv stack reads uint8 frames -- and then the SAME image-resident bf16 gradient kernels as a
+  uint8 minibatch: loss and every gradient against the float64 oracle on the engine's ReLU branch."""
+  from derl_amd import _lib
+  rs = np.random.RandomState(7 + batch)
+  A = 4
+  weights = gi.nature_cnn_weights(A, 33)
+  pool = (gi.frames(batch + 3, 2000 + batch).astype(np.float32) / 255).astype(np.float32)
+  idx = rs.permutation(batch + 3)[:batch].astype(np.int32)
+  data = dict(observations=pool, actions=rs.randint(0, A, batch).astype(np.int64),
+              log_prob=(rs.standard_normal(batch) * 0.1 - 1.4).astype(np.float32),
+              advantages=rs.standard_normal(batch).astype(np.float32),
+              values=rs.standard_normal((batch, 1)).astype(np.float32) * 0.2,
+              value_targets=rs.standard_normal((batch, 1)).astype(np.float32))
+  eng = make_engine(A, weights, max_batch=max(256, batch))
+  loss, grads = run_loss_and_backward(eng, data, 0, 0.1, 0.25, 0.01, A, torch.from_numpy(idx).to(DEV), route=route)
+  lib = _lib.load()
+  assert lib.dx_cnn_last_route(1).decode() != "convstack_train"        # conv1 forward: an fp32 stage
+  assert lib.dx_cnn_last_route(10).decode() == "dgrad_b6"
+  masks = engine_relu_masks(eng, batch)
+  flipped, worst = mask_disagreement(weights, pool[idx], masks)
+  assert worst < 3e-6, (flipped, worst)
+  terms, ograds = oracle.ppo_loss_and_grads(weights, dict(data, observations=pool[idx]), "cnn", 0.1, 0.25, 0.01,
+                                            dtype=torch.float64, relu_masks=masks)
+  nt.assert_allclose(loss[0], terms["loss"], rtol=1e-4, atol=1e-5)
+  for k, og in ograds.items():
+    scale = np.abs(og).max()
+    nt.assert_allclose(grads[k].cpu().numpy(), og, rtol=1e-4, atol=1e-5 + 1e-5 * scale, err_msg=k)
+
+
 @pytest.mark.parametrize("shape,batch", [((80, 96), 40), ((80, 96), 640), ((64, 64), 40), ((64, 64), 640)])
 def test_other_frame_geometries_match_the_oracle(shape, batch):
   """The reference's NatureCNN takes any frame size (models.py:94-124 derives the linear layer's width
@@ -285,7 +318,8 @@ def engine_relu_masks(eng, batch):
 
 def _float64_preactivations(weights, obs, masks=None):
   import torch.nn.functional as F
-  x = (torch.from_numpy(obs).permute(0, 3, 1, 2).float() / 255).double().contiguous()
+  x = torch.from_numpy(obs).permute(0, 3, 1, 2)
+  x = (x.float() / 255 if x.dtype == torch.uint8 else x).double().contiguous()  # (float observations are taken as they are)
   for i, s in enumerate((4, 2, 1)):
     x = F.conv2d(x, torch.from_numpy(weights[f"base.conv-{i}.weight"]).double(),
                  torch.from_numpy(weights[f"base.conv-{i}.bias"]).double(), stride=s)
