@@ -57,10 +57,17 @@ bool wgrad_direct_on() {
   if (v < 0) { const char *e = getenv("DX_WGRAD_DIRECT"); v = e ? atoi(e) : 1; }
   return v != 0;
 }
+// smallest batch that takes the image-resident weight-gradient kernels: the fp32 ones (wgrad_direct.hip, wgrad_fc.hip)
+// want enough images for their 256-512 persistent workgroups; the bf16 ones (wgrad_b6.hip) are one workgroup per
+// image below that and measured 2x the generic kernel at 128-384 images (10.7 / 12.2 us against 21.2 / 21.6 at 128)
 int wgrad_direct_min_batch() {
   static int v = -1;
   if (v < 0) { const char *e = getenv("DX_WGRAD_DIRECT_MIN_B"); v = e ? atoi(e) : 512; }
   return v;
+}
+static int conv_wgrad_min_batch() {
+  static const bool set = getenv("DX_WGRAD_DIRECT_MIN_B") != nullptr;
+  return set || !wgrad_b6_on() ? wgrad_direct_min_batch() : 16;
 }
 
 // DX_ROLLOUT_LANES=1: the native rollout on the caller's stream only (default 2: see
@@ -232,7 +239,7 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
       const int nwg = wgrad_b6_on() ? 256 : wgrad_direct_workgroups(st, B);
       const int cap = wgrad_direct_workgroups(st, c->max_batch) > 256 ? wgrad_direct_workgroups(st, c->max_batch) : 256;
       if (ms_cap < cap) ms_cap = cap;
-      if (B >= wgrad_direct_min_batch()) {
+      if (B >= conv_wgrad_min_batch()) {
         p.s[l].direct = 1;
         p.s[l].msplit = static_cast<int>(B < nwg ? B : nwg);
       }
