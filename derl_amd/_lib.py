@@ -50,10 +50,12 @@ SIGNATURES = {
     "dx_categorical_loss_f32": [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float,
                                 c_float, c_longlong, P, P, c_int, P, P],
     "dx_synth_atari_step": [P, c_longlong, P, P, c_int, c_uint64, c_uint64, c_float, c_float, P],
+    "dx_synth_mujoco_step": [P, P, P, c_int, c_int, c_uint64, c_uint64, c_float, P],
     "dx_mlp_init": [P],
     "dx_mlp_pack": [P, P],
     "dx_mlp_forward": [P, P, c_int, P],
     "dx_mlp_backward": [P, c_int, P],
+    "dx_mlp_rollout_synth": [P, P, c_int, c_int, P, P, P, P, P, c_uint64, c_uint64, c_uint64, c_uint64, c_float, P],
     "dx_mlp_ppo_epoch": [P, P, P],
     "dx_mlp_persist_plan": [P, c_int, c_longlong, P, P],
     "dx_mlp_last_route": [],

@@ -343,14 +343,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partials
 }
 
 // ---- diagonal Gaussian head (thread per row; P <= 31 action dimensions) -----------------
-constexpr float kHalfLog2Pi = 0.91893853320467274178f;  // log(sqrt(2*pi))
-
-__device__ __forceinline__ float normal01(uint64_t seed, uint64_t counter, uint64_t idx) {
-  // Box-Muller from two counter-based uniforms; u1 in (0,1]
-  const float u1 = 1.0f - uniform01(seed, counter * 2, idx);
-  const float u2 = uniform01(seed ^ 0xA5A5A5A5A5A5A5A5ull, counter * 2 + 1, idx);
-  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-}
+// (normal01, normal_act_row, kHalfLog2Pi: heads_dev.hpp)
 
 __global__ __launch_bounds__(256) void normal_act_kernel(
     const float *__restrict__ head, const float *__restrict__ logstd, int B, int P,
@@ -359,18 +352,8 @@ __global__ __launch_bounds__(256) void normal_act_kernel(
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float *row = head + static_cast<long long>(b) * kHeadLd;
-  float lp = 0.f;
-  for (int d = 0; d < P; ++d) {
-    const float mu = row[d];
-    const float sigma = expf(logstd[d]);
-    const float eps = normals ? normals[static_cast<long long>(b) * P + d]
-                              : normal01(seed, counter, static_cast<uint64_t>(b) * 32 + d);
-    const float act = mu + sigma * eps;
-    actions[static_cast<long long>(b) * P + d] = act;
-    const float diff = act - mu;
-    lp += -(diff * diff) / (2.f * (sigma * sigma)) - logf(sigma) - kHalfLog2Pi;
-  }
-  log_prob[b] = lp;
+  log_prob[b] = normal_act_row(row, logstd, P, normals ? normals + static_cast<long long>(b) * P : nullptr, seed, counter, b,
+                               actions + static_cast<long long>(b) * P);
   values[b] = row[P];
 }
 

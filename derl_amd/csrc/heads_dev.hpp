@@ -32,6 +32,31 @@ __device__ __forceinline__ float wave_sum_all(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// ---- diagonal Gaussian head: one row's sample (derl/policies.py:40-42,66), shared by dx_normal_act_f32 (heads.hip)
+// and the one-launch MLP rollout (mlp_fused.hip) so that both write the same bits ----
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;  // log(sqrt(2*pi))
+__device__ __forceinline__ float normal01(uint64_t seed, uint64_t counter, uint64_t idx) {
+  // Box-Muller from two counter-based uniforms; u1 in (0,1]
+  const float u1 = 1.0f - uniform01(seed, counter * 2, idx);
+  const float u2 = uniform01(seed ^ 0xA5A5A5A5A5A5A5A5ull, counter * 2 + 1, idx);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+// row = the policy's P means followed by the value; actions (P) and the log-probability of row b
+__device__ __forceinline__ float normal_act_row(const float *row, const float *logstd, int P, const float *normals_row, uint64_t seed,
+                                                uint64_t counter, long long b, float *actions_row) {
+  float lp = 0.f;
+  for (int d = 0; d < P; ++d) {
+    const float mu = row[d];
+    const float sigma = expf(logstd[d]);
+    const float eps = normals_row ? normals_row[d] : normal01(seed, counter, static_cast<uint64_t>(b) * 32 + d);
+    const float act = mu + sigma * eps;
+    actions_row[d] = act;
+    const float diff = act - mu;
+    lp += -(diff * diff) / (2.f * (sigma * sigma)) - logf(sigma) - kHalfLog2Pi;
+  }
+  return lp;
+}
+
 __device__ __forceinline__ float lane_value(float v, int lane_uniform) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_uniform));
 }

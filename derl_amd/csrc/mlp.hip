@@ -215,6 +215,26 @@ int dx_mlp_forward(const dx_mlp_ctx *c, const float *obs, int B, void *stream) {
   return DX_OK;
 }
 
+// T steps of the Gaussian policy against the MuJoCo-shaped synthetic device env from ONE launch (mlp_fused.hip:
+// mlp_rollout_synth_kernel) -- the inner loop of derl/runners/env_runner.py:43-65 for the measurement env; buffers
+// bit-identical to dx_mlp_forward + dx_normal_act_f32 + dx_synth_mujoco_step per step.  DX_ENOSUP without logstd (a
+// categorical MLP) or when the fused kernels do not apply (observations wider than 64, DX_MLP_UNFUSED=1).
+int dx_mlp_rollout_synth(const dx_mlp_ctx *c, float *obs, int T, int N, float *actions, float *log_prob, float *values,
+                         float *rewards, uint8_t *resets, uint64_t policy_seed, uint64_t policy_counter, uint64_t env_seed,
+                         uint64_t env_counter, float p_reset, void *stream) {
+  DX_TRACE("dx_mlp_rollout_synth");
+  if (int rc = check_mlp(c, "dx_mlp_rollout_synth", N, false)) return rc;
+  if (!c->has_logstd || c->off_logstd < 0 || !use_fused(c)) return fail(DX_ENOSUP, "dx_mlp_rollout_synth: Gaussian policy on the fused kernels only");
+  MlpRolloutArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.f = fused_args(c, N);
+  a.off_logstd = c->off_logstd;
+  a.obs = obs; a.actions = actions; a.log_prob = log_prob; a.values = values; a.rewards = rewards; a.resets = resets;
+  a.T = T; a.policy_seed = policy_seed; a.policy_counter = policy_counter; a.env_seed = env_seed; a.env_counter = env_counter;
+  a.p_reset = p_reset;
+  return launch_mlp_rollout_synth(a, as_stream(stream));
+}
+
 // ctx->dhead (B, 32) -> ctx->grads (every tensor except logstd, which the Gaussian loss
 // kernel writes itself), using the activations of the matching dx_mlp_forward
 int dx_mlp_backward(const dx_mlp_ctx *c, int B, void *stream) {

@@ -10,6 +10,8 @@
 //             permute_reduce as before) with the two tanh' dgrads in between.
 // blockIdx.y = net (0 policy, 1 value); workgroups loop over row tiles.
 #include "mlp_fused.hpp"
+#include "heads_dev.hpp"
+#include "synth_dev.hpp"
 
 namespace dx {
 namespace {
@@ -118,6 +120,107 @@ __global__ __launch_bounds__(kThreads) void mlp_forward_fused_kernel(MlpFusedArg
       }
     }
     // the next tile's staging only writes xs (last read before the first barrier above)
+  }
+}
+
+// The whole rollout horizon of the Gaussian MLP policy against the MuJoCo-shaped synthetic env in ONE launch
+// (derl/runners/env_runner.py:43-65 for the measurement env): the env's next observation is a hash of (seed,
+// counter, env, component) and does not depend on the action, and a policy step reads only its own env's
+// observation, so a workgroup keeps 8 envs for all T steps with BOTH nets' weights resident in LDS -- per step
+// the forward of mlp_forward_fused_kernel (the same fma chains per row: identical bits), the sample of
+// dx_normal_act_f32 (heads_dev.hpp: normal_act_row) and dx_synth_mujoco_step's values.  The per-step loop is
+// ~11 launches per step (two native, the rest the env's); config 3's 64 steps took 2.3 ms of its 15.4 ms iteration.
+template <int DP>
+__global__ __launch_bounds__(kThreads) void mlp_rollout_synth_kernel(const MlpRolloutArgs a) {
+  constexpr int RPW = 2, R = 4 * RPW, LD0 = DP + 1;
+  constexpr int kNet = kH * LD0 + kH * kLdT + kHeadLd * kLdT + 160;  // floats of one net's weights and biases
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *xs = lds + 2 * kNet;  // [R][DP]
+  float *hs = xs + R * DP;     // [R][64]
+  float *gs = hs + R * kH;     // [R][64]
+  float *hd = gs + R * kH;     // [R][32]: the policy's means, then the value
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int D = a.f.D, P = a.f.P, N = a.f.B;
+  const float *p = a.f.params;
+  for (int net = 0; net < 2; ++net) {
+    float *W0 = lds + net * kNet, *W1 = W0 + kH * LD0, *W2 = W1 + kH * kLdT, *bs = W2 + kHeadLd * kLdT;
+    const int outs = net == 0 ? P : 1;
+    const float *w0 = p + a.f.off_w[3 * net], *w1 = p + a.f.off_w[3 * net + 1], *w2 = p + a.f.off_w[3 * net + 2];
+    for (int i = t; i < kH * DP; i += kThreads) {
+      const int j = i / DP, k = i - j * DP;
+      W0[j * LD0 + k] = k < D ? w0[j * D + k] : 0.f;
+    }
+    for (int i = t; i < kH * kH; i += kThreads) W1[(i >> 6) * kLdT + (i & 63)] = w1[i];
+    for (int i = t; i < kHeadLd * kH; i += kThreads) W2[(i >> 6) * kLdT + (i & 63)] = (i >> 6) < outs ? w2[i] : 0.f;
+    if (t < kH) {
+      bs[t] = p[a.f.off_b[3 * net] + t];
+      bs[kH + t] = p[a.f.off_b[3 * net + 1] + t];
+      if (t < kHeadLd) bs[2 * kH + t] = t < outs ? p[a.f.off_b[3 * net + 2] + t] : 0.f;
+    }
+  }
+  const long long row0 = static_cast<long long>(blockIdx.x) * R;
+  for (int i = t; i < R * DP; i += kThreads) {
+    const int r = i / DP, k = i - r * DP;
+    xs[i] = (row0 + r < N && k < D) ? a.obs[(row0 + r) * D + k] : 0.f;
+  }
+  __syncthreads();
+  const int r0 = wave * RPW;
+  for (int step = 0; step < a.T; ++step) {
+    for (int net = 0; net < 2; ++net) {
+      const float *W0 = lds + net * kNet, *W1 = W0 + kH * LD0, *W2 = W1 + kH * kLdT, *bs = W2 + kHeadLd * kLdT;
+      const int outs = net == 0 ? P : 1, col = net == 0 ? 0 : P;
+      float acc[RPW];
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) acc[rr] = bs[lane];
+      dot_rows<RPW, DP>(acc, W0 + lane * LD0, xs + r0 * DP, DP);
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) hs[(r0 + rr) * kH + lane] = tanhf(acc[rr]);
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) acc[rr] = bs[kH + lane];
+      dot_rows<RPW, kH>(acc, W1 + lane * kLdT, hs + r0 * kH, kH);
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) gs[(r0 + rr) * kH + lane] = tanhf(acc[rr]);
+      __syncthreads();
+      {
+        constexpr int HR = RPW / 2;
+        const int o = lane & 31, rh = r0 + (lane >> 5) * HR;
+        float out[HR];
+#pragma unroll
+        for (int rr = 0; rr < HR; ++rr) out[rr] = bs[2 * kH + o];
+        dot_rows<HR, kH>(out, W2 + o * kLdT, gs + rh * kH, kH);
+        if (o < outs) {
+#pragma unroll
+          for (int rr = 0; rr < HR; ++rr) hd[(rh + rr) * kHeadLd + col + o] = out[rr];
+        }
+      }
+      __syncthreads();  // (hs / gs are rewritten by the next net; hd is read below)
+    }
+    // ---- sample (thread = row), then the env's step for these rows ----
+    const long long srow = static_cast<long long>(step) * N;
+    if (t < R && row0 + t < N) {
+      const long long b = row0 + t;
+      a.log_prob[srow + b] = normal_act_row(hd + t * kHeadLd, p + a.off_logstd, P, nullptr, a.policy_seed, a.policy_counter + step, b,
+                                            a.actions + (srow + b) * P);
+      a.values[srow + b] = hd[t * kHeadLd + P];
+    }
+    const uint64_t key = synth_mujoco_key(a.env_seed, a.env_counter + step);
+    float *next = a.obs + static_cast<long long>(step + 1) * N * D;
+    for (int i = t; i < R * DP; i += kThreads) {
+      const int r = i / DP, k = i - r * DP;
+      const long long b = row0 + r;
+      float v = 0.f;
+      if (b < N && k < D) {
+        v = synth_mujoco_obs(key, b, k);
+        next[b * D + k] = v;
+      }
+      xs[i] = v;
+      if (k == 0 && b < N) {
+        a.rewards[srow + b] = synth_mujoco_reward(key, b);
+        a.resets[srow + b] = synth_mujoco_reset(key, b, a.p_reset) ? 1 : 0;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -316,6 +419,30 @@ bool mlp_fused_supported(int obs_pad) { return obs_pad == 32 || obs_pad == 64; }
 int mlp_fused_tile_rows(int B, int obs_pad) {
   if (obs_pad == 64) return B >= 2048 ? 16 : 8;
   return B >= 4096 ? 32 : B >= 1024 ? 16 : 8;
+}
+
+template <int DP>
+int rollout_as(const MlpRolloutArgs &a, hipStream_t s) {
+  constexpr int R = 8;
+  constexpr size_t bytes = sizeof(float) * (2 * (kH * (DP + 1) + kH * kLdT + kHeadLd * kLdT + 160) + R * DP + 2 * R * kH + R * kHeadLd);
+  static_assert(bytes <= 160 * 1024, "LDS");
+  static bool configured = false;
+  if (!configured) {
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_rollout_synth_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(bytes)));
+    configured = true;
+  }
+  hipLaunchKernelGGL((mlp_rollout_synth_kernel<DP>), dim3(cdiv(a.f.B, R)), dim3(kThreads), bytes, s, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+int launch_mlp_rollout_synth(const MlpRolloutArgs &a, hipStream_t s) {
+  DX_REQUIRE(a.obs && a.actions && a.log_prob && a.values && a.rewards && a.resets && a.T >= 1 && a.f.B >= 1 && a.off_logstd >= 0,
+             "mlp_rollout_synth: bad arguments");
+  if (a.f.Dp == 32) return rollout_as<32>(a, s);
+  if (a.f.Dp == 64) return rollout_as<64>(a, s);
+  return fail(DX_ENOSUP, "mlp_rollout_synth: observations wider than 64");
 }
 
 int launch_mlp_forward_fused(const MlpFusedArgs &a, hipStream_t s) {

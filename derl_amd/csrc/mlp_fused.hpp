@@ -18,6 +18,21 @@ struct MlpFusedArgs {
   int ms_cap, nslab;         // slab capacity per layer / workgroups (= slabs written) per net
 };
 
+// `T` steps of the Gaussian policy against the MuJoCo-shaped synthetic env in ONE launch (mlp_fused.hip): every env's
+// chain observation -> both nets -> sample -> next observation is local to its workgroup
+struct MlpRolloutArgs {
+  MlpFusedArgs f;        // params / offsets / D, Dp, P; B = number of envs
+  long long off_logstd;
+  float *obs;            // (T + 1, N, D), obs[0] given, the rest written
+  float *actions;        // (T, N, P)
+  float *log_prob, *values, *rewards;  // (T, N)
+  uint8_t *resets;       // (T, N)
+  int T;
+  uint64_t policy_seed, policy_counter, env_seed, env_counter;
+  float p_reset;
+};
+int launch_mlp_rollout_synth(const MlpRolloutArgs &a, hipStream_t stream);
+
 bool mlp_fused_supported(int obs_pad);
 int mlp_fused_tile_rows(int B, int obs_pad);
 int launch_mlp_forward_fused(const MlpFusedArgs &a, hipStream_t stream);

@@ -10,7 +10,35 @@ __global__ __launch_bounds__(256) void synth_atari_kernel(const dx::SynthArgs a)
   dx::synth_atari_block(a, blockIdx.x, gridDim.x);
 }
 
+// one thread per (env, component): obs_dim components, then the env's reward and reset
+__global__ __launch_bounds__(256) void synth_mujoco_kernel(float *obs, float *rewards, uint8_t *resets, int nenvs, int obs_dim,
+                                                           uint64_t seed, uint64_t counter, float p_reset) {
+  const uint64_t key = dx::synth_mujoco_key(seed, counter);
+  const long long total = static_cast<long long>(nenvs) * obs_dim;
+  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long long>(gridDim.x) * 256) {
+    const long long e = i / obs_dim;
+    const int k = static_cast<int>(i - e * obs_dim);
+    obs[i] = dx::synth_mujoco_obs(key, e, k);
+    if (k == 0) {
+      if (rewards) rewards[e] = dx::synth_mujoco_reward(key, e);
+      if (resets) resets[e] = dx::synth_mujoco_reset(key, e, p_reset) ? 1 : 0;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int dx_synth_mujoco_step(float *obs, float *rewards, uint8_t *resets, int nenvs, int obs_dim, uint64_t seed,
+                                    uint64_t counter, float p_reset, void *stream) {
+  DX_TRACE("dx_synth_mujoco_step");
+  DX_REQUIRE(obs && nenvs >= 1 && obs_dim >= 1 && obs_dim <= 64, "dx_synth_mujoco_step: need observations of 1 .. 64 components");
+  const long long total = static_cast<long long>(nenvs) * obs_dim;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(synth_mujoco_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                     dx::as_stream(stream), obs, rewards, resets, nenvs, obs_dim, seed, counter, p_reset);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
 
 extern "C" int dx_synth_atari_step(void *frames, long long frame_bytes_total, float *rewards,
                                    uint8_t *resets, int nenvs, uint64_t seed, uint64_t counter,

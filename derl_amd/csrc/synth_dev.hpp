@@ -46,6 +46,31 @@ __device__ __forceinline__ void synth_atari_block(const SynthArgs &a, int block,
   }
 }
 
+// ---- the MuJoCo-shaped measurement env (derl_amd/env/synthetic.py: SyntheticMuJoCoEnv): float32 observations
+// N(0, 1) clipped to +-10 (the range derl/env/mujoco_wrappers.py:64-124's Normalize produces), rewards N(0, 1), resets
+// Bernoulli(p) -- every value a hash of (seed, counter, env, component), so any split over launches and workgroups
+// draws the same numbers (synth.hip: dx_synth_mujoco_step; mlp_rollout.hip: the whole horizon in one launch) ----
+__device__ __forceinline__ float synth_normal(uint64_t key, uint64_t idx) {  // Box-Muller on two 24-bit uniforms
+  const uint64_t r = synth_mix64(key + idx * 0x9E3779B97F4A7C15ull);
+  const float u1 = (static_cast<float>(r & 0xffffff) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+  const float u2 = static_cast<float>((r >> 24) & 0xffffff) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+__device__ __forceinline__ uint64_t synth_mujoco_key(uint64_t seed, uint64_t counter) {
+  return synth_mix64(seed * 0x9E3779B97F4A7C15ull + counter);
+}
+__device__ __forceinline__ float synth_mujoco_obs(uint64_t key, long long env, int k) {  // component k < 64 of env's observation
+  const float z = synth_normal(key, static_cast<uint64_t>(env) * 64 + k);
+  return fminf(fmaxf(z, -10.f), 10.f);
+}
+__device__ __forceinline__ float synth_mujoco_reward(uint64_t key, long long env) {
+  return synth_normal(~key, static_cast<uint64_t>(env));
+}
+__device__ __forceinline__ bool synth_mujoco_reset(uint64_t key, long long env, float p_reset) {
+  const uint64_t r = synth_mix64((key ^ 0xD1B54A32D192ED03ull) + static_cast<uint64_t>(env) * 0x9E3779B97F4A7C15ull);
+  return static_cast<float>(r >> 40) * (1.0f / 16777216.0f) < p_reset;
+}
+
 // grid of the stand-alone launch (and the env share of the fused one)
 inline int synth_blocks(long long nvec, int nenvs) {
   long long blocks = (nvec + 256 * 4 - 1) / (256 * 4);

@@ -60,37 +60,43 @@ class SyntheticAtariEnv:
 class SyntheticMuJoCoEnv:
   """float32 (nenvs, obs_dim) N(0,1) observations clipped to +-10 (the range
   derl/env/mujoco_wrappers.py:64-124 Normalize produces), rewards N(0,1), resets
-  Bernoulli(0.001)."""
+  Bernoulli(0.001) -- every value a hash of (seed, step counter, env, component)
+  (``dx_synth_mujoco_step``), so the native whole-horizon rollout (``dx_mlp_rollout_synth``)
+  draws the same numbers as this per-step loop."""
 
-  host_rng_free = True  # draws from its own device generator only
+  host_rng_free = True  # never touches the global np.random stream (see IterateWithMinibatches)
 
   def __init__(self, nenvs, obs_dim=17, act_dim=6, seed=0, p_reset=0.001, device="cuda", rank=0):
+    if not 1 <= int(obs_dim) <= 64:
+      raise ValueError("obs_dim must be in 1 .. 64")
     self.nenvs = int(nenvs)
     self.unwrapped = self
     self.device = torch.device(device)
     self.observation_space = Box(-10., 10., (obs_dim,), np.float32)
     self.action_space = Box(-1., 1., (act_dim,), np.float32)
     self.p_reset = p_reset
-    self.generator = torch.Generator(device=self.device)
-    self.generator.manual_seed(int(seed) * 1000003 + int(rank))
+    self.seed = int(seed) * 1000003 + int(rank)
+    self.counter = 0
 
-  def _obs(self, out=None):
+  def _generate(self, out, rewards=None, resets=None):
     shape = (self.nenvs,) + self.observation_space.shape
     if out is None:
       out = torch.empty(shape, dtype=torch.float32, device=self.device)
-    out.normal_(generator=self.generator).clamp_(-10., 10.)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+      raise ValueError(f"out must be a contiguous float32 tensor of shape {shape}")
+    _lib.call("dx_synth_mujoco_step", _lib.ptr(out), _lib.ptr(rewards), _lib.ptr(resets), self.nenvs,
+              shape[1], self.seed, self.counter, float(self.p_reset), _lib.stream_ptr(self.device))
+    self.counter += 1
     return out
 
   def reset(self, out=None):
-    return self._obs(out)
+    return self._generate(out)
 
   def step(self, actions, out=None, rewards_out=None, resets_out=None):
-    del actions
-    obs = self._obs(out)
-    rewards = torch.randn(self.nenvs, device=self.device, generator=self.generator)
-    resets = torch.rand(self.nenvs, device=self.device, generator=self.generator) < self.p_reset
-    if rewards_out is not None:
-      rewards = rewards_out.copy_(rewards)
-    if resets_out is not None:
-      resets = resets_out.copy_(resets)
+    del actions  # the synthetic dynamics ignore the action
+    rewards = rewards_out if rewards_out is not None else torch.empty(
+        self.nenvs, dtype=torch.float32, device=self.device)
+    resets = resets_out if resets_out is not None else torch.empty(
+        self.nenvs, dtype=torch.bool, device=self.device)
+    obs = self._generate(out, rewards, resets)
     return obs, rewards, resets, None

@@ -118,6 +118,17 @@ class MlpEngine:
               _lib.stream_ptr(self.device))
     return self.head[:batch * 32].view(batch, 32)
 
+  def rollout_synth(self, buffers, horizon, nenvs, policy_seed, policy_counter, env_seed, env_counter, p_reset):
+    """Enqueues `horizon` (act, synthetic MuJoCo-shaped env step) pairs as ONE launch.  Raises NativeError
+    (DX_ENOSUP) for a categorical MLP or observations wider than 64."""
+    self.check_health()
+    self.reserve(nenvs)
+    self.pack()
+    _lib.call("dx_mlp_rollout_synth", ctypes.byref(self.ctx), _lib.ptr(buffers["obs"]), int(horizon), int(nenvs),
+              _lib.ptr(buffers["actions"]), _lib.ptr(buffers["log_prob"]), _lib.ptr(buffers["values"]),
+              _lib.ptr(buffers["rewards"]), _lib.ptr(buffers["resets"]), int(policy_seed), int(policy_counter),
+              int(env_seed), int(env_counter), float(p_reset), _lib.stream_ptr(self.device))
+
   def backward(self, batch):
     """Consumes self.dhead (B, 32) and fills self.grads (logstd is written by the loss)."""
     _lib.call("dx_mlp_backward", ctypes.byref(self.ctx), int(batch), _lib.stream_ptr(self.device))

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import _lib
 from . import ops
 from .mlp_engine import MlpEngine
 from .models import GatheredRows, orthogonal_init
@@ -155,6 +156,31 @@ class _MlpActorCritic(nn.Module):
     head = self.head(self.prepare(observations))
     self._act_kernel(head, policy, out=(actions_out, log_prob_out, values_out.view(-1)))
     policy.act_counter += 1
+
+  def policy_rollout_into(self, policy, env, buffers, horizon):
+    """All `horizon` steps against the MuJoCo-shaped synthetic device env in one native launch (Gaussian policy,
+    observations up to 64 wide); False = take the per-step loop."""
+    from .env.synthetic import SyntheticMuJoCoEnv  # pylint: disable=import-outside-toplevel
+    from .env.summarize import DeviceSummarize  # pylint: disable=import-outside-toplevel
+    if isinstance(env, DeviceSummarize):  # statistics are taken from the buffers afterwards
+      env = env.env
+    obs = buffers["obs"]
+    if (not self.gaussian or not isinstance(env, SyntheticMuJoCoEnv) or obs.dtype != torch.float32
+        or obs.shape[-1] > 64 or buffers["actions"].dtype != torch.float32):
+      return False
+    if getattr(self, "_rollout_unsupported", False):
+      return False
+    try:
+      self.engine.rollout_synth(buffers, horizon, env.nenvs, policy.seed, policy.act_counter, env.seed, env.counter,
+                                env.p_reset)
+    except _lib.NativeError as error:  # the layer-by-layer route (DX_MLP_UNFUSED=1): no one-launch rollout
+      if "dx_mlp_rollout_synth" not in str(error):
+        raise
+      self._rollout_unsupported = True
+      return False
+    policy.act_counter += horizon
+    env.counter += horizon
+    return True
 
   def loss_forward_backward(self, policy, data, mode, cliprange, value_loss_coef, entropy_coef,
                             global_batch, actions, old_log_prob, advantages, old_values,

@@ -429,6 +429,16 @@ int dx_mlp_init(dx_mlp_ctx *ctx);
 int dx_mlp_pack(const dx_mlp_ctx *ctx, void *stream);
 int dx_mlp_forward(const dx_mlp_ctx *ctx, const float *obs, int B, void *stream);
 int dx_mlp_backward(const dx_mlp_ctx *ctx, int B, void *stream);
+/* T rollout steps of the Gaussian policy (derl/policies.py:61-80 with derl/models.py:240-271) against the MuJoCo-shaped
+ * synthetic device env from ONE launch -- the inner loop of derl/runners/env_runner.py:43-65 for the measurement env:
+ * every env's chain observation -> both nets -> sample -> next observation is local to its workgroup.  Buffers are
+ * bit-identical to dx_mlp_forward + dx_normal_act_f32 + dx_synth_mujoco_step per step.  obs (T+1, N, obs_dim) float32
+ * with obs[0] given; actions (T, N, P); log_prob, values, rewards (T, N) float32; resets (T, N) bytes.  DX_ENOSUP for a
+ * categorical MLP or observations wider than 64. */
+int dx_mlp_rollout_synth(const dx_mlp_ctx *ctx, float *obs, int T, int N, float *actions, float *log_prob,
+                         float *values, float *rewards, uint8_t *resets, uint64_t policy_seed,
+                         uint64_t policy_counter, uint64_t env_seed, uint64_t env_counter, float p_reset,
+                         void *stream);
 
 /* Every minibatch update of one epoch of the MLP actor-critic from ONE call -- the loop of
  * derl/alg/common.py:66-78 (Trainer.step) over the minibatches of
@@ -521,6 +531,11 @@ int dx_normal_loss_f32(const float *head_out, const float *logstd, const float *
 int dx_synth_atari_step(void *frames, long long frame_bytes_total, float *rewards,
                         uint8_t *resets, int nenvs, uint64_t seed, uint64_t counter,
                         float p_reward, float p_reset, void *stream);
+/* The MuJoCo-shaped measurement env (no MuJoCo in this image): one step of nenvs envs -- observations
+ * (nenvs, obs_dim <= 64) float32 N(0, 1) clipped to +-10 (the range derl/env/mujoco_wrappers.py:64-124's Normalize
+ * produces), rewards N(0, 1), resets Bernoulli(p_reset), all hashed from (seed, counter, env, component). */
+int dx_synth_mujoco_step(float *obs, float *rewards, uint8_t *resets, int nenvs, int obs_dim, uint64_t seed,
+                         uint64_t counter, float p_reset, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Gradient exchange.  derl has no distributed code; the step these sit

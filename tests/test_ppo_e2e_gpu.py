@@ -425,6 +425,42 @@ def test_fused_native_rollout_equals_per_step_loop():
       assert torch.equal(x[k], y[k]), k
 
 
+def test_fused_native_mlp_rollout_equals_per_step_loop():
+  """dx_mlp_rollout_synth (the whole horizon of the Gaussian MLP policy against the MuJoCo-shaped synthetic env in
+  ONE launch) writes the rollout buffers of the Python per-step loop (dx_mlp_forward + dx_normal_act_f32 +
+  dx_synth_mujoco_step per step) bit for bit -- same policy / env seeds and counters -- over two rollouts, with an
+  env count that is not a multiple of the kernel's 8 rows per workgroup."""
+  import derl_amd as derl
+  from derl_amd.policies import ActorCriticPolicy
+
+  def rollout(use_fused):
+    torch.manual_seed(0)
+    env = derl.env.make("HalfCheetah-v3", nenvs=133, seed=3)
+    model = derl.make_model(env.observation_space, env.action_space, 1)
+    policy = ActorCriticPolicy(model, seed=9)
+    taken = []
+    if not use_fused:
+      policy.rollout_into = lambda *a, **k: False
+    else:
+      inner = policy.rollout_into
+      policy.rollout_into = lambda *a, **k: (taken.append(inner(*a, **k)), taken[-1])[1]
+    runner = derl.EnvRunner(env, policy, horizon=7, nsteps=133 * 7 * 2)
+    outs = []
+    for inter in runner.run():
+      outs.append({k: v.clone() for k, v in inter.items() if isinstance(v, torch.Tensor)})
+    return outs, taken
+
+  (a, taken), (b, _) = rollout(True), rollout(False)
+  assert taken == [True, True]
+  assert len(a) == len(b) == 2
+  for x, y in zip(a, b):
+    for k in x:
+      assert torch.equal(x[k], y[k]), k
+  obs = a[0]["observations"]
+  assert float(obs.abs().max()) <= 10.0 and 0.9 < float(obs.std()) < 1.1 and abs(float(obs.mean())) < 0.05
+  assert abs(float(a[0]["rewards"].mean())) < 0.2 and 0.8 < float(a[0]["rewards"].std()) < 1.2
+
+
 def test_ppo_learns_cartpole():
   """The whole path as a learner, not only as arithmetic: PPO with BASELINE config 1's
   hyper-parameters (factory/ppo.py atari preset, nenvs 8 x 128 steps) on the built-in CartPole-v1
