@@ -41,18 +41,22 @@ __device__ __forceinline__ float normal01(uint64_t seed, uint64_t counter, uint6
   const float u2 = uniform01(seed ^ 0xA5A5A5A5A5A5A5A5ull, counter * 2 + 1, idx);
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
-// row = the policy's P means followed by the value; actions (P) and the log-probability of row b
+// one action dimension: the sample and its term of the log-probability
+__device__ __forceinline__ float normal_act_dim(float mu, float logstd_d, float eps, float *act_out) {
+  const float sigma = expf(logstd_d);
+  const float act = mu + sigma * eps;
+  *act_out = act;
+  const float diff = act - mu;
+  return -(diff * diff) / (2.f * (sigma * sigma)) - logf(sigma) - kHalfLog2Pi;
+}
+// row = the policy's P means followed by the value; actions (P) and the log-probability of row b (terms added in
+// dimension order)
 __device__ __forceinline__ float normal_act_row(const float *row, const float *logstd, int P, const float *normals_row, uint64_t seed,
                                                 uint64_t counter, long long b, float *actions_row) {
   float lp = 0.f;
   for (int d = 0; d < P; ++d) {
-    const float mu = row[d];
-    const float sigma = expf(logstd[d]);
     const float eps = normals_row ? normals_row[d] : normal01(seed, counter, static_cast<uint64_t>(b) * 32 + d);
-    const float act = mu + sigma * eps;
-    actions_row[d] = act;
-    const float diff = act - mu;
-    lp += -(diff * diff) / (2.f * (sigma * sigma)) - logf(sigma) - kHalfLog2Pi;
+    lp += normal_act_dim(row[d], logstd[d], eps, actions_row + d);
   }
   return lp;
 }

@@ -131,44 +131,45 @@ __global__ __launch_bounds__(kThreads) void mlp_forward_fused_kernel(MlpFusedArg
 // dx_normal_act_f32 (heads_dev.hpp: normal_act_row) and dx_synth_mujoco_step's values.  The per-step loop is
 // ~11 launches per step (two native, the rest the env's); config 3's 64 steps took 2.3 ms of its 15.4 ms iteration.
 template <int DP>
-__global__ __launch_bounds__(kThreads) void mlp_rollout_synth_kernel(const MlpRolloutArgs a) {
+__global__ __launch_bounds__(2 * kThreads) void mlp_rollout_synth_kernel(const MlpRolloutArgs a) {
   constexpr int RPW = 2, R = 4 * RPW, LD0 = DP + 1;
   constexpr int kNet = kH * LD0 + kH * kLdT + kHeadLd * kLdT + 160;  // floats of one net's weights and biases
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *xs = lds + 2 * kNet;  // [R][DP]
-  float *hs = xs + R * DP;     // [R][64]
-  float *gs = hs + R * kH;     // [R][64]
-  float *hd = gs + R * kH;     // [R][32]: the policy's means, then the value
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float *xs = lds + 2 * kNet;     // [R][DP]
+  float *hsb = xs + R * DP;       // [2 nets][R][64]
+  float *gsb = hsb + 2 * R * kH;  // [2 nets][R][64]
+  float *hd = gsb + 2 * R * kH;   // [R][32]: the policy's means, then the value
+  float *lpt = hd + R * kHeadLd;  // [R][32]: the log-probability's terms per action dimension
+  // threads 0-255: the policy net, 256-511: the value net -- the two chains of a step run side by side
+  const int t = threadIdx.x, net = t >> 8, tt = t & 255, lane = tt & 63, wave = tt >> 6;
   const int D = a.f.D, P = a.f.P, N = a.f.B;
   const float *p = a.f.params;
-  for (int net = 0; net < 2; ++net) {
-    float *W0 = lds + net * kNet, *W1 = W0 + kH * LD0, *W2 = W1 + kH * kLdT, *bs = W2 + kHeadLd * kLdT;
-    const int outs = net == 0 ? P : 1;
+  float *W0 = lds + net * kNet, *W1 = W0 + kH * LD0, *W2 = W1 + kH * kLdT, *bs = W2 + kHeadLd * kLdT;
+  float *hs = hsb + net * R * kH, *gs = gsb + net * R * kH;
+  const int outs = net == 0 ? P : 1, col = net == 0 ? 0 : P;
+  {
     const float *w0 = p + a.f.off_w[3 * net], *w1 = p + a.f.off_w[3 * net + 1], *w2 = p + a.f.off_w[3 * net + 2];
-    for (int i = t; i < kH * DP; i += kThreads) {
+    for (int i = tt; i < kH * DP; i += kThreads) {
       const int j = i / DP, k = i - j * DP;
       W0[j * LD0 + k] = k < D ? w0[j * D + k] : 0.f;
     }
-    for (int i = t; i < kH * kH; i += kThreads) W1[(i >> 6) * kLdT + (i & 63)] = w1[i];
-    for (int i = t; i < kHeadLd * kH; i += kThreads) W2[(i >> 6) * kLdT + (i & 63)] = (i >> 6) < outs ? w2[i] : 0.f;
-    if (t < kH) {
-      bs[t] = p[a.f.off_b[3 * net] + t];
-      bs[kH + t] = p[a.f.off_b[3 * net + 1] + t];
-      if (t < kHeadLd) bs[2 * kH + t] = t < outs ? p[a.f.off_b[3 * net + 2] + t] : 0.f;
+    for (int i = tt; i < kH * kH; i += kThreads) W1[(i >> 6) * kLdT + (i & 63)] = w1[i];
+    for (int i = tt; i < kHeadLd * kH; i += kThreads) W2[(i >> 6) * kLdT + (i & 63)] = (i >> 6) < outs ? w2[i] : 0.f;
+    if (tt < kH) {
+      bs[tt] = p[a.f.off_b[3 * net] + tt];
+      bs[kH + tt] = p[a.f.off_b[3 * net + 1] + tt];
+      if (tt < kHeadLd) bs[2 * kH + tt] = tt < outs ? p[a.f.off_b[3 * net + 2] + tt] : 0.f;
     }
   }
   const long long row0 = static_cast<long long>(blockIdx.x) * R;
-  for (int i = t; i < R * DP; i += kThreads) {
+  for (int i = t; i < R * DP; i += 2 * kThreads) {
     const int r = i / DP, k = i - r * DP;
     xs[i] = (row0 + r < N && k < D) ? a.obs[(row0 + r) * D + k] : 0.f;
   }
   __syncthreads();
   const int r0 = wave * RPW;
   for (int step = 0; step < a.T; ++step) {
-    for (int net = 0; net < 2; ++net) {
-      const float *W0 = lds + net * kNet, *W1 = W0 + kH * LD0, *W2 = W1 + kH * kLdT, *bs = W2 + kHeadLd * kLdT;
-      const int outs = net == 0 ? P : 1, col = net == 0 ? 0 : P;
+    {
       float acc[RPW];
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr) acc[rr] = bs[lane];
@@ -182,45 +183,53 @@ __global__ __launch_bounds__(kThreads) void mlp_rollout_synth_kernel(const MlpRo
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr) gs[(r0 + rr) * kH + lane] = tanhf(acc[rr]);
       __syncthreads();
-      {
-        constexpr int HR = RPW / 2;
-        const int o = lane & 31, rh = r0 + (lane >> 5) * HR;
-        float out[HR];
+      constexpr int HR = RPW / 2;
+      const int o = lane & 31, rh = r0 + (lane >> 5) * HR;
+      float out[HR];
 #pragma unroll
-        for (int rr = 0; rr < HR; ++rr) out[rr] = bs[2 * kH + o];
-        dot_rows<HR, kH>(out, W2 + o * kLdT, gs + rh * kH, kH);
-        if (o < outs) {
+      for (int rr = 0; rr < HR; ++rr) out[rr] = bs[2 * kH + o];
+      dot_rows<HR, kH>(out, W2 + o * kLdT, gs + rh * kH, kH);
+      if (o < outs) {
 #pragma unroll
-          for (int rr = 0; rr < HR; ++rr) hd[(rh + rr) * kHeadLd + col + o] = out[rr];
-        }
-      }
-      __syncthreads();  // (hs / gs are rewritten by the next net; hd is read below)
-    }
-    // ---- sample (thread = row), then the env's step for these rows ----
-    const long long srow = static_cast<long long>(step) * N;
-    if (t < R && row0 + t < N) {
-      const long long b = row0 + t;
-      a.log_prob[srow + b] = normal_act_row(hd + t * kHeadLd, p + a.off_logstd, P, nullptr, a.policy_seed, a.policy_counter + step, b,
-                                            a.actions + (srow + b) * P);
-      a.values[srow + b] = hd[t * kHeadLd + P];
-    }
-    const uint64_t key = synth_mujoco_key(a.env_seed, a.env_counter + step);
-    float *next = a.obs + static_cast<long long>(step + 1) * N * D;
-    for (int i = t; i < R * DP; i += kThreads) {
-      const int r = i / DP, k = i - r * DP;
-      const long long b = row0 + r;
-      float v = 0.f;
-      if (b < N && k < D) {
-        v = synth_mujoco_obs(key, b, k);
-        next[b * D + k] = v;
-      }
-      xs[i] = v;
-      if (k == 0 && b < N) {
-        a.rewards[srow + b] = synth_mujoco_reward(key, b);
-        a.resets[srow + b] = synth_mujoco_reset(key, b, a.p_reset) ? 1 : 0;
+        for (int rr = 0; rr < HR; ++rr) hd[(rh + rr) * kHeadLd + col + o] = out[rr];
       }
     }
     __syncthreads();
+    // ---- sample: thread = (row, action dimension); the env's step for these rows by the other half ----
+    const long long srow = static_cast<long long>(step) * N;
+    if (t < R * 32) {
+      const int r = t >> 5, d = t & 31;
+      const long long b = row0 + r;
+      if (d < P && b < N)
+        lpt[r * 32 + d] = normal_act_dim(hd[r * kHeadLd + d], p[a.off_logstd + d], normal01(a.policy_seed, a.policy_counter + step, static_cast<uint64_t>(b) * 32 + d),
+                                         a.actions + (srow + b) * P + d);
+    } else {
+      const uint64_t key = synth_mujoco_key(a.env_seed, a.env_counter + step);
+      float *next = a.obs + static_cast<long long>(step + 1) * N * D;
+      const int i = t - R * 32;  // R * 32 <= 256 threads left: one (row, component) each for DP <= 32, two for 64
+      for (int j = i; j < R * DP; j += 2 * kThreads - R * 32) {
+        const int r = j / DP, k = j - r * DP;
+        const long long b = row0 + r;
+        float v = 0.f;
+        if (b < N && k < D) {
+          v = synth_mujoco_obs(key, b, k);
+          next[b * D + k] = v;
+        }
+        xs[j] = v;
+        if (k == 0 && b < N) {
+          a.rewards[srow + b] = synth_mujoco_reward(key, b);
+          a.resets[srow + b] = synth_mujoco_reset(key, b, a.p_reset) ? 1 : 0;
+        }
+      }
+    }
+    __syncthreads();
+    if (t < R && row0 + t < N) {  // the terms in dimension order, as dx_normal_act_f32 adds them
+      float lp = 0.f;
+      for (int d = 0; d < P; ++d) lp += lpt[t * 32 + d];
+      a.log_prob[srow + row0 + t] = lp;
+      a.values[srow + row0 + t] = hd[t * kHeadLd + P];
+    }
+    // (hd / lpt are rewritten only behind the next step's barriers)
   }
 }
 
@@ -424,7 +433,7 @@ int mlp_fused_tile_rows(int B, int obs_pad) {
 template <int DP>
 int rollout_as(const MlpRolloutArgs &a, hipStream_t s) {
   constexpr int R = 8;
-  constexpr size_t bytes = sizeof(float) * (2 * (kH * (DP + 1) + kH * kLdT + kHeadLd * kLdT + 160) + R * DP + 2 * R * kH + R * kHeadLd);
+  constexpr size_t bytes = sizeof(float) * (2 * (kH * (DP + 1) + kH * kLdT + kHeadLd * kLdT + 160) + R * DP + 4 * R * kH + 2 * R * kHeadLd);
   static_assert(bytes <= 160 * 1024, "LDS");
   static bool configured = false;
   if (!configured) {
@@ -432,7 +441,7 @@ int rollout_as(const MlpRolloutArgs &a, hipStream_t s) {
                                static_cast<int>(bytes)));
     configured = true;
   }
-  hipLaunchKernelGGL((mlp_rollout_synth_kernel<DP>), dim3(cdiv(a.f.B, R)), dim3(kThreads), bytes, s, a);
+  hipLaunchKernelGGL((mlp_rollout_synth_kernel<DP>), dim3(cdiv(a.f.B, R)), dim3(2 * kThreads), bytes, s, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
