@@ -17,18 +17,20 @@ namespace dx {
 namespace {
 
 constexpr int kH = 64, kHeadLd = 32, kThreads = 256;
-constexpr int kLdT = kH + 1;  // row stride of a 64-wide weight matrix read with lane = row
+constexpr int kLdT = kH + 4;  // row stride of a 64-wide weight matrix read with lane = row: 16-byte aligned rows (one
+                              // ds_read_b128 per four weights) whose 16-lane read groups still land on distinct banks (272 B = 17 quads)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
-// acc[rr] += sum_k w(k) * in[(row0 + rr) * ld + k], k in [0, K): W rows in LDS with odd stride
+// acc[rr] += sum_k w(k) * in[(row0 + rr) * ld + k], k in [0, K): W rows in LDS, stride = 4 (mod 8) floats
 template <int ROWS, int K>
 __device__ inline void dot_rows(float (&acc)[ROWS], const float *wrow, const float *in, int ld) {
 #pragma unroll 4
   for (int k = 0; k < K; k += 4) {
-    const float w0 = wrow[k], w1 = wrow[k + 1], w2 = wrow[k + 2], w3 = wrow[k + 3];
+    const f32x4 w = lds4(wrow + k);
+    const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
       const f32x4 x = lds4(in + rr * ld + k);
@@ -42,11 +44,11 @@ __device__ inline void dot_rows(float (&acc)[ROWS], const float *wrow, const flo
 
 template <int RPW, int DP>
 __global__ __launch_bounds__(kThreads) void mlp_forward_fused_kernel(MlpFusedArgs a) {
-  constexpr int R = 4 * RPW, LD0 = DP + 1;
+  constexpr int R = 4 * RPW, LD0 = DP + 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *W0 = lds;                  // [64][DP+1]
-  float *W1 = W0 + kH * LD0;        // [64][65]
-  float *W2 = W1 + kH * kLdT;       // [32][65]
+  float *W0 = lds;                  // [64][DP+4]
+  float *W1 = W0 + kH * LD0;        // [64][68]
+  float *W2 = W1 + kH * kLdT;       // [32][68]
   float *bs = W2 + kHeadLd * kLdT;  // b0[64] b1[64] b2[32]
   float *xs = bs + 160;             // [R][DP]
   float *hs = xs + R * DP;          // [R][64]
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void mlp_forward_fused_kernel(MlpFusedArg
 // ~11 launches per step (two native, the rest the env's); config 3's 64 steps took 2.3 ms of its 15.4 ms iteration.
 template <int DP>
 __global__ __launch_bounds__(2 * kThreads) void mlp_rollout_synth_kernel(const MlpRolloutArgs a) {
-  constexpr int RPW = 2, R = 4 * RPW, LD0 = DP + 1;
+  constexpr int RPW = 2, R = 4 * RPW, LD0 = DP + 4;
   constexpr int kNet = kH * LD0 + kH * kLdT + kHeadLd * kLdT + 160;  // floats of one net's weights and biases
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *xs = lds + 2 * kNet;     // [R][DP]
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(kThreads) void mlp_backward_fused_kernel(MlpFusedAr
 
 template <int RPW, int DP>
 constexpr size_t forward_lds() {
-  return sizeof(float) * (kH * (DP + 1) + kH * kLdT + kHeadLd * kLdT + 160 + 4 * RPW * DP + 2 * 4 * RPW * kH);
+  return sizeof(float) * (kH * (DP + 4) + kH * kLdT + kHeadLd * kLdT + 160 + 4 * RPW * DP + 2 * 4 * RPW * kH);
 }
 
 template <int RPW, int DP>
@@ -433,7 +435,7 @@ int mlp_fused_tile_rows(int B, int obs_pad) {
 template <int DP>
 int rollout_as(const MlpRolloutArgs &a, hipStream_t s) {
   constexpr int R = 8;
-  constexpr size_t bytes = sizeof(float) * (2 * (kH * (DP + 1) + kH * kLdT + kHeadLd * kLdT + 160) + R * DP + 4 * R * kH + 2 * R * kHeadLd);
+  constexpr size_t bytes = sizeof(float) * (2 * (kH * (DP + 4) + kH * kLdT + kHeadLd * kLdT + 160) + R * DP + 4 * R * kH + 2 * R * kHeadLd);
   static_assert(bytes <= 160 * 1024, "LDS");
   static bool configured = false;
   if (!configured) {
