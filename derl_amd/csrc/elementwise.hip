@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const uint8_t *sr
 
 // Up to kMaxGather arrays gathered by ONE index vector in one launch (blockIdx.y = array):
 // the minibatch selection of every small per-sample array of a rollout.
-constexpr int kMaxGather = 8;
+constexpr int kMaxGather = 16;
 struct GatherTable {
   const uint8_t *src[kMaxGather];
   uint8_t *dst[kMaxGather];

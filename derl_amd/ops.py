@@ -136,12 +136,12 @@ def gather_rows(src, idx, out=None):
 
 
 def gather_rows_multi(sources, idx):
-  """[src[idx] for src in sources] along dim 0 with one launch per 8 arrays."""
+  """[src[idx] for src in sources] along dim 0 with one launch per 16 arrays."""
   _dev(idx, "idx", torch.int32)
   n = idx.numel()
   outs = []
-  for start in range(0, len(sources), 8):
-    group = sources[start:start + 8]
+  for start in range(0, len(sources), 16):
+    group = sources[start:start + 16]
     k = len(group)
     src_p, dst_p, rb = (_lib.c_void_p * k)(), (_lib.c_void_p * k)(), (_lib.c_longlong * k)()
     for i, src in enumerate(group):

@@ -199,7 +199,7 @@ class IterateWithMinibatches(RunnerWrapper):
 
   @staticmethod
   def _gather_epoch(interactions, order_dev):
-    """Device arrays with small rows, permuted for a whole epoch by ONE gather launch (per 8
+    """Device arrays with small rows, permuted for a whole epoch by ONE gather launch (per 16
     arrays): the epoch's minibatches are then contiguous slices, exactly the reference's
     shuffle-in-place-then-slice (onpolicy.py:44-62) without touching the rollout buffers."""
     if order_dev is None:

@@ -127,7 +127,7 @@ int dx_host_compose_permutations(uint32_t *mt_key_host, int *mt_pos_host, long l
  * gathered by index inside the conv loader instead of being copied). */
 int dx_gather_rows(const void *src, const int32_t *idx, void *dst, long long nrows,
                    long long row_bytes, void *stream);
-/* The same selection for up to 8 arrays sharing one index vector, in one launch (host
+/* The same selection for up to 16 arrays sharing one index vector, in one launch (host
  * arrays of narrays device pointers / row sizes): onpolicy.py:59-62 loops over every key of
  * the interactions dict. */
 int dx_gather_rows_multi(const void *const *src, void *const *dst, const long long *row_bytes,

@@ -105,15 +105,17 @@ def test_gather_rows(shape, dtype):
   nt.assert_array_equal(out, src[idx])  # bit-exact: byte movement
 
 
-@pytest.mark.parametrize("narrays", [1, 5, 8, 11])
+@pytest.mark.parametrize("narrays", [1, 5, 8, 11, 16, 19])
 def test_gather_rows_multi(narrays):
-  """Several per-sample arrays selected by one index vector in one launch (per 8 arrays)."""
+  """Several per-sample arrays selected by one index vector in one launch (per 16 arrays)."""
   from derl_amd import ops
   rs = np.random.RandomState(narrays)
   n = 333
   specs = [((n,), np.float32), ((n, 1), np.float32), ((n,), np.int64), ((n, 3), np.uint8),
            ((n,), np.uint8), ((n, 17), np.float32), ((n, 2), np.float64), ((n, 5), np.int32),
-           ((n, 1), np.float32), ((n,), np.int64), ((n, 7), np.uint8)][:narrays]
+           ((n, 1), np.float32), ((n,), np.int64), ((n, 7), np.uint8), ((n, 6), np.float32), ((n,), np.float32),
+           ((n, 2), np.int64), ((n, 9), np.uint8), ((n, 4), np.float32), ((n,), np.uint8), ((n, 3), np.float64),
+           ((n, 1), np.int32)][:narrays]
   sources = [rs.uniform(0, 255, size=shape).astype(dtype) for shape, dtype in specs]
   idx = rs.randint(0, n, size=200).astype(np.int32)  # repeats allowed
   outs = ops.gather_rows_multi([t(src) for src in sources], t(idx))
