@@ -228,9 +228,21 @@ __device__ __forceinline__ void load_pair(const uint8_t *smem, const int (&pb)[N
     for (int pl = 0; pl < 3; ++pl) x[h][pl] = *reinterpret_cast<const u32x4 *>(smem + pb[2 * PR + h] + off + pl * plane);
 }
 
-template <int LAYER, int KH, int NT, int NS, int S, int PR>
+// The NEXT phase's weight fragments can ride along: K step S of the loop issues the three loads of step S of `next`
+// (COUNT steps, unconditionally: a branch per load would cut the MFMA stream into basic blocks).  Used by the training
+// forward only (conv2's fragments under conv1, the next image's conv1 taps 0-5 under conv2: the bursts of 18-27
+// loads between the layers stall the issuing wave for ~4,000 cycles per image); in the rollout flavour the 72 extra
+// live registers next to the policy's tail spill.
+template <int NN, int COUNT>
+struct NextWeights {
+  const uint16_t *base;  // this wave's first piece (uniform)
+  unsigned lane_bytes;
+  u32x4 (&w)[NN][3];     // (a reference: a pointer would send the fragments through scratch memory)
+};
+
+template <int LAYER, int KH, int NT, int NS, int S, int PR, int NN, int COUNT>
 __device__ __forceinline__ void conv_half_from(const uint8_t *smem, const int (&pb)[NT], const u32x4 (&w)[NS][3], f32x4 (&acc)[NT],
-                                               u32x4 (&x)[2][3]) {
+                                               u32x4 (&x)[2][3], const NextWeights<NN, COUNT> &next) {
   constexpr bool last = S == NS - 1 && PR == NT / 2 - 1;
   constexpr int SN = PR + 1 < NT / 2 ? S : S + 1, PN = PR + 1 < NT / 2 ? PR + 1 : 0;
   u32x4 xn[2][3];
@@ -240,21 +252,26 @@ __device__ __forceinline__ void conv_half_from(const uint8_t *smem, const int (&
   // wave waiting for LDS after every five: 40 cycles per MFMA where the pipe needs 16, and the older wave of a
   // SIMD kept the pipe from the younger -- the halves of conv1 finished 7,000 cycles apart)
   if constexpr (!last) load_pair<LAYER, KH, SN, PN, NT>(smem, pb, xn);
+  if constexpr (PR == NT / 2 - 1 && S < COUNT) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) next.w[S][pl] = load16(next.base + (S * 3 + pl) * 512, next.lane_bytes);
+  }
   __builtin_amdgcn_sched_barrier(0);
   acc[2 * PR] = mac_rest(acc[2 * PR], w[S], x[0]);
   acc[2 * PR + 1] = mac_rest(mac_first(acc[2 * PR + 1], w[S], x[1]), w[S], x[1]);
-  if constexpr (!last) conv_half_from<LAYER, KH, NT, NS, SN, PN>(smem, pb, w, acc, xn);
+  if constexpr (!last) conv_half_from<LAYER, KH, NT, NS, SN, PN, NN, COUNT>(smem, pb, w, acc, xn, next);
 }
 
 // One K half of conv1 (KH: taps 8 KH .. 8 KH + 7) or conv2 (KH: steps 9 KH .. 9 KH + 8 of 18) for this wave's
 // 16 channels: NT pixel tiles two at a time, activations from the LDS planes (pb = byte address of the
 // lane's pixel and k group in plane 0).
-template <int LAYER, int KH, int NT, int NS>
-__device__ __forceinline__ void conv_half(const uint8_t *smem, const int (&pb)[NT], const u32x4 (&w)[NS][3], f32x4 (&acc)[NT]) {
+template <int LAYER, int KH, int NT, int NS, int NN, int COUNT>
+__device__ __forceinline__ void conv_half(const uint8_t *smem, const int (&pb)[NT], const u32x4 (&w)[NS][3], f32x4 (&acc)[NT],
+                                          const NextWeights<NN, COUNT> &next) {
   static_assert(NT % 2 == 0, "tiles go in pairs");
   u32x4 x[2][3];
   load_pair<LAYER, KH, 0, 0, NT>(smem, pb, x);
-  conv_half_from<LAYER, KH, NT, NS, 0, 0>(smem, pb, w, acc, x);
+  conv_half_from<LAYER, KH, NT, NS, 0, 0, NN, COUNT>(smem, pb, w, acc, x, next);
 }
 
 // the K halves' exchange: tiles FROM .. FROM + N - 1 of this wave's accumulators go to its partner
@@ -363,22 +380,26 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const unsigned off1 = static_cast<unsigned>(lane * 16), off2 = off1;
 
+  // conv1's weight fragments: A fragment of v_mfma_f32_16x16x32_bf16 = 8 consecutive k of row (channel) 16 nt + n16:
+  // plane pl, tap 8 kh2 + s, k group kq.  Taps 0-5 travel while conv0 runs (a rollout step fetches them at its top, a
+  // training image's arrive under the previous image's conv2 loop), taps 6-7 after conv0, whose two-tile waves need
+  // the registers.
+  u32x4 w1[8][3];
+  auto fetch_w1_head = [&]() {
+    const unsigned o1 = static_cast<unsigned>(opaque(static_cast<int>(off1)));
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load16(a.Wf1 + ((wave_s * 8 + s) * 3 + pl) * 512, o1);
+  };
+  if (TRAIN) fetch_w1_head();
   for (t = 0; t < steps; ++t) {
     if (t > 0) { DX_CS_MARK(0) }
     if (TRAIN && t > 0) {
       e += gridDim.x;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the image's frame (LDS-DMA, below) have landed
     }
-    // conv1's weight fragments travel while conv0 runs: A fragment of v_mfma_f32_16x16x32_bf16 = 8 consecutive k
-    // of row (channel) 16 nt + n16: plane pl, tap 8 kh2 + s, k group kq
-    u32x4 w1[8][3];
-    {  // (the last two taps' fragments after conv0, whose two-tile waves need the registers)
-      const unsigned o1 = static_cast<unsigned>(opaque(static_cast<int>(off1)));
-#pragma unroll
-      for (int s = 0; s < 6; ++s)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load16(a.Wf1 + ((wave_s * 8 + s) * 3 + pl) * 512, o1);
-    }
+    if (!TRAIN) fetch_w1_head();
     lds_barrier();  // this step's frame (and, at step 0, conv0's planes) are in LDS
     DX_CS_MARK(1)
 
@@ -420,8 +441,15 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       }
       f32x4 acc[6] = {zero4, zero4, zero4, zero4, zero4, zero4};
       DX_CS_MARK(12)
-      if (kh2 == 0) conv_half<1, 0, 6, 8>(smem, pb, w1, acc);
-      else conv_half<1, 1, 6, 8>(smem, pb, w1, acc);
+      if constexpr (TRAIN) {  // conv2's fragments travel under this loop, K step s fetching step s of them
+        const NextWeights<9, 8> nw2{a.Wf2 + wave_s * (9 * 3 * 512), static_cast<unsigned>(opaque(static_cast<int>(off2))), w2};
+        if (kh2 == 0) conv_half<1, 0, 6, 8>(smem, pb, w1, acc, nw2);
+        else conv_half<1, 1, 6, 8>(smem, pb, w1, acc, nw2);
+      } else {
+        const NextWeights<9, 0> none{nullptr, 0u, w2};
+        if (kh2 == 0) conv_half<1, 0, 6, 8>(smem, pb, w1, acc, none);
+        else conv_half<1, 1, 6, 8>(smem, pb, w1, acc, none);
+      }
       DX_CS_MARK(13)
       const int oc0 = 16 * nt + 4 * kq;  // the four channels of this lane's D rows
       const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);  // (ahead of the 27 loads below: vmcnt returns in order)
@@ -429,7 +457,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
       // conv2's fragments travel under the exchange (conv1's have just freed their registers)
       const unsigned o2 = static_cast<unsigned>(opaque(static_cast<int>(off2)));
 #pragma unroll
-      for (int s = 0; s < 9; ++s)
+      for (int s = TRAIN ? 8 : 0; s < 9; ++s)  // (training: steps 0-7 came under the loop above)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) w2[s][pl] = load16(a.Wf2 + ((wave_s * 9 + s) * 3 + pl) * 512, o2);
       DX_CS_MARK(3)
@@ -485,8 +513,15 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
         pb[mt] = oY1 + oy * kY1R + ox * kY1P + 16 * kq;
       }
       f32x4 acc[4] = {zero4, zero4, zero4, zero4};
-      if (kh2 == 0) conv_half<2, 0, 4, 9>(smem, pb, w2, acc);
-      else conv_half<2, 1, 4, 9>(smem, pb, w2, acc);
+      if constexpr (TRAIN) {  // the next image's conv1 fragments, taps 0-5 (also behind the last image: nobody reads them)
+        const NextWeights<8, 6> nw1{a.Wf1 + wave_s * (8 * 3 * 512), static_cast<unsigned>(opaque(static_cast<int>(off1))), w1};
+        if (kh2 == 0) conv_half<2, 0, 4, 9>(smem, pb, w2, acc, nw1);
+        else conv_half<2, 1, 4, 9>(smem, pb, w2, acc, nw1);
+      } else {
+        const NextWeights<8, 0> none{nullptr, 0u, w1};
+        if (kh2 == 0) conv_half<2, 0, 4, 9>(smem, pb, w2, acc, none);
+        else conv_half<2, 1, 4, 9>(smem, pb, w2, acc, none);
+      }
       DX_CS_MARK(5)
       __builtin_amdgcn_sched_barrier(0);  // (conv2's fragments are dead from here: room for the tail's weights)
       const int p_keep0 = 16 * (kh2 == 0 ? 0 : 2) + n16;

@@ -53,8 +53,12 @@ __global__ __launch_bounds__(512) void ubench_kernel(const uint8_t *wsrc, float 
           acc[2 * pr] = mac_rest(mac_first(acc[2 * pr], w1[s], x[0]), w1[s], x[0]);
           acc[2 * pr + 1] = mac_rest(mac_first(acc[2 * pr + 1], w1[s], x[1]), w1[s], x[1]);
         }
-    } else if (kh2 == 0) conv_half<1, 0, 6, 8>(smem, pb, w1, acc);
-    else conv_half<1, 1, 6, 8>(smem, pb, w1, acc);
+    } else {
+      u32x4 unused[9][3];
+      const NextWeights<9, 0> none{nullptr, 0u, unused};
+      if (kh2 == 0) conv_half<1, 0, 6, 8>(smem, pb, w1, acc, none);
+      else conv_half<1, 1, 6, 8>(smem, pb, w1, acc, none);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long t1 = __builtin_readcyclecounter();
