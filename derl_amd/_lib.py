@@ -15,7 +15,7 @@ if os.environ.get("DERL_AMD_LIBRARY", "") == "diag":
   LIB_PATH = os.path.join(_PKG, "libderl_amd_diag.so")
 elif os.environ.get("DERL_AMD_LIBRARY", "").endswith(".so"):  # another build of the library (tools/: A/B on one box)
   LIB_PATH = os.path.join(_PKG, os.path.basename(os.environ["DERL_AMD_LIBRARY"]))
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_int, c_float, c_void_p, c_char_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p
 c_size_t, c_int64, c_uint64, c_double = ctypes.c_size_t, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
@@ -77,6 +77,7 @@ SIGNATURES = {
     "dx_cnn_rollout_synth": [P, P, c_int, c_int, P, P, P, P, P, c_uint64, c_uint64, c_uint64,
                              c_uint64, c_float, c_float, P],
     "dx_cnn_ppo_epoch": [P, P, P],
+    "dx_comm_available": [],
     "dx_comm_unique_id": [P],
     "dx_comm_init": [P, c_int, c_int],
     "dx_comm_info": [P, P, P, P],
@@ -110,7 +111,13 @@ _lib = None
 
 
 class NativeError(RuntimeError):
-  """A C-ABI call failed (carries dx_last_error())."""
+  """A C-ABI call failed (carries dx_last_error(); ``status`` = the call's return code, one of the
+  DX_E* values of include/derl_amd.h, or None when no call was made)."""
+  status = None
+
+
+# return codes of include/derl_amd.h
+DX_EINVAL, DX_EHIP, DX_ENOSUP, DX_EWS, DX_ETIMEOUT = -1, -2, -3, -4, -5
 
 
 def load():
@@ -142,7 +149,9 @@ def last_error():
 
 def check(status, what):
   if status != 0:
-    raise NativeError(f"{what} failed with status {status}: {last_error()}")
+    error = NativeError(f"{what} failed with status {status}: {last_error()}")
+    error.status = status
+    raise error
 
 
 def call(name, *args):

@@ -52,9 +52,16 @@ std::mutex g_lock;
 
 int load_rccl() {
   if (g_rccl.handle) return DX_OK;
+  void *h = nullptr;
+  // DERL_AMD_RCCL_LIBRARY=<path>: this RCCL build and no other (a site's own build; also how the
+  // two-rank bootstrap test makes ONE rank really unable to load it)
+  const char *forced = getenv("DERL_AMD_RCCL_LIBRARY");
+  if (forced && *forced) {
+    h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(DX_ENOSUP, "dx_comm: cannot load RCCL from DERL_AMD_RCCL_LIBRARY=%s: %s", forced, dlerror());
+  }
   // the copy already in the process first (inside torch: torch/lib/librccl.so, soname librccl.so.1)
   const char *names[] = {"librccl.so.1", "librccl.so"};
-  void *h = nullptr;
   for (const char *n : names)
     if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
   for (const char *n : names)
@@ -133,8 +140,10 @@ int comm_in_stream(const char *who, hipStream_t stream, Issue issue) {
   DX_HIP(hipStreamWaitEvent(g_comm.stream, g_comm.ready, 0));
   if (int rc = issue(g_comm.stream)) return rc;
   DX_HIP(hipEventRecord(g_comm.done, g_comm.stream));
-  DX_HIP(hipStreamWaitEvent(stream, g_comm.done, 0));  // in-order stream: covers pending reductions too
-  g_comm.pending = false;
+  // (in-order communicator stream: `done` also covers the gradient reductions issued before it -- for THIS
+  // caller stream.  `pending` stays set: the reductions' owner may be another stream, whose dx_allreduce_wait
+  // must still wait; waiting again for the newest `done` event is harmless)
+  DX_HIP(hipStreamWaitEvent(stream, g_comm.done, 0));
   return DX_OK;
 }
 
@@ -180,6 +189,16 @@ int dx_comm_unique_id(void *id_out_host) {
   if (int rc = load_rccl()) return rc;
   static_assert(sizeof(ncclUniqueId) == DX_COMM_ID_BYTES, "unique id size");
   DX_NCCL(g_rccl.GetUniqueId(static_cast<ncclUniqueId *>(id_out_host)));
+  return DX_OK;
+}
+
+int dx_comm_available(void) {
+  DX_TRACE("dx_comm_available");
+  std::lock_guard<std::mutex> guard(g_lock);
+  DX_REQUIRE(g_comm.comm == nullptr, "dx_comm_available: a communicator already exists (dx_comm_destroy first)");
+  if (int rc = load_rccl()) return rc;
+  int dev = -1;
+  DX_HIP(hipGetDevice(&dev));
   return DX_OK;
 }
 

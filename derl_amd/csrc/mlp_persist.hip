@@ -116,6 +116,16 @@ __device__ __forceinline__ double ld_d(const double *p) {
                                                       __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// The timeout word: 0 = no give-up so far; 1 + 2 x minibatch + barrier = the first give-up; kCommitted = workgroup 0
+// decided to write the epoch's results back (a compare-and-swap from 0 at the last barrier's far side: the ONE word
+// orders that decision against a give-up at the same barrier -- whichever swap lands first stands, so "gave up" and
+// "stepped" exclude each other).
+constexpr unsigned kCommitted = 0x7fffffffu;
+__device__ __forceinline__ bool timed_out(const PersistArgs &a) {
+  const unsigned w = __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return w != 0 && w != kCommitted;
+}
+
 // Grid barrier: every wave has drained its stores, one lane arrives, polls until `target` arrivals.
 // `code` = 1 + 2 x minibatch + (0 | 1): what a give-up leaves in the timeout word.
 __device__ __forceinline__ void grid_barrier(const PersistArgs &a, unsigned target, int *dead, unsigned code) {
@@ -128,12 +138,13 @@ __device__ __forceinline__ void grid_barrier(const PersistArgs &a, unsigned targ
       while (__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(2);
         ++spins;
-        if (spins > a.spin_limit ||
-            ((spins & 1023u) == 0 && __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        if (spins > a.spin_limit || ((spins & 1023u) == 0 && timed_out(a))) {
           unsigned expected = 0;  // the first give-up names the barrier
           __hip_atomic_compare_exchange_strong(a.timeout, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
-          *dead = 1;  // give up for good: later barriers only arrive
+          // kCommitted: workgroup 0 passed the epoch's LAST barrier and took the write-back decision before this
+          // give-up could register -- every workgroup had arrived, the epoch is complete and stands
+          if (expected != kCommitted) *dead = 1;  // give up for good: later barriers only arrive
           break;
         }
       }
@@ -143,10 +154,9 @@ __device__ __forceinline__ void grid_barrier(const PersistArgs &a, unsigned targ
 }
 // after a barrier: did any workgroup give up so far?  (a give-up's store is complete before that
 // workgroup's NEXT arrival -- s_waitcnt vmcnt(0) opens every barrier -- so whoever passed a later
-// barrier sees it; a give-up at the very last barrier is the workgroup's own `dead`)
-__device__ __forceinline__ bool gave_up(const PersistArgs &a, const int *dead) {
-  return *dead != 0 || __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-}
+// barrier sees it; a give-up at the very last barrier is the workgroup's own `dead`, or loses the
+// compare-and-swap against workgroup 0's commit and does not count)
+__device__ __forceinline__ bool gave_up(const PersistArgs &a, const int *dead) { return *dead != 0 || timed_out(a); }
 
 // aligned vec4 index -> (LDS index of its first element, validity bits of its four elements,
 // canonical index of its first element); the four elements are consecutive in all three layouts
@@ -236,8 +246,9 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
       __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, static_cast<int>(static_cast<long long>(G) * kTotalA * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_gral = __builtin_amdgcn_make_buffer_rsrc(a.gral, 0, kTotalA * 4, 0x00020000);
 
-  // a workspace poisoned by an earlier give-up: nothing runs on it again (uniform over the grid: the
-  // word is only ever written at the END of a launch)
+  // a workspace poisoned by an earlier give-up: nothing runs on it again.  (The word is only ever written at the
+  // END of a launch; a workgroup that STARTS so late that the others have already given up on it and finished may
+  // read their word and leave at once -- the launch has failed by then, and says so.)
   if (__hip_atomic_load(a.sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   // ---- epoch start: the model into LDS, this thread's share of the Adam moments into registers ----
   for (int i = t; i < 2 * kNetLds + 32 + kR * kLd0 + 6 * kR * kLd1 + 3 * kR * kLd0; i += kT) Wl[i] = 0.f;
@@ -643,8 +654,16 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
             c = c < 1.f ? c : 1.f;
           }
           coef_s[0] = c;
-          // the epoch's results go back to the caller only if no barrier of the epoch gave up
-          coef_s[1] = (k == a.nmb - 1 && wg == 0 && !gave_up(a, dead)) ? 1.f : 0.f;
+          // the epoch's results go back to the caller only if no barrier of the epoch gave up: decided by ONE
+          // compare-and-swap of the timeout word (0 -> kCommitted), so that a give-up at this last barrier either
+          // registered before it (no write-back, DX_ETIMEOUT) or fails against it (the epoch stands)
+          bool commit = false;
+          if (k == a.nmb - 1 && wg == 0 && *dead == 0) {
+            unsigned expected = 0;
+            commit = __hip_atomic_compare_exchange_strong(a.timeout, &expected, kCommitted, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+          }
+          coef_s[1] = commit ? 1.f : 0.f;
         }
       }
       __syncthreads();

@@ -75,25 +75,31 @@ def init_from_env(backend=None):
     try:
       init_native_comm()
     except _lib.NativeError as error:
-      # init_native_comm raises on EVERY rank or on none (its ranks agree through a MIN all-reduce
-      # before any of them leaves): without the library's communicator the whole run continues on
+      # init_native_comm raises on EVERY rank or on none (its ranks agree through MIN all-reduces
+      # before any of them enters ncclCommInitRank and before any leaves): without the library's communicator the whole run continues on
       # torch.distributed's own RCCL collectives, update by update
       print(f"derl_amd: native RCCL communicator unavailable ({error}); using torch.distributed", flush=True)
   return world_size()
 
 
 def init_native_comm():
-  """Creates the library's RCCL communicator over the ranks of the default process group: rank 0
-  makes the unique id (dx_comm_unique_id), one torch.distributed broadcast hands it out, every
-  rank joins (dx_comm_init) on its current device.
+  """Creates the library's RCCL communicator over the ranks of the default process group: every
+  rank checks that it CAN join (dx_comm_available: RCCL loads, no communicator exists, the device
+  answers), rank 0 makes the unique id (dx_comm_unique_id), one torch.distributed broadcast hands
+  it out, every rank joins (dx_comm_init) on its current device.
 
-  The ranks AGREE on the outcome before any of them acts on it.  A rank whose library call fails
-  keeps the error to itself and still takes part in both bootstrap collectives: rank 0 broadcasts
-  an all-zero id when it could not make one (a real id is never all zero), and a MIN all-reduce of
-  the per-rank success flags follows dx_comm_init.  Either every rank returns with the
-  communicator up, or every rank tears its own down again and raises NativeError -- no rank is
-  left waiting in a collective the others never enter, and no two ranks disagree on whether the
-  data path reduces through the library or through torch.distributed."""
+  The ranks AGREE before they act, twice.  (1) ncclCommInitRank is itself a collective over all
+  ranks: a rank that skipped it would leave the others blocked inside it.  So no rank enters it
+  unless a MIN all-reduce of the per-rank readiness flags says that every rank will -- the
+  failures a rank can have on its own (RCCL not loadable, a communicator left over, no device)
+  are all caught by dx_comm_available, which has no side effects.  (2) What can still fail is the
+  id on rank 0 (it then broadcasts an all-zero id -- a real one never is -- and nobody calls
+  dx_comm_init) and ncclCommInitRank itself, which RCCL reports on every rank that is in it; a
+  second MIN all-reduce of the per-rank outcomes follows dx_comm_init.  Either every rank returns
+  with the communicator up, or every rank tears its own down again and raises NativeError, and no
+  two ranks disagree on whether the data path reduces through the library or through
+  torch.distributed.  (Not covered: a rank that dies or hangs INSIDE ncclCommInitRank -- RCCL's
+  own timeout / abort is what ends that.)"""
   global _native  # pylint: disable=global-statement
   if _native:
     return
@@ -102,8 +108,17 @@ def init_native_comm():
                        "travels over it)")
   on_gpu = dist.get_backend() == "nccl"
   device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-  ident = (ctypes.c_ubyte * 128)()
   problem = None
+  try:
+    _lib.call("dx_comm_available")
+  except _lib.NativeError as error:
+    problem = error
+  ready = torch.tensor([0 if problem else 1], dtype=torch.int32, device=device)
+  dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+  if int(ready.item()) == 0:
+    raise _lib.NativeError(str(problem) if problem is not None else
+                           "another rank cannot join an RCCL communicator (dx_comm_available failed there)")
+  ident = (ctypes.c_ubyte * 128)()
   if rank() == 0:
     try:
       _lib.call("dx_comm_unique_id", ctypes.byref(ident))

@@ -170,11 +170,22 @@ class _MlpActorCritic(nn.Module):
       return False
     if getattr(self, "_rollout_unsupported", False):
       return False
+    # the kernel takes raw pointers: what it assumes about them is checked here
+    nenvs = int(env.nenvs)
+    if obs.ndim != 3 or obs.shape[0] < horizon + 1 or obs.shape[1] != nenvs or obs.shape[2] != self.engine.obs_dim:
+      raise ValueError(f"rollout buffers: observations {tuple(obs.shape)} do not fit horizon {horizon}, "
+                       f"{nenvs} envs x {self.engine.obs_dim} components")
+    for key in ("obs", "actions", "log_prob", "values", "rewards", "resets"):
+      t = buffers[key]
+      if not t.is_cuda or not t.is_contiguous() or (key != "obs" and (t.shape[0] < horizon or t.shape[1] != nenvs)):
+        raise ValueError(f"rollout buffers: '{key}' must be a contiguous device array of (>= {horizon}, {nenvs}, ...)")
     try:
-      self.engine.rollout_synth(buffers, horizon, env.nenvs, policy.seed, policy.act_counter, env.seed, env.counter,
+      self.engine.rollout_synth(buffers, horizon, nenvs, policy.seed, policy.act_counter, env.seed, env.counter,
                                 env.p_reset)
-    except _lib.NativeError as error:  # the layer-by-layer route (DX_MLP_UNFUSED=1): no one-launch rollout
-      if "dx_mlp_rollout_synth" not in str(error):
+    except _lib.NativeError as error:
+      # ONLY "this configuration has no one-launch rollout" (DX_ENOSUP: the layer-by-layer route, DX_MLP_UNFUSED=1)
+      # selects the per-step loop; a bad argument or a failed launch is an error, not a route
+      if error.status != _lib.DX_ENOSUP:
         raise
       self._rollout_unsupported = True
       return False

@@ -40,7 +40,7 @@ extern "C" {
 #define DX_EWS (-4)      /* workspace too small                                     */
 #define DX_ETIMEOUT (-5) /* a persistent kernel's grid barrier gave up (dx_mlp_ppo_epoch) */
 
-#define DX_ABI_VERSION 5
+#define DX_ABI_VERSION 6
 
 int dx_abi_version(void);
 const char *dx_last_error(void);
@@ -272,7 +272,8 @@ int dx_cnn_backward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
  * dx_cnn_backward_part(part = 2 [then 1], or 3).  norm_stats != NULL: `advantages` are raw and
  * normalised here with {sum, sumsq, n} (derl/runners/trajectory_transforms.py:89-92), written to
  * adv_normalized_out if given.  `counter`: one word, zero before the first call (the launch leaves
- * it zero).  `partials`: >= 8 * ceil(B / 64) doubles.  DX_ENOSUP for more than 7 actions.
+ * it zero).  `partials`: >= 8 * ceil(B / 8) doubles covers every route (the factored tail asks for
+ * 8 * min(ceil(B / 16), 256), the layer-by-layer heads for 8 * ceil(B / 64); less is DX_EINVAL).  DX_ENOSUP for more than 7 actions.
  *
  * Routes (same outputs and gradients, other association / arithmetic; csrc/cnn.hip):
  *  - 84 x 84 uint8 frames: the three conv layers of the whole minibatch are ONE launch of the image-resident
@@ -546,6 +547,11 @@ int dx_synth_mujoco_step(float *obs, float *rewards, uint8_t *resets, int nenvs,
  *   dx_comm_unique_id   rank 0 makes the 128-byte id (HOST buffer); the host side hands it to
  *                       the other ranks by any means (derl_amd/distributed.py: one
  *                       torch.distributed broadcast -- the only thing torch.distributed does).
+ *   dx_comm_available   side-effect-free readiness check of THIS rank: RCCL loads (dlopen; the
+ *                       library named by DERL_AMD_RCCL_LIBRARY if set), no communicator exists yet,
+ *                       the current device answers.  ncclCommInitRank is itself a collective, so
+ *                       the ranks must agree that all of them can enter it BEFORE any does
+ *                       (derl_amd/distributed.py: a MIN all-reduce of this call's outcome).
  *   dx_comm_init        collective: every rank calls it with the same id, on its own device.
  *   dx_allreduce_grads  in-place SUM of count floats, ASYNCHRONOUS to `stream`: it starts once
  *                       the work already enqueued on `stream` is done, and runs on the
@@ -564,6 +570,7 @@ int dx_synth_mujoco_step(float *obs, float *rewards, uint8_t *resets, int nenvs,
  * Not thread-safe against concurrent use of the same communicator.
  * --------------------------------------------------------------------------------- */
 #define DX_COMM_ID_BYTES 128
+int dx_comm_available(void);
 int dx_comm_unique_id(void *id_out_host);
 int dx_comm_init(const void *unique_id_host, int rank, int world);
 /* any output may be NULL; world = 0 when there is no communicator */

@@ -77,9 +77,13 @@ def bootstrap_agreement():
   real_call = _lib.call
   log = []
 
-  def scripted(fail_id_on=None, fail_init_on=None):
+  def scripted(fail_id_on=None, fail_init_on=None, unavailable_on=None):
     def call(name, *args):
       log.append(name)
+      if name == "dx_comm_available":
+        if rank == unavailable_on:
+          raise _lib.NativeError("scripted: RCCL cannot be loaded")
+        return 0
       if name == "dx_comm_unique_id":
         if rank == fail_id_on:
           raise _lib.NativeError("scripted: no unique id")
@@ -118,20 +122,68 @@ def bootstrap_agreement():
   # rank 1 cannot join: both fall back, rank 0 (which had joined) destroys its communicator
   outcome, native, calls = attempt(fail_init_on=1)
   assert outcome.startswith("fallback") and not native, (rank, outcome)
-  assert calls == (["dx_comm_unique_id", "dx_comm_init", "dx_comm_destroy"] if rank == 0 else ["dx_comm_init"]), calls
+  assert calls == (["dx_comm_available", "dx_comm_unique_id", "dx_comm_init", "dx_comm_destroy"] if rank == 0
+                   else ["dx_comm_available", "dx_comm_init"]), calls
   # rank 0 cannot join: the same, mirrored
   outcome, native, calls = attempt(fail_init_on=0)
   assert outcome.startswith("fallback") and not native, (rank, outcome)
-  assert calls == (["dx_comm_unique_id", "dx_comm_init"] if rank == 0 else ["dx_comm_init", "dx_comm_destroy"]), calls
+  assert calls == (["dx_comm_available", "dx_comm_unique_id", "dx_comm_init"] if rank == 0
+                   else ["dx_comm_available", "dx_comm_init", "dx_comm_destroy"]), calls
   # rank 0 cannot even make the id: it still broadcasts (zeros); nobody calls dx_comm_init
   outcome, native, calls = attempt(fail_id_on=0)
   assert outcome.startswith("fallback") and not native, (rank, outcome)
-  assert calls == (["dx_comm_unique_id"] if rank == 0 else []), calls
+  assert calls == (["dx_comm_available", "dx_comm_unique_id"] if rank == 0 else ["dx_comm_available"]), calls
+  # a rank that cannot join at all (RCCL not loadable ...): NOBODY makes an id or enters dx_comm_init --
+  # ncclCommInitRank is a collective, the ready rank would wait in it for the other
+  for who in (0, 1):
+    outcome, native, calls = attempt(unavailable_on=who)
+    assert outcome.startswith("fallback") and not native, (rank, outcome)
+    assert calls == ["dx_comm_available"], calls
   # nothing fails: both ranks have the communicator
   outcome, native, calls = attempt()
   assert outcome == "native" and native, (rank, outcome)
   assert "dx_comm_destroy" not in calls
   print(f"rank {rank}: bootstrap_agreement OK", flush=True)
+
+
+def bootstrap_real_failure():
+  """The same agreement with the REAL library calls (gloo; with or without a GPU): rank 1's library is
+  pointed at an RCCL that does not exist (DERL_AMD_RCCL_LIBRARY), so its dx_comm_available really fails in
+  dlopen.  Both ranks must leave init_native_comm with NativeError, neither may have made an id or entered
+  dx_comm_init (a collective the other rank would never join), and the process group's next collective
+  still matches up."""
+  from derl_amd import _lib
+  world, rank = distributed.world_size(), distributed.rank()
+  assert world == 2
+  if rank == 1:
+    os.environ["DERL_AMD_RCCL_LIBRARY"] = "/nonexistent/librccl-for-the-bootstrap-test.so"
+  real_call, log = _lib.call, []
+
+  def logging_call(name, *args):
+    log.append(name)
+    return real_call(name, *args)
+
+  _lib.call = logging_call
+  try:
+    distributed.init_native_comm()
+    outcome = "native"
+  except _lib.NativeError as error:
+    outcome = "fallback: " + str(error)
+  finally:
+    _lib.call = real_call
+  assert outcome.startswith("fallback") and not distributed.native_comm(), (rank, outcome)
+  assert log == ["dx_comm_available"], (rank, log)
+  if rank == 1:
+    assert "DERL_AMD_RCCL_LIBRARY" in outcome, outcome
+    try:
+      real_call("dx_comm_available")
+      raise AssertionError("rank 1 loaded an RCCL that does not exist")
+    except _lib.NativeError as error:
+      assert error.status == _lib.DX_ENOSUP, error.status
+  ones = torch.ones(3)
+  torch.distributed.all_reduce(ones)
+  assert ones.tolist() == [2.0, 2.0, 2.0]
+  print(f"rank {rank}: bootstrap_real_failure OK", flush=True)
 
 
 def gpu_step():
@@ -411,7 +463,7 @@ def rccl_ordering():
 if __name__ == "__main__":
   mode = sys.argv[1]
   distributed.init_from_env(backend="nccl" if mode.startswith("rccl") else "gloo")
-  {"cpu_math": cpu_math, "bootstrap_agreement": bootstrap_agreement, "gpu_step": gpu_step, "gpu_minibatch_stats": gpu_minibatch_stats,
+  {"cpu_math": cpu_math, "bootstrap_agreement": bootstrap_agreement, "bootstrap_real_failure": bootstrap_real_failure, "gpu_step": gpu_step, "gpu_minibatch_stats": gpu_minibatch_stats,
    "gpu_learns": gpu_learns, "rccl_one_rank": rccl_one_rank,
    "rccl_ordering": rccl_ordering}[mode]()
   distributed.destroy()

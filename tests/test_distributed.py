@@ -31,6 +31,13 @@ def test_native_comm_bootstrap_ranks_agree_on_failure_world_size_2_gloo_cpu():
   launch("bootstrap_agreement", 29518)
 
 
+def test_native_comm_bootstrap_with_one_rank_really_unable_to_load_rccl_world_size_2_gloo_cpu():
+  """No scripted stubs: rank 1's library is pointed at an RCCL that does not exist, so its readiness check
+  (dx_comm_available) really fails in dlopen; neither rank may enter ncclCommInitRank
+  (dist_worker.bootstrap_real_failure)."""
+  launch("bootstrap_real_failure", 29520)
+
+
 @pytest.mark.gpu
 def test_two_ranks_one_gpu_step_matches_single_process():
   launch("gpu_step", 29512)
