@@ -1,0 +1,536 @@
+// The forward of a TRAINING minibatch through the conv stack of derl/models.py:104-111 as one launch, one workgroup
+// per CU walking its share of the images -- the image-resident kernel of convstack.hip with its eight waves
+// SPECIALISED and two images in flight:
+//
+//   waves 0-3 ("B": one per SIMD, the older wave of each SIMD pair): conv1 and conv2 of image i.  Wave b owns output
+//     channels 16 b .. 16 b + 15 of both layers over the WHOLE contraction (16 taps / 18 steps), so nothing is
+//     exchanged between waves: one accumulator per tile from the first tap to the bias.  Its weight fragments live in
+//     ONE buffer of 9 x 3 fragments (108 registers) that cycles through conv1 taps 0-7 -> conv1 taps 8-15 -> conv2
+//     steps 0-8 -> conv2 steps 9-17 -> the next image's conv1 taps 0-7: K step s of a half is overwritten by step s of the
+//     next half right after its last MFMA has issued (three 1-KB loads from the fragment-ordered copies in L2 under the
+//     MFMAs of step s + 1; no load bursts between the layers).
+//   waves 4-7 ("A"): conv0 of image i + 1.  Its frame arrives by LDS-DMA while B finishes conv1 of image i, its 13 pixel
+//     tiles (4 + 3 + 3 + 3) multiply UNDER B's conv2 loop on the same matrix pipes, and its epilogue (1 / 255, bias,
+//     ReLU, the exact three-way split into the y0 planes: the most vector-ALU work of the whole stack) runs beside B's
+//     conv2 epilogue.
+//
+// Why: in the one-role-for-all kernel every phase was serial -- conv0 MFMA | conv0 epilogue | conv1 | K-half exchange +
+// epilogue | conv2 | exchange + epilogue -- 42,400 cycles per image of which 22,200 are matrix time (stamps):
+// the matrix pipes idle through every epilogue and exchange, and the halves of a SIMD pair finish their loops 3,700
+// cycles apart (the older wave wins the arbitration).  Here a SIMD's pipe is fed by B's stream alone during conv1, by
+// B's and A's together during conv2, and the two epilogues overlap.
+//
+// LDS map = convstack.hip's (148 KB): conv0's weight planes resident; region B holds y0 (image i) -> y1 (image i, at its
+// start) + the frame of image i + 1 (at its end) -> y0 (image i + 1).  Four workgroup barriers per image:
+//   alpha  y0(i) complete                 B: conv1 reads y0(i)                    A: -
+//   beta   every B wave has read y0(i)    B: bias / ReLU / split -> y1(i)         A: frame(i + 1) by LDS-DMA
+//   gamma  y1(i) complete, frame landed   B: conv2 reads y1(i)                    A: conv0 MFMAs of image i + 1
+//   delta  y1(i) and the frame are dead   B: bias / ReLU -> y2(i) (global)        A: epilogue -> y0(i + 1)
+// Arithmetic: the same exact splits and the same six products per fp32 product as convstack.hip (kTerms); a tile's sum
+// runs over all taps in one accumulator instead of two K halves added at the end, so results differ from the rollout
+// flavour's in the last bits (summation order), like every other route.
+#include "convstack_dev.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace dx {
+namespace {
+
+// A whole layer's contraction for this wave's 16 channels: 2 NS K steps (two halves of NS: the fragment buffer R holds
+// one half) over NT pixel tiles, two tiles at a time; weight fragments R[step % NS].  A wave is ALONE on its SIMD's
+// matrix pipe for most of this, so nothing but its own instruction stream hides its LDS latency: the activation
+// fragments (three planes per tile, convstack_dev.hpp: load_pair) are read TWO tile pairs ahead of the MFMAs that use
+// them (one pair ahead left 24 reads of the four B waves -- in lockstep behind the barrier -- landing together under
+// eleven MFMAs: 13,100 cycles for 9,200 of matrix time).  The NEXT weights ride along: once global step G - 1 has issued
+// its last MFMA (at the first tile pair of step G) its three registers are reloaded -- half 0's step with half 1's
+// (`nexta`), half 1's with the next layer's first half (`nextb`, NNEXT steps).
+// (V: timing variants of the diag flavour, WRONG results -- 1: no weight reloads in the loops, 2: no LDS re-reads of the
+// activation fragments, 4: A multiplies nothing)
+template <int V, int LAYER, int NT, int NS, int NNEXT, int DIST, int G, int PR>
+__device__ __forceinline__ void conv_run_from(const uint8_t *smem, const int (&pb)[NT], u32x4 (&R)[9][3], f32x4 (&acc)[NT],
+                                              u32x4 (&x0)[2][3], u32x4 (&x1)[2][3], const uint16_t *nexta, const uint16_t *nextb,
+                                              unsigned lane_bytes) {
+  constexpr int kPairs = NT / 2, kAll = 2 * NS * kPairs, kThis = G * kPairs + PR;  // position in the (step, pair) sequence
+  constexpr int S = G % NS;
+  constexpr bool last = kThis == kAll - 1;
+  constexpr int kAhead = kThis + DIST, GA = kAhead / kPairs, PA = kAhead % kPairs;  // the pair read now (DIST = 2, or 1 where registers are short)
+  u32x4 x2[2][3];
+  constexpr bool reads = kAhead < kAll && !(V & 2);
+  constexpr bool weights = PR == 0 && G >= 1 && !(V & 1) && (G - 1 < NS || (G - 1) % NS < NNEXT);
+  // One scheduling region per tile pair: its twelve MFMAs, the six fragment reads of the pair DIST ahead and (first pair
+  // of a step) the three weight loads of the step that has just retired -- INTERLEAVED, one memory instruction behind each
+  // of the first MFMAs.  Issued as a burst (mac_first | reads | the other eleven MFMAs: convstack.hip's form, fine with
+  // two such waves per SIMD) every read and load holds this wave's in-order stream while the LDS / the texture path
+  // takes it -- 16 cycles for a 1-KB global load -- and no MFMA issues meanwhile.
+  if constexpr (reads) load_pair<LAYER, GA / NS, GA % NS, PA, NT>(smem, pb, x2);
+  if constexpr (weights) {
+    constexpr int SP = (G - 1) % NS;  // the step that has just retired
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) R[SP][pl] = load_piece(G - 1 < NS ? nexta : nextb, (SP * 3 + pl) * 512, lane_bytes);
+  }
+  acc[2 * PR] = mac_first(acc[2 * PR], R[S], x0[0]);
+  acc[2 * PR] = mac_rest(acc[2 * PR], R[S], x0[0]);
+  acc[2 * PR + 1] = mac_rest(mac_first(acc[2 * PR + 1], R[S], x0[1]), R[S], x0[1]);
+  if constexpr (reads) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA,
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+    }
+  }
+  if constexpr (weights) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one global load
+    }
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, 2 * kTerms - (reads ? 6 : 0) - (weights ? 3 : 0), 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!last) {
+    constexpr int GN = PR + 1 < kPairs ? G : G + 1, PN = PR + 1 < kPairs ? PR + 1 : 0;
+    if constexpr (V & 2) conv_run_from<V, LAYER, NT, NS, NNEXT, DIST, GN, PN>(smem, pb, R, acc, x1, x0, nexta, nextb, lane_bytes);
+    else if constexpr (DIST == 1) conv_run_from<V, LAYER, NT, NS, NNEXT, DIST, GN, PN>(smem, pb, R, acc, x2, x2, nexta, nextb, lane_bytes);
+    else conv_run_from<V, LAYER, NT, NS, NNEXT, DIST, GN, PN>(smem, pb, R, acc, x1, x2, nexta, nextb, lane_bytes);
+  }
+}
+
+template <int V, int LAYER, int NT, int NS, int NNEXT, int DIST = 2>
+__device__ __forceinline__ void conv_run(const uint8_t *smem, const int (&pb)[NT], u32x4 (&R)[9][3], f32x4 (&acc)[NT],
+                                         const uint16_t *nexta, const uint16_t *nextb, unsigned lane_bytes) {
+  static_assert(NT % 2 == 0 && NS <= 9 && NNEXT <= 9, "tiles go in pairs; the fragment buffer holds nine steps");
+  constexpr int kPairs = NT / 2;
+  u32x4 x0[2][3], x1[2][3];
+  load_pair<LAYER, 0, 0, 0, NT>(smem, pb, x0);
+  if constexpr (DIST == 2) load_pair<LAYER, 0, 1 / kPairs, 1 % kPairs, NT>(smem, pb, x1);  // position 1 of the (step, pair) sequence
+  conv_run_from<V, LAYER, NT, NS, NNEXT, DIST, 0, 0>(smem, pb, R, acc, x0, x1, nexta, nextb, lane_bytes);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = NS - 1; s < NNEXT; ++s)  // the last step's registers (and conv2's ninth step behind conv1's eight)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      if constexpr (!(V & 1)) R[s][pl] = load_piece(nextb, (s * 3 + pl) * 512, lane_bytes);
+}
+
+// conv0 for NT_ 32-pixel tiles (tile0, tile0 + 4, ...) of an A wave, as convstack_dev.hpp's conv0_mfma but software-
+// pipelined one level deeper: while chunk c's MFMAs issue, the pixels of chunk c + 1 (read from LDS a chunk earlier) are
+// converted byte -> bf16 (12 vector-ALU instructions per tile: the bulk of this loop's instructions) and chunk c + 2's
+// pixels / chunk c + 1's weight fragments are read -- four conversions and at most one read behind every MFMA.  An A
+// wave runs four tiles in ONE in-order stream beside B's conv2 stream; with convert-then-multiply per chunk it took
+// 16,300 cycles for 4,600 of matrix time and B waited 5,800 of them.
+template <int NT_, int NA>
+__device__ __forceinline__ void conv0_mfma_pipelined(const uint8_t *smem, int tile0, int lane, f32x16 (&acc)[NA]) {
+  static_assert(NT_ <= NA, "accumulator tiles");
+  const int r = lane & 31, kg = lane >> 5;
+  int pb[NT_];
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) {
+    const int p = min(32 * (tile0 + 4 * t) + r, kP0 - 1);  // columns past the image compute a copy that is not stored
+    const int oy = p / 20, ox = p - 20 * oy;
+    pb[t] = oFrame + (4 * oy * kIn + 4 * ox) * 4 + 8 * kg;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  }
+  const int wb = oW0 + r * kWRowB + 16 * kg;
+  uint2 px[NT_];      // raw pixels of the chunk after the one being multiplied
+  bf16x8 pf[NT_];     // converted pixels of the chunk being multiplied
+  u32x4 wf[3];
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) px[t] = *reinterpret_cast<const uint2 *>(smem + pb[t]);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB);
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) pf[t] = cs_expand8(px[t]);
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) px[t] = *reinterpret_cast<const uint2 *>(smem + pb[t] + 16);  // chunk 1
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {  // chunk c: kernel row c / 2, bytes 16 (c % 2) .. + 15 of its 32
+    bf16x8 pfn[NT_];
+    uint2 pxn[NT_];
+    u32x4 wfn[3];
+    if (c + 1 < 16) {
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) pfn[t] = cs_expand8(px[t]);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) wfn[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB + 32 * (c + 1));
+    }
+    if (c + 2 < 16) {
+      const int aoff = ((c + 2) >> 1) * kRowB + 16 * ((c + 2) & 1);
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) pxn[t] = *reinterpret_cast<const uint2 *>(smem + pb[t] + aoff);
+    }
+#pragma unroll
+    for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[pl]), pf[t], acc[t], 0, 0, 0);
+    if (c + 1 < 16) {
+      constexpr int kMfma = 3 * NT_, kReads = 3 + NT_;
+#pragma unroll
+      for (int i = 0; i < kMfma; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA,
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // four conversions of the next chunk,
+        if (i < kReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < 16) {
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) { pf[t] = pfn[t]; px[t] = pxn[t]; }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) wf[pl] = wfn[pl];
+    }
+  }
+}
+
+// bias + ReLU + exact three-way split of four channels (oc0 ..) of conv1's output pixel p: the y1 planes in LDS, and
+// the fp32 values kept for the backward
+__device__ __forceinline__ void finish_conv1(uint8_t *smem, f32x4 sum, f32x4 bias, int p, int oc0, float *gy1) {
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x = sum[j] + bias[j];
+    v[j] = x > 0.f ? x : 0.f;
+  }
+  if (p < kP1) {
+    store_planes4(smem, oY1 + (p / 9) * kY1R + (p % 9) * kY1P + oc0 * 2, kY1Plane, v);
+    *reinterpret_cast<f32x4 *>(gy1 + p * 64 + oc0) = v;
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool roleB = wave < 4;
+  const int grid = static_cast<int>(gridDim.x);
+  int e = blockIdx.x;  // the image: blockIdx + t grid
+  const int steps = (a.B - static_cast<int>(blockIdx.x) + grid - 1) / grid;
+  unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int stamp_wave = kDiag ? (a.env0 >> 24) & 7 : 0;
+  const int stamp_step = kDiag ? a.stamp_step : 0;
+  int t = 0;
+#define DX_CS_MARK(i) if (kDiag && a.stamps && t == stamp_step) tk[i] = __builtin_amdgcn_s_memtime();
+  if (kDiag && a.stamps) { tk[14] = __builtin_amdgcn_s_memrealtime(); tk[15] = __builtin_amdgcn_s_memtime(); }
+
+  // ---- image 0's frame and conv0's weight planes (resident for the whole launch): all eight waves ----
+  {
+    const uint8_t *src = a.obs + static_cast<long long>(a.sample_idx ? a.sample_idx[e] : e) * kFrameB;
+    u32x4 fr[4];  // the frame: 1,764 pieces of 16 bytes
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const u32x4 *>(src + 16 * min(tid + 512 * u, kFrameB / 16 - 1));
+    u32x4 wv[6];  // conv0's planes: 3 x 32 rows x 32 pieces
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = u * 512 + tid;
+      wv[u] = *reinterpret_cast<const u32x4 *>(a.Wb0 + (i >> 10) * 8192 + ((i >> 5) & 31) * 256 + (i & 31) * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (tid + 512 * u < kFrameB / 16) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * (tid + 512 * u)) = fr[u];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = u * 512 + tid;
+      *reinterpret_cast<u32x4 *>(smem + oW0 + (i >> 10) * kWPlaneB + ((i >> 5) & 31) * kWRowB + (i & 31) * 16) = wv[u];
+    }
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const unsigned lane16 = static_cast<unsigned>(lane * 16);
+
+  if (roleB) {
+    // =================================== B: conv1 + conv2 of image t ===================================
+    const int nt = wave;  // output channels 16 nt .. 16 nt + 15 of both layers
+    const int n16 = lane & 15, kq = lane >> 4, oc0 = 16 * nt + 4 * kq;
+    // fragment-ordered copies (launch_convstack_pack): piece (wave' = nt + 4 half, step, plane) is one KB
+    const uint16_t *w1h0 = a.Wf1 + nt * (8 * 3 * 512), *w1h1 = a.Wf1 + (nt + 4) * (8 * 3 * 512);
+    const uint16_t *w2h0 = a.Wf2 + nt * (9 * 3 * 512), *w2h1 = a.Wf2 + (nt + 4) * (9 * 3 * 512);
+    u32x4 R[9][3];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) R[s][pl] = load_piece(w1h0, (s * 3 + pl) * 512, lane16);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) R[8][pl] = R[7][pl];  // (defined; first written for real behind conv1's second half)
+    const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);
+    const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
+    // conv0's tile nt is this wave's too (the A waves take tiles 4 .. 12): multiplied behind its conv2 loop, where it
+    // otherwise waited 4,300 cycles for the A wave's four tiles, and finished beside its conv2 epilogue
+    auto load_bias0 = [&](f32x4 (&bias0)[4], int l) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (l >> 5));
+    };
+    lds_barrier();  // p1: frame 0 and conv0's planes are in LDS
+    {
+      f32x16 accb[1];
+      conv0_mfma<1, 4, 1>(smem, nt, lane, accb);
+      lds_barrier();  // p2: every wave has read the frame
+      f32x4 bias0[4];
+      load_bias0(bias0, lane);
+      conv0_store<1, 4, 1>(smem, nt, lane, accb, bias0, a.y0 + static_cast<long long>(e) * (kP0 * 32));
+    }
+    for (t = 0; t < steps; ++t, e += grid) {
+      DX_CS_MARK(7)
+      lds_barrier();  // alpha: y0 of this image is complete
+      DX_CS_MARK(0)
+      // (per-lane address tables are rebuilt per image behind an opaque copy of the lane index: hoisted out of the image
+      // loop, the tables and everything the compiler derives from them -- one register per plane and tap beyond the
+      // 64 KB immediate range -- do not fit beside the fragment buffer and spill)
+      int pb1[4];  // byte address of the lane's pixel (tile mt) and k group in plane 0 of y0
+      {
+        const int l1 = opaque(lane), m16 = l1 & 15, k4 = l1 >> 4;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {  // (conv1's tiles 4 and 5 are the A wave's of this SIMD)
+          const int p = min(16 * mt + m16, kP1 - 1), oy = p / 9, ox = p - 9 * oy;
+          pb1[mt] = oY0 + 2 * oy * kY0R + 2 * ox * kY0P + 16 * k4;
+        }
+      }
+      const bool more = t + 1 < steps;  // (uniform) an image follows
+      u32x4 fr[3];  // pieces 16 + nt + 4 u of the next image's frame (the A waves carry pieces 0 .. 15)
+      if (more) {
+        const int next = e + grid;
+        const uint8_t *src = a.obs + static_cast<long long>(a.sample_idx ? a.sample_idx[next] : next) * kFrameB;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) fr[u] = *reinterpret_cast<const u32x4 *>(src + 16 * min((16 + nt + 4 * u) * 64 + opaque(lane), kFrameB / 16 - 1));
+      }
+      f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+      conv_run<V, 1, 4, 8, 9>(smem, pb1, R, acc, w1h1, w2h0, lane16);
+      DX_CS_MARK(1)
+      lds_barrier();  // beta: every B wave has read y0 -- the y1 planes may overwrite its start
+      DX_CS_MARK(2)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)  // C/D layout: column (pixel) = lane & 15, rows (channels) 4 (lane >> 4) + j
+        finish_conv1(smem, acc[m], bias1, 16 * m + (opaque(lane) & 15), oc0, a.y1 + static_cast<long long>(e) * (kP1 * 64));
+      if (more) {  // (the end of region B: the y1 planes lie at its start)
+        const int lf = opaque(lane);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int unit = (16 + nt + 4 * u) * 64 + lf;
+          if (unit < kFrameB / 16) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * unit) = fr[u];
+        }
+      }
+      DX_CS_MARK(3)
+      lds_barrier();  // gamma: y1 and the next image's frame are complete
+      DX_CS_MARK(4)
+      int pb2[4];  // the same in y1
+      {
+        const int l2 = opaque(lane), m16 = l2 & 15, k4 = l2 >> 4;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int p = min(16 * mt + m16, kP2 - 1), oy = p / 7, ox = p - 7 * oy;
+          pb2[mt] = oY1 + oy * kY1R + ox * kY1P + 16 * k4;
+        }
+      }
+      f32x4 acc2[4] = {zero4, zero4, zero4, zero4};
+      conv_run<V, 2, 4, 9, 8>(smem, pb2, R, acc2, w2h1, w1h0, lane16);  // (then the next image's first taps; behind the last image nobody reads them)
+      f32x16 accb[1];
+      if (more && !(V & 4)) conv0_mfma_pipelined<1, 1>(smem, nt, opaque(lane), accb);
+      DX_CS_MARK(5)
+      lds_barrier();  // delta: every wave has read y1 and the frame -- the y0 planes may overwrite both
+      DX_CS_MARK(6)
+      if (more) {
+        const int l0 = opaque(lane);
+        f32x4 bias0[4];
+        load_bias0(bias0, l0);
+        conv0_store<1, 4, 1>(smem, nt, l0, accb, bias0, a.y0 + static_cast<long long>(e + grid) * (kP0 * 32));
+      }
+      float *out = a.y2 + static_cast<long long>(e) * (kP2 * 64);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int p = 16 * m + n16;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x = acc2[m][j] + bias2[j];
+          v[j] = x > 0.f ? x : 0.f;
+        }
+        if (p < kP2) *reinterpret_cast<f32x4 *>(out + p * 64 + oc0) = v;
+      }
+    }
+  } else {
+    // =================================== A: conv0 of image t + 1 ===================================
+    const int aw = wave - 4;  // tiles 4 + aw, 8 + aw (and 12 for aw = 0) of the 13 tiles of 32 pixels; tile b is B wave b's
+    // (the younger wave of a SIMD pair loses every arbitration at equal priority: with its two conv1 tiles it ended
+    // 1,300 cycles behind B's four)
+    __builtin_amdgcn_s_setprio(1);
+    // conv0's bias for this lane's 16 accumulator rows (channels 8 q + 4 (lane >> 5) + j): fetched per image (L2), not
+    // kept in 16 registers across the conv1 phase
+    auto load_bias0 = [&](f32x4 (&bias0)[4], int l) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (l >> 5));
+    };
+    // conv1's tiles 4 and 5 for the channels of this SIMD's B wave (nt = aw), over the whole contraction: its own
+    // fragment buffer cycles taps 0-7 -> taps 8-15 -> the next image's taps 0-7
+    const int n16 = lane & 15, kq = lane >> 4, oc0 = 16 * aw + 4 * kq;
+    const uint16_t *w1h0 = a.Wf1 + aw * (8 * 3 * 512), *w1h1 = a.Wf1 + (aw + 4) * (8 * 3 * 512);
+    u32x4 R[9][3];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) R[s][pl] = load_piece(w1h0, (s * 3 + pl) * 512, lane16);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) R[8][pl] = R[7][pl];  // (never used: conv1 has eight steps per half)
+    const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);
+    lds_barrier();  // p1: frame 0 and conv0's planes are in LDS
+    {
+      f32x16 acc0[3];
+      if (aw == 0) conv0_mfma<3, 4, 3>(smem, 4 + aw, lane, acc0);
+      else conv0_mfma<2, 4, 3>(smem, 4 + aw, lane, acc0);
+      lds_barrier();  // p2: every A wave has read the frame
+      float *gy0 = a.y0 + static_cast<long long>(e) * (kP0 * 32);
+      f32x4 bias0[4];
+      load_bias0(bias0, lane);
+      if (aw == 0) conv0_store<3, 4, 3>(smem, 4 + aw, lane, acc0, bias0, gy0);
+      else conv0_store<2, 4, 3>(smem, 4 + aw, lane, acc0, bias0, gy0);
+    }
+    for (t = 0; t < steps; ++t, e += grid) {
+      const bool more = t + 1 < steps;  // (uniform) an image follows
+      f32x16 acc0[3];  // (per image: nothing of it lives across the loop's back edge)
+      DX_CS_MARK(7)
+      lds_barrier();  // alpha: y0 of image t is complete
+      DX_CS_MARK(0)
+      u32x4 fr[4];  // the next image's frame: this wave's 4 KB of it -- pieces aw + 4 u; the B waves carry pieces 16 .. 27 (a gather
+                    // from HBM: 4,700 cycles when fetched by LDS-DMA behind beta, where B then waited for it; here it
+                    // travels under the conv1 loops)
+      if (more) {
+        const int next = e + grid;
+        const uint8_t *src = a.obs + static_cast<long long>(a.sample_idx ? a.sample_idx[next] : next) * kFrameB;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const u32x4 *>(src + 16 * ((aw + 4 * u) * 64 + opaque(lane)));
+      }
+      int pb1[2];
+      {
+        const int l1 = opaque(lane), m16 = l1 & 15, k4 = l1 >> 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int p = min(16 * (4 + mt) + m16, kP1 - 1), oy = p / 9, ox = p - 9 * oy;
+          pb1[mt] = oY0 + 2 * oy * kY0R + 2 * ox * kY0P + 16 * k4;
+        }
+      }
+      f32x4 acc[2] = {zero4, zero4};
+      conv_run<V, 1, 2, 8, 0, 1>(smem, pb1, R, acc, w1h1, w1h0, lane16);  // (one pair ahead: the frame's registers are live)
+      DX_CS_MARK(1)
+      lds_barrier();  // beta: y0 of image t is dead
+      DX_CS_MARK(2)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        finish_conv1(smem, acc[m], bias1, 16 * (4 + m) + (opaque(lane) & 15), oc0, a.y1 + static_cast<long long>(e) * (kP1 * 64));
+      if (more) {
+        // the next image's frame (fetched into registers during B's conv1: see below) goes into the LDS slot conv0 reads
+        // -- the end of region B; the y1 planes B writes meanwhile lie at its start
+        const int lf = opaque(lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * ((aw + 4 * u) * 64 + lf)) = fr[u];
+      }
+      DX_CS_MARK(3)
+      lds_barrier();  // gamma: the frame is complete
+      DX_CS_MARK(4)
+      if (more && !(V & 4)) {
+        const int l0 = opaque(lane);
+        if (aw == 0) conv0_mfma_pipelined<3, 3>(smem, 4 + aw, l0, acc0);
+        else conv0_mfma_pipelined<2, 3>(smem, 4 + aw, l0, acc0);
+      }
+      if (more) {  // the next image's conv1 taps 0-7: under the epilogue (not carried through the conv0 loop: 96 registers)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) R[s][pl] = load_piece(w1h0, (s * 3 + pl) * 512, lane16);
+      }
+      DX_CS_MARK(5)
+      lds_barrier();  // delta: the frame and y1 of image t are dead
+      DX_CS_MARK(6)
+      if (more) {
+        float *gy0 = a.y0 + static_cast<long long>(e + grid) * (kP0 * 32);
+        const int l0 = opaque(lane);
+        f32x4 bias0[4];
+        load_bias0(bias0, l0);
+        if (aw == 0) conv0_store<3, 4, 3>(smem, 4 + aw, l0, acc0, bias0, gy0);
+        else conv0_store<2, 4, 3>(smem, 4 + aw, l0, acc0, bias0, gy0);
+      }
+    }
+  }
+#undef DX_CS_MARK
+  if (kDiag && a.stamps && tid == 64 * stamp_wave) {
+    tk[8] = __builtin_amdgcn_s_memtime();
+    tk[13] = __builtin_amdgcn_s_memrealtime();
+    tk[15] = tk[8] - tk[15];   // the whole launch in shader cycles,
+    tk[14] = tk[13] - tk[14];  // and in ticks of the constant 100 MHz clock
+    for (int i = 0; i < 16; ++i) a.stamps[blockIdx.x * 16 + i] = tk[i];
+  }
+}
+
+}  // namespace
+
+// the forward of a training minibatch (ConvStackArgs::train): a.B images over `blocks` workgroups (one per CU)
+int launch_convstack_train(const ConvStackArgs &args, int blocks, hipStream_t stream) {
+  ConvStackArgs a = args;
+  static bool configured[64] = {};
+  int dev = 0;
+  DX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !configured[dev]) {
+    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(convstack_train_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kLdsBytes));
+#if DX_DIAG
+    for (const void *f : {reinterpret_cast<const void *>(convstack_train_kernel<1>), reinterpret_cast<const void *>(convstack_train_kernel<2>),
+                          reinterpret_cast<const void *>(convstack_train_kernel<3>), reinterpret_cast<const void *>(convstack_train_kernel<4>),
+                          reinterpret_cast<const void *>(convstack_train_kernel<7>)})
+      DX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+#endif
+    if (dev >= 0 && dev < 64) configured[dev] = true;
+  }
+#if DX_DIAG
+  if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one image (DX_CS_STEP) as seen by wave DX_CS_DIAG, on stderr (synchronous)
+    unsigned long long *dev_stamps = nullptr;
+    DX_HIP(hipMalloc(&dev_stamps, static_cast<size_t>(blocks) * 128));
+    a.stamps = dev_stamps;
+    const int stamp_wave = atoi(getenv("DX_CS_DIAG")) & 7;
+    a.env0 |= stamp_wave << 24;
+    a.stamp_step = getenv("DX_CS_STEP") ? atoi(getenv("DX_CS_STEP")) : 0;
+    const int steps = a.B / blocks;
+    if (a.stamp_step >= steps) a.stamp_step = steps - 1;
+    const int variant = getenv("DX_CS_VARIANT") ? atoi(getenv("DX_CS_VARIANT")) : 0;  // (timing variants: WRONG results)
+    switch (variant) {
+      case 1: hipLaunchKernelGGL(convstack_train_kernel<1>, dim3(blocks), dim3(512), kLdsBytes, stream, a); break;
+      case 2: hipLaunchKernelGGL(convstack_train_kernel<2>, dim3(blocks), dim3(512), kLdsBytes, stream, a); break;
+      case 3: hipLaunchKernelGGL(convstack_train_kernel<3>, dim3(blocks), dim3(512), kLdsBytes, stream, a); break;
+      case 4: hipLaunchKernelGGL(convstack_train_kernel<4>, dim3(blocks), dim3(512), kLdsBytes, stream, a); break;
+      case 7: hipLaunchKernelGGL(convstack_train_kernel<7>, dim3(blocks), dim3(512), kLdsBytes, stream, a); break;
+      default: hipLaunchKernelGGL(convstack_train_kernel<0>, dim3(blocks), dim3(512), kLdsBytes, stream, a);
+    }
+    DX_LAUNCH_CHECK();
+    DX_HIP(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> h(static_cast<size_t>(blocks) * 16);
+    DX_HIP(hipMemcpy(h.data(), dev_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    DX_HIP(hipFree(dev_stamps));
+    static const int order[9] = {7, 0, 1, 2, 3, 4, 5, 6, 8};
+    const bool b = stamp_wave < 4;
+    const char *what[8] = {"wait at alpha (y0 complete)", b ? "conv1 loop (16 taps)" : "-", "wait at beta (y0 read by all)",
+                           b ? "bias / ReLU / split -> y1" : "next frame by LDS-DMA", "wait at gamma (y1 complete, frame landed)",
+                           b ? "conv2 loop (18 steps)" : "conv0 MFMAs of the next image", "wait at delta (y1 and frame dead)",
+                           b ? "bias / ReLU -> y2 (one image only: to the launch's end)" : "conv0 epilogue -> y0 planes (to the launch's end)"};
+    double total = 0;
+    fprintf(stderr, "[convstack_train B=%d image %d wave %d] cycles per workgroup (mean):\n", a.B, a.stamp_step, stamp_wave);
+    for (int i = 0; i < 7; ++i) {
+      double d = 0;
+      for (int k = 0; k < blocks; ++k) d += static_cast<double>(h[k * 16 + order[i + 1]] - h[k * 16 + order[i]]) / blocks;
+      total += d;
+      fprintf(stderr, "  %-58s %8.0f\n", what[i], d);
+    }
+    fprintf(stderr, "  %-58s %8.0f\n", "total (alpha wait .. delta passed)", total);
+    double cyc = 0, ticks = 0;
+    for (int k = 0; k < blocks; ++k) { cyc += static_cast<double>(h[k * 16 + 15]); ticks += static_cast<double>(h[k * 16 + 14]); }
+    fprintf(stderr, "  whole launch: %.0f cycles per workgroup (%.0f per image) in %.2f us: shader clock %.0f MHz\n", cyc / blocks,
+            cyc / blocks / steps, ticks / blocks / 100.0, cyc / ticks * 100.0);
+    return DX_OK;
+  }
+#endif
+  a.stamps = nullptr;
+  a.stamp_step = 0;
+  hipLaunchKernelGGL(convstack_train_kernel<0>, dim3(blocks), dim3(512), kLdsBytes, stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+}  // namespace dx

@@ -253,6 +253,8 @@ struct ConvStackArgs {
 };
 bool convstack_supported(int in_h, int in_w, int in_c);
 int launch_convstack(const ConvStackArgs &args, hipStream_t stream);
+// the training forward (args.train) on `blocks` workgroups, waves specialised by layer, two images in flight (convstack_train.hip)
+int launch_convstack_train(const ConvStackArgs &args, int blocks, hipStream_t stream);
 // The conv-stack kernel's copies of conv1 / conv2's bf16 planes ([3][64][512], [3][64][576]) and of the
 // factored tail's Wc ([8][3136], may be NULL) in the order its waves read them: every fragment load of the
 // kernel is then ONE contiguous KB per wave (the planes' own layout made each a gather of 16 x 64 bytes).
