@@ -60,7 +60,30 @@ def executed_flops(name, route, batch, num_actions):
   return fl, PEAK_F32_MFMA_TFLOPS, "fp32 MFMA" if fl else ""
 
 
-PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+POWER_FILE = os.path.join("profiles", "r05_power.json")        # tools/power_probe.py over every stage + the rollout launch
+MFMA_POWER_FILE = os.path.join("profiles", "r05_mfma_power.txt")  # tools/ubench/mfma_power: bare matrix-instruction loops
+
+
+def power_evidence(stage):
+  """What the committed power probe says about `stage` (never a literal): the row of tools/power_probe.py's JSON for
+  it, the idle row, the highest stage power of the document and where the bare-loop energies are kept."""
+  path = os.path.join(ROOT, POWER_FILE)
+  if not os.path.exists(path):
+    return {"file": None, "note": "no committed power probe for this round (tools/power_probe.py -> " + POWER_FILE + ")"}
+  with open(path) as f:
+    doc = json.load(f)
+  rows = doc.get("rows", [])
+  row = next((r for r in rows if r.get("stage") == stage), None)
+  idle = next((r for r in rows if str(r.get("stage", "")).startswith("idle")), None)
+  powers = [r["power_w"] for r in rows if isinstance(r.get("power_w"), (int, float)) and r is not idle]
+  return {"file": POWER_FILE, "commit": doc.get("commit"), "device": doc.get("device"),
+          "stage": {k: row.get(k) for k in ("stage", "us", "power_w", "power_w_max", "sclk_mhz", "temp_c")} if row else None,
+          "idle_power_w": idle.get("power_w") if idle else None,
+          "stage_power_w_range": [min(powers), max(powers)] if powers else None,
+          "in_kernel_clock": doc.get("in_kernel_clock"),
+          "bare_mfma_loops": MFMA_POWER_FILE if os.path.exists(os.path.join(ROOT, MFMA_POWER_FILE)) else None}
+
 
 
 def pmc_traffic(stage, minibatch):
@@ -89,11 +112,10 @@ def stage_flops(name, batch, num_actions):
   return 0.0
 
 
-def time_stages(model, obs, idx, batch, iters=10):
-  """Average duration (us) of every stage of an update at `batch`, with HIP events on the stream
-  the kernels are launched on (torch's current stream).  Sets ``time_stages.names`` (the stages the
-  training loop really runs: FACTORED_STAGES when the linear layer + heads run as one affine map)
-  and ``time_stages.routes``."""
+def stage_launcher(model, obs, idx, batch):
+  """(names, routes-getter, launch(name)) for the stages an update at `batch` really runs, in pipeline order
+  (FACTORED_STAGES when the linear layer + heads run as one affine map; the three conv forwards as ONE
+  launch when the image-resident kernel takes them).  Shared by time_stages and tools/power_probe.py."""
   import ctypes
   from derl_amd import _lib
   eng = model.engine
@@ -126,16 +148,30 @@ def time_stages(model, obs, idx, batch, iters=10):
       _lib.call("dx_cnn_stage", ctypes.byref(eng.ctx), STAGE_IDS.index(name), _lib.ptr(obs), is_u8, _lib.ptr(idx),
                 batch, stream)
 
+  if not factored:
+    for name in names:  # defines every buffer
+      launch(name)
+    eng.dhead[:batch * 32].normal_()
+
+  def routes():
+    return {name: lib.dx_cnn_last_route(STAGE_IDS.index(name)).decode() if name in STAGE_IDS
+            else "convstack_train" if name == CONV_STACK_FWD else "tail_factored" for name in names}
+
+  return names, routes, launch
+
+
+def time_stages(model, obs, idx, batch, iters=10):
+  """Average duration (us) of every stage of an update at `batch`, with HIP events on the stream
+  the kernels are launched on (torch's current stream).  Sets ``time_stages.names`` (the stages the
+  training loop really runs: FACTORED_STAGES when the linear layer + heads run as one affine map)
+  and ``time_stages.routes``."""
+  names, routes, launch = stage_launcher(model, obs, idx, batch)
   # In situ: every pass runs the stages in pipeline order (a stage then finds its input where the
   # training loop leaves it -- partly in the last-level cache -- and the clocks are where a busy
   # GPU keeps them), one event pair per stage.  Timing one stage back to back right after an idle
   # gap measured the clock ramp instead: 477 us against the 405-415 us the same kernel takes in the
   # rocprofv3 trace of the training loop.
   n = len(names)
-  if not factored:
-    for name in names:  # defines every buffer
-      launch(name)
-    eng.dhead[:batch * 32].normal_()
   for _ in range(3):  # warm-up passes
     for name in names:
       launch(name)
@@ -166,8 +202,7 @@ def time_stages(model, obs, idx, batch, iters=10):
   time_stages.pass_us = pass_us
   time_stages.bracketed_us = bracketed
   time_stages.names = names
-  time_stages.routes = {name: lib.dx_cnn_last_route(STAGE_IDS.index(name)).decode() if name in STAGE_IDS
-                        else "convstack_train" if name == CONV_STACK_FWD else "tail_factored" for name in names}
+  time_stages.routes = routes()
   return {name: us * scale for name, us in bracketed.items()}
 
 
@@ -364,7 +399,7 @@ def main():
   composite = 1.0 / floor_s * world
   result["iteration_roofline"] = {
       "bound": "mfma", "algorithmic_mflop_per_env_step": round(per_step_mflop, 1),
-      "bound_env_steps_per_s": round(bound, 1), "frac": round(value / bound, 4),
+      "bound_env_steps_per_s": round(bound, 1), "vs_fp32_reference_line": round(value / bound, 4),
       "note": "fp32-MFMA peak x n_gpus / the flops per env step of the reference's layer-by-layer association "
               "(SURVEY.md 8d); a reference line, NOT a ceiling: the conv layers run on bf16 MFMA (3 resp. 6 exact "
               "bf16 products per fp32 product) and, when `linear_layer_and_heads` says factored, the linear layer + "
@@ -423,9 +458,14 @@ def main():
         rollout_row = {"envs": nenvs, "steps": args.nsteps, "us": round(roll_us, 1),
                        "us_per_step": round(roll_us / args.nsteps, 2),
                        "conv_TFLOPs_algorithmic": round(conv_flops / (roll_us * 1e-6) / 1e12, 1),
-                       "frac_of_fp32_mfma_peak": round(conv_flops / (roll_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
+                       "vs_fp32_reference_line": round(conv_flops / (roll_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
+                       "executed_frac_of_bf16_peak": round((2.0 * nenvs * args.nsteps * (3.0 * MACS["conv0"] + 6.0 * (MACS["conv1"] + MACS["conv2"]))) / (roll_us * 1e-6) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                        "note": "conv0 + conv1 + conv2 algorithmic flops of nenvs x nsteps frames / the launch's time; "
-                               "the layers execute on bf16 MFMA (3 and 6 bf16 products per fp32 product)"}
+                               "the layers execute on bf16 MFMA (3 and 6 bf16 products per fp32 product).  CAVEAT: the "
+                               "one-launch horizon leans on the synthetic env ignoring the action (SURVEY 8d defines it so, "
+                               "and the CPU baseline steps the same env): step t + 1's frame is generated BEFORE step t's "
+                               "action is sampled (the sample runs under the next step's conv0).  With an action-dependent "
+                               "device env the step serialises sample -> frame"}
       except Exception as error:  # a runner / env without the native rollout
         rollout_row = {"error": str(error)}
     names = time_stages.names
@@ -464,10 +504,7 @@ def main():
         "frac": round(tf / peak, 4), "traffic": pmc_traffic(dominant, mb)[0],
         "traffic_source": f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes) taken at "
                           f"commit {pmc_traffic(dominant, mb)[1]}",
-        "power": "every bf16 stage of the update runs AT the 1.4 kW package limit (tools/power_probe.py): bare "
-                 "v_mfma_f32_16x16x32_bf16 loops with operands in registers sustain 2.15 PFLOP/s at 1.3 kW and 2.05 GHz "
-                 "on this part (tools/ubench/mfma_power.hip: 1.22 pJ per bf16 multiply-add against 14.7 pJ for "
-                 "v_mfma_f32_32x32x2_f32), so `frac` of the 2.5 PFLOP/s nameplate cannot exceed ~0.88",
+        "power": power_evidence(dominant),
         "stage_pass_us": round(getattr(time_stages, "pass_us", 0.0), 1),
         "stage_bracket_scale": round(getattr(time_stages, "bracket_scale", 1.0), 4),
         "timing": "HIP events around each stage launched in pipeline order, scaled by `stage_bracket_scale` = one "
@@ -478,10 +515,11 @@ def main():
                   "default command are stand-alone averages (profiles/r04_*_bench_kernel_stats.csv)",
         "network_fwd_bwd": {"us": round(total_us, 1),
                             "achieved": round(total_flops / (total_us * 1e-6) / 1e12, 2),
-                            "frac": round(total_flops / (total_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                            "vs_fp32_reference_line": round(total_flops / (total_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                             "note": "flops of the reference's layer-by-layer association / measured time of one "
-                                    "update's stages: with the factored tail this 'fraction' can exceed what the "
-                                    "fp32 pipes could do -- see iteration_roofline.composite for the honest ceiling"},
+                                    "update's stages, against the fp32-MFMA peak: a reference line, not a roofline fraction "
+                                    "(nothing runs on fp32 MFMA; the factored tail executes fewer flops) -- "
+                                    "iteration_roofline.composite is the ceiling"},
         "rollout_act": {"batch": nenvs, "us": round(act_us, 1),
                         "achieved": round(fwd_flops / (act_us * 1e-6) / 1e12, 2),
                         "note": "one dx_cnn_act launch (conv stack + policy tail + sampling, one workgroup per image); "

@@ -26,6 +26,7 @@ P = c_void_p
 SIGNATURES = {
     "dx_abi_version": [],
     "dx_last_error": [],
+    "dx_reload_env": [],
     "dx_launch_count": [],
     "dx_device_info": [c_int, c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "dx_gae_f32": [P, P, P, P, c_int, c_int, c_float, c_float, P, P, P],
@@ -73,6 +74,7 @@ SIGNATURES = {
     "dx_cnn_stage": [P, c_int, P, c_int, P, c_int, P],
     "dx_cnn_last_route": [c_int],
     "dx_cnn_tail_factored": [P],
+    "dx_cnn_fused_heads": [P],
     "dx_cnn_act": [P, P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
     "dx_cnn_rollout_synth": [P, P, c_int, c_int, P, P, P, P, P, c_uint64, c_uint64, c_uint64,
                              c_uint64, c_float, c_float, P],

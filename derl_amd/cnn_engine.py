@@ -170,10 +170,10 @@ class CnnEngine:
               int(policy_seed), int(policy_counter), int(env_seed), int(env_counter),
               float(p_reward), float(p_reset), _lib.stream_ptr(self.device))
 
-  FUSED_HEADS_MAX_ACTIONS = 7  # dx_cnn_heads_loss_f32 keeps the A + 1 head rows in registers
-
   def fused_heads(self):
-    return self.num_actions <= self.FUSED_HEADS_MAX_ACTIONS
+    """Whether heads + loss + the heads' backward run as ONE launch (dx_cnn_heads_loss_f32): up to 18 actions where the
+    linear layer + heads are one affine map of y2 (84 x 84 frames), up to 7 on the layer-by-layer route."""
+    return bool(_lib.load().dx_cnn_fused_heads(ctypes.byref(self.ctx)))
 
   def _loss_counter(self):
     if getattr(self, "_counter", None) is None:

@@ -25,8 +25,7 @@ int conv_out(int n, int k, int s) { return (n - k) / s + 1; }
 
 bool use_b3() {  // experiment build + DX_SPLIT_BF16=1: big NT stages on the bf16 matrix cores
 #ifdef DX_EXPERIMENT_B3
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_SPLIT_BF16"); v = e ? atoi(e) : 0; }
+  const int v = DX_ENV("DX_SPLIT_BF16", 0);
   return v != 0;
 #else
   return false;
@@ -38,14 +37,12 @@ bool use_b3() {  // experiment build + DX_SPLIT_BF16=1: big NT stages on the bf1
 // box: 32 envs 10.96 vs 11.03 ms, 64 envs 17.69 vs 17.32 ms -- the 32x32-tile kernel up to 500 tiles
 // (40 images).  (Round 2, four waves per tile: B=64 9.4 vs 11.1 us, B=128 14.7 vs 11.7 us.)
 int conv0_lat_max_tiles() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_C0LAT_MAX_TILES"); v = e ? atoi(e) : 500; }
+  const int v = DX_ENV("DX_C0LAT_MAX_TILES", 500);
   return v;
 }
 
 bool conv0_f32() {  // DX_CONV0_F32=1: first layer on the fp32 matrix instructions (conv0.hip)
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_CONV0_F32"); v = e ? atoi(e) : 0; }
+  const int v = DX_ENV("DX_CONV0_F32", 0);
   return v != 0;
 }
 
@@ -53,33 +50,29 @@ bool conv0_f32() {  // DX_CONV0_F32=1: first layer on the fp32 matrix instructio
 // instead of the dedicated ones (wgrad_direct.hip, wgrad_fc.hip); DX_WGRAD_DIRECT_MIN_B: smallest
 // batch routed to them
 bool wgrad_direct_on() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_WGRAD_DIRECT"); v = e ? atoi(e) : 1; }
+  const int v = DX_ENV("DX_WGRAD_DIRECT", 1);
   return v != 0;
 }
 // smallest batch that takes the image-resident weight-gradient kernels: the fp32 ones (wgrad_direct.hip, wgrad_fc.hip)
 // want enough images for their 256-512 persistent workgroups; the bf16 ones (wgrad_b6.hip) are one workgroup per
 // image below that and measured 2x the generic kernel at 128-384 images (10.7 / 12.2 us against 21.2 / 21.6 at 128)
 int wgrad_direct_min_batch() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_WGRAD_DIRECT_MIN_B"); v = e ? atoi(e) : 512; }
+  const int v = DX_ENV("DX_WGRAD_DIRECT_MIN_B", 512);
   return v;
 }
 static int conv_wgrad_min_batch() {
-  static const bool set = getenv("DX_WGRAD_DIRECT_MIN_B") != nullptr;
+  const bool set = DX_ENV_SET("DX_WGRAD_DIRECT_MIN_B");
   return set || !wgrad_b6_on() ? wgrad_direct_min_batch() : 16;
 }
 
 // DX_ROLLOUT_LANES=1: the native rollout on the caller's stream only (default 2: see
 // dx_cnn_rollout_synth); DX_ROLLOUT_LANE_MIN: fewest envs a lane may have (default 64)
 int rollout_lanes() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_ROLLOUT_LANES"); v = e ? atoi(e) : 2; }
+  const int v = DX_ENV("DX_ROLLOUT_LANES", 2);
   return v;
 }
 int rollout_lane_min() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_ROLLOUT_LANE_MIN"); v = e ? atoi(e) : 64; }
+  const int v = DX_ENV("DX_ROLLOUT_LANE_MIN", 64);
   return v < 1 ? 1 : v;
 }
 
@@ -110,25 +103,22 @@ SideStream *side_stream() {
 }
 
 bool ntp_fc_fwd() {  // DX_NTP_FC_FWD=0: the linear layer's forward on nt_dma.hip's 128x128 tiles
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NTP_FC_FWD"); v = e ? atoi(e) : 1; }
+  const int v = DX_ENV("DX_NTP_FC_FWD", 1);
   return v != 0;
 }
 
 // DX_NT_DMA=0: linear-layer forward / dgrad on the implicit-GEMM kernel instead of nt_dma.hip
 bool nt_dma_on() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NT_DMA"); v = e ? atoi(e) : 1; }
+  const int v = DX_ENV("DX_NT_DMA", 1);
   return v != 0;
 }
 
 const char *g_route[ST_COUNT] = {};  // kernel family of the last launch of every stage (run_stage)
 
 // DX_FC_FACTORED=0: the linear layer and the heads as separate GEMM stages (the layer-by-layer
-// association) also where the factored tail of tail.hip applies (84 x 84 frames, <= 7 actions)
+// association) also where the factored tail of tail.hip applies (84 x 84 frames, <= 18 actions)
 bool fc_factored_env() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_FC_FACTORED"); v = e ? atoi(e) : 1; }
+  const int v = DX_ENV("DX_FC_FACTORED", 1);
   return v != 0;
 }
 
@@ -220,7 +210,7 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
     p.s[l].bsplit = 0;  // 0 = msplit (set below)
     long long b_cap = 0;  // bias partials beyond the weight slabs' count
     if (l == L_FC && tail_supported(c->flat, c->num_actions)) {  // the factored tail's partial G slabs live here
-      const long long need = (tail_slab_floats(c->max_batch) + static_cast<long long>(N) * K - 1) / (static_cast<long long>(N) * K);
+      const long long need = (tail_slab_floats(c->max_batch, c->num_actions) + static_cast<long long>(N) * K - 1) / (static_cast<long long>(N) * K);
       if (ms_cap < need) ms_cap = need;
     }
     if (l == L_FC && wgrad_direct_on()) {  // capacity for the dedicated kernel's slices / bias chunks
@@ -297,8 +287,8 @@ int dx_cnn_init(dx_cnn_ctx *c) {
   c->pb_c1f = take_planes(wsz[1]); c->pb_c2f = take_planes(wsz[2]); c->pb_fcf = take_planes(wsz[3]);
   c->pb_c1d = take_planes(wsz[1]); c->pb_c2d = take_planes(wsz[2]); c->pb_fcd = take_planes(wsz[3]);
   c->pb_c0f = take_planes(wsz[0]);
-  c->pk_wc = take(8LL * d.flat); c->pk_beff = take(64);
-  c->pk_wcs = take(tail_supported(d.flat, A) ? tail_pack_scratch_floats() : 0);
+  c->pk_wc = take((tail_supported(d.flat, A) ? tail_rows(A) : 8LL) * d.flat); c->pk_beff = take(64);
+  c->pk_wcs = take(tail_supported(d.flat, A) ? tail_pack_scratch_floats(A) : 0);
   c->ps_c1f = take(convstack_pack_elems(0) / 2); c->ps_c2f = take(convstack_pack_elems(1) / 2);
   c->ps_wc = take(convstack_pack_elems(2));
   c->ps_c1d = take(dgrad_b6_pack_elems(1) / 2); c->ps_c2d = take(dgrad_b6_pack_elems(2) / 2);
@@ -342,12 +332,7 @@ static uint16_t *planes(const dx_cnn_ctx *c, long long off) {
 // forward mirror and the bf16 planes of it), part 2 = every other mirror, 3 = both.  The split lets
 // dx_cnn_ppo_epoch start the next minibatch's first layer while the rest is still being packed.
 static bool convstack_train_env() {
-  static int on = -1;
-  if (on < 0) {
-    const char *e = getenv("DX_CONVSTACK_TRAIN");
-    on = e ? atoi(e) : 1;
-  }
-  return on != 0;
+  return DX_ENV("DX_CONVSTACK_TRAIN", 1) != 0;
 }
 static bool dgrad_b6_usable(const dx_cnn_ctx *c) {  // (the kernels are built for the conv stack of an 84 x 84 observation)
   return dgrad_b6_on() && c->h0 == 20 && c->w0 == 20 && c->h1 == 9 && c->w1 == 9 && c->h2 == 7 && c->w2 == 7;
@@ -729,13 +714,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
 // (tests/test_cnn_gpu.py passes with the switch on).
 static int fc_ksplit(int B, int flat);
 static bool fwd_lanes(int B) {
-  static int mode = -2, limit = 0;
-  if (mode == -2) {
-    const char *e = getenv("DX_FWD_LANES");
-    const char *m = getenv("DX_FWD_LANE_MIN");
-    limit = m ? atoi(m) : 4096;
-    mode = e ? atoi(e) : 0;
-  }
+  const int mode = DX_ENV("DX_FWD_LANES", 0), limit = DX_ENV("DX_FWD_LANE_MIN", 4096);
   return B >= 2 && B % 2 == 0 && (mode == 1 || (mode == -1 && B >= limit));
 }
 
@@ -866,13 +845,7 @@ int dx_cnn_heads_loss_f32(const dx_cnn_ctx *c, const int64_t *actions, const flo
 // the side stream returned nothing (23.8 vs 23.6-23.8 ms per iteration, alternating): the default then is
 // the serial order.
 static bool bwd_overlap(int B) {
-  static int mode = -2, limit = 0;
-  if (mode == -2) {
-    const char *e = getenv("DX_BWD_OVERLAP");
-    const char *m = getenv("DX_BWD_OVERLAP_MIN");
-    limit = m ? atoi(m) : 2048;
-    mode = e ? atoi(e) : -1;
-  }
+  const int mode = DX_ENV("DX_BWD_OVERLAP", -1), limit = DX_ENV("DX_BWD_OVERLAP_MIN", 2048);
   return mode == 1 || (mode == -1 && B >= limit && !(wgrad_b6_on() && dgrad_b6_on()));
 }
 
@@ -910,7 +883,7 @@ static int backward_stages(const dx_cnn_ctx *c, int first, int last, const void 
       continue;
     }
     // DX_BWD_OVERLAP_MASK: which weight-gradient stages go aside (1 = linear layer, 2 = conv2, 4 = conv1)
-    static const int aside_mask = [] { const char *e = getenv("DX_BWD_OVERLAP_MASK"); return e ? atoi(e) : 7; }();
+    const int aside_mask = DX_ENV("DX_BWD_OVERLAP_MASK", 7);
     const bool aside = side != nullptr && ((st == ST_FC_WGRAD && (aside_mask & 1)) || (st == ST_CONV2_WGRAD && (aside_mask & 2)) ||
                                             (st == ST_CONV1_WGRAD && (aside_mask & 4)));
     if (aside) {  // everything enqueued on `s` so far (this layer's output gradient) comes first
@@ -923,7 +896,7 @@ static int backward_stages(const dx_cnn_ctx *c, int first, int last, const void 
     // the heads' slabs (heads stages or dx_cnn_heads_loss_f32, on `s`) are ordered before the side
     // stream's finalisation by the fork of the linear layer's weight gradient
     rc = run_stage(c, st, obs, obs_is_u8, sample_idx, B, plan, aside ? side->stream[0] : s);
-    static const bool side_finalize = [] { const char *e = getenv("DX_BWD_SIDE_FINALIZE"); return !(e && atoi(e) == 0); }();
+    const bool side_finalize = DX_ENV("DX_BWD_SIDE_FINALIZE", 1) != 0;
     if (rc == DX_OK && aside && side_finalize && st == ST_CONV1_WGRAD && which == 3 && last == ST_CONV0_WGRAD) {
       rc = finalize_any(c, plan, 2 | 8, B, factored, side->stream[0]);
       which = 4;
@@ -977,13 +950,7 @@ int dx_cnn_backward_part(const dx_cnn_ctx *c, const void *obs, int obs_is_u8, co
 // DX_FC_ROLLOUT=0: the rollout's linear layer on the 32x32-tile split-K latency kernel (igemm_lat.hip)
 // instead of the weight-stationary kernel of fc_rollout.hip; DX_FC_ROLLOUT_MAX_B: largest batch it takes
 static bool fc_rollout_on(int B, int flat) {
-  static int on = -1, max_b = 0;
-  if (on < 0) {
-    const char *e = getenv("DX_FC_ROLLOUT");
-    const char *m = getenv("DX_FC_ROLLOUT_MAX_B");
-    max_b = m ? atoi(m) : 1024;
-    on = e ? (atoi(e) != 0) : 1;
-  }
+  const int on = DX_ENV("DX_FC_ROLLOUT", 1), max_b = DX_ENV("DX_FC_ROLLOUT_MAX_B", 1024);
   return on != 0 && B <= max_b && fc_rollout_supported(B, kHid, flat);
 }
 
@@ -999,13 +966,7 @@ static int fc_ksplit(int B, int flat) {
 // DX_CONVSTACK=0: the rollout's conv layers as three launches (igemm_lat.hip / conv0_b16.hip) instead of
 // the one-workgroup-per-image launch of convstack.hip; DX_CONVSTACK_MAX_B: largest batch it takes
 static bool convstack_on(int B) {
-  static int on = -1, max_b = 0;
-  if (on < 0) {
-    const char *e = getenv("DX_CONVSTACK");
-    const char *m = getenv("DX_CONVSTACK_MAX_B");
-    max_b = m ? atoi(m) : 1024;
-    on = e ? (atoi(e) != 0) : 1;
-  }
+  const int on = DX_ENV("DX_CONVSTACK", 1), max_b = DX_ENV("DX_CONVSTACK_MAX_B", 1024);
   return on != 0 && B <= max_b;
 }
 
@@ -1199,6 +1160,13 @@ int dx_cnn_tail_factored(const dx_cnn_ctx *c) {
   return (c != nullptr && c->struct_bytes == static_cast<int>(sizeof(dx_cnn_ctx)) && fc_factored(c)) ? 1 : 0;
 }
 
+// 1 when dx_cnn_heads_loss_f32 applies to this ctx (the heads, the loss and the heads' backward in one launch): up to
+// 18 actions where the tail is factored (tail.hip), up to 7 on the layer-by-layer route (the head rows in registers)
+int dx_cnn_fused_heads(const dx_cnn_ctx *c) {
+  if (c == nullptr || c->struct_bytes != static_cast<int>(sizeof(dx_cnn_ctx))) return 0;
+  return (fc_factored(c) || c->num_actions + 1 <= 8) ? 1 : 0;
+}
+
 // Kernel family the LAST launch of `stage` took ("ntp", "wgrad_direct", "igemm_pix", ...; "" before any).
 const char *dx_cnn_last_route(int stage) {
   return (stage >= 0 && stage < ST_COUNT && g_route[stage]) ? g_route[stage] : "";
@@ -1233,7 +1201,7 @@ int cnn_pack_between_updates(const dx_cnn_ctx *c, bool last_update, int obs_is_u
   const bool light = fc_factored(c) && !last_update;
   // (the direct pack: only when the NEXT minibatch's every stage reads the bf16 planes -- uint8 frames through the
   // one-launch forward, bf16 data gradients, the first layer's bf16 kernels; DX_PACK_DIRECT=0: the general packs)
-  static const bool direct_env = [] { const char *e = getenv("DX_PACK_DIRECT"); return !(e && atoi(e) == 0); }();
+  const bool direct_env = DX_ENV("DX_PACK_DIRECT", 1) != 0;
   const bool direct = light && direct_env && convstack_train_usable(c, obs_is_u8) && dgrad_b6_usable(c) && wgrad_b6_on() &&
                       c->in_c == 4 && conv0_direct_supported(c->in_h, c->in_w, c->in_c, c->h0, c->w0);
   return pack_part(c, 3, s, light, direct);

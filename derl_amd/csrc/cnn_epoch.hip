@@ -69,9 +69,9 @@ static int epoch_body(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream, 
   DX_REQUIRE(e->loss_partials_capacity >= 8 * ((e->mbsize + 7) / 8), "dx_cnn_ppo_epoch: loss_partials too small");
   hipStream_t s = as_stream(stream);
   const long long tail = c->off_w[3];  // grads[tail ..) = linear layer + heads
-  // heads + loss + heads' backward in one launch where the action count allows (<= 7), like the
+  // heads + loss + heads' backward in one launch where the action count allows (dx_cnn_fused_heads), like the
   // per-update path (models._cnn_loss_forward_backward): the same kernels on both paths
-  const bool fused_heads = e->loss_counter != nullptr && c->num_actions + 1 <= 8;
+  const bool fused_heads = e->loss_counter != nullptr && dx_cnn_fused_heads(c) != 0;
   // with the fused launch the normalisation happens inside it: the statistics of EVERY minibatch of
   // the epoch come from one launch (bit-identical to the per-minibatch kernel's) instead of one
   // normalisation launch per update
@@ -86,7 +86,7 @@ static int epoch_body(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream, 
   // 32 envs 11.33 -> 12.17 ms -- a dependency between two HIP streams costs tens of microseconds on
   // this stack, more than the ~35 us of small launches it hides (the backward's side stream pays the
   // same price and wins only because it hides whole GEMM stages).
-  static const bool tail_overlap = [] { const char *v = getenv("DX_EPOCH_TAIL_OVERLAP"); return v && atoi(v) != 0; }();
+  const bool tail_overlap = DX_ENV("DX_EPOCH_TAIL_OVERLAP", 0) != 0;
   int k = 0;
   for (long long start = 0; start < e->samples; start += e->mbsize, ++k) {
     const int B = static_cast<int>(e->samples - start < e->mbsize ? e->samples - start : e->mbsize);

@@ -59,6 +59,30 @@ struct TraceRange {
 };
 #define DX_TRACE(name) ::dx::TraceRange dx_trace_range_(name)
 
+// Environment switches (diagnostic switches): read through ONE cache.  A switch is parsed the first time a
+// call needs it and again after dx_reload_env() (include/derl_amd.h) -- the values are process-wide on purpose (one
+// process per GPU), but nothing else about them is static: a host or a test that changes a switch says so.
+struct EnvSlot { int generation = -1, value = 0; bool set = false; };
+int env_generation();
+void env_read(EnvSlot &slot, const char *name, int dflt);  // getenv + atoi
+inline const EnvSlot &env_cached(EnvSlot &slot, const char *name, int dflt) {
+  if (slot.generation != env_generation()) env_read(slot, name, dflt);
+  return slot;
+}
+#define DX_ENV(name, dflt) ([]() -> int { static ::dx::EnvSlot slot_; return ::dx::env_cached(slot_, name, dflt).value; }())
+#define DX_ENV_SET(name) ([]() -> bool { static ::dx::EnvSlot slot_; return ::dx::env_cached(slot_, name, 0).set; }())
+
+// Per-device one-time set-up of a call site (the dynamic-LDS opt-in belongs to a DEVICE's code object: a process that
+// drives two devices must make it on each), and the CU count of the current device (devices may differ).
+struct DeviceFlags { bool seen[64] = {}; };
+int lds_opt_in(DeviceFlags &flags, const void *kernel, int bytes);
+int device_cus(int *cus_out);
+#define DX_LDS_OPT_IN(kernel, bytes)                                                                              \
+  do {                                                                                                            \
+    static ::dx::DeviceFlags flags_;                                                                              \
+    if (int rc_ = ::dx::lds_opt_in(flags_, reinterpret_cast<const void *>(kernel), static_cast<int>(bytes))) return rc_; \
+  } while (0)
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 inline int cdiv(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }

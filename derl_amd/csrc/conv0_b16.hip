@@ -486,19 +486,13 @@ __global__ __launch_bounds__(256) void conv0_lat_b16_kernel(const Conv0Args a, c
 namespace {
 // DX_C0_WAVES=4|8 pins the waves per workgroup of the 256-pixel-tile forward (A/B runs)
 int conv0_waves_env() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_C0_WAVES"); v = e ? atoi(e) : 0; }
+  const int v = DX_ENV("DX_C0_WAVES", 0);
   return v;
 }
 
 template <int T2>
 int launch_conv0_fwd_b16_as(const Conv0Args &a, const uint16_t *Wb, int lds, hipStream_t stream) {
-  static bool configured = false;
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv0_fwd_b16_kernel<T2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    configured = true;
-  }
+  DX_LDS_OPT_IN(conv0_fwd_b16_kernel<T2>, 160 * 1024);
   int grid = a.ntiles < 512 ? a.ntiles : 512;
 #if DX_DIAG
   if (getenv("DX_C0_DIAG")) {  // in-kernel phase cycles, summarised on stderr (synchronous)
@@ -552,12 +546,7 @@ int launch_conv0_lat_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t str
 namespace {
 template <bool GROUP4>
 int launch_conv0_wgrad_b16_as(const Conv0Args &a, int nblocks, int lds, hipStream_t stream) {
-  static bool configured = false;
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv0_wgrad_b16_kernel<GROUP4>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    configured = true;
-  }
+  DX_LDS_OPT_IN(conv0_wgrad_b16_kernel<GROUP4>, 160 * 1024);
 #if DX_DIAG
   if (getenv("DX_C0_DIAG")) {  // in-kernel phase cycles, summarised on stderr (synchronous)
     unsigned long long *dev = nullptr;
@@ -593,7 +582,7 @@ int launch_conv0_wgrad_b16(const Conv0Args &a, int nblocks, hipStream_t stream) 
   DX_REQUIRE(lds <= 160 * 1024 && patch_bytes(a) <= kPatchRegs * 256 * 16,
              "conv0_wgrad_b16: tile does not fit (%d LDS bytes, patch %d)", lds, patch_bytes(a));
   // DX_C0_GROUP4=0: the per-pixel offset table for every shape (A/B runs)
-  static const bool allow4 = [] { const char *e = getenv("DX_C0_GROUP4"); return !(e && atoi(e) == 0); }();
+  const bool allow4 = DX_ENV("DX_C0_GROUP4", 1) != 0;
   const bool group4 = allow4 && a.w0 % 4 == 0 && (a.h0 * a.w0) % 4 == 0;
   return group4 ? launch_conv0_wgrad_b16_as<true>(a, nblocks, lds, stream)
                 : launch_conv0_wgrad_b16_as<false>(a, nblocks, lds, stream);

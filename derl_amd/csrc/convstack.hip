@@ -52,11 +52,11 @@ namespace {
 // out[j] = the waves' sums in wave order + beff[j]; softmax over the A logits, inverse-CDF draw, log-prob, value.
 __device__ __forceinline__ void sample_step(const ConvStackArgs &a, const float *tailred, int t, int e, int lane) {
   const int A = a.A, col = lane & 31;
-  const float *part = tailred + (t & 1) * 64;
+  const float *part = tailred + (t & 1) * (8 * kTailOut);
   float x = 0.f;
-  if (lane < 8) {
+  if (lane <= A) {  // output `lane`: the waves' sums in wave order + beff
 #pragma unroll
-    for (int w = 0; w < 8; ++w) x += part[w * 8 + lane];
+    for (int w = 0; w < 8; ++w) x += part[w * kTailOut + lane];
     x += a.beff[lane];
   }
   float mx = -INFINITY;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   float *red = reinterpret_cast<float *>(smem + oRed);
-  float *tailred = reinterpret_cast<float *>(smem + oTail);  // [step parity][8 waves][8 outputs]
+  float *tailred = reinterpret_cast<float *>(smem + oTail);  // [step parity][8 waves][kTailOut outputs]
   // the weights come in fragment order (launch_convstack_pack): piece (wave, step, plane) is one KB, 16 bytes per lane
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const unsigned off1 = static_cast<unsigned>(lane * 16), off2 = off1;
@@ -293,15 +293,17 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
             __builtin_amdgcn_global_load_lds(src + 1024 * piece + 16 * lane3, smem + oFrame + 1024 * piece, 16, 0, 0);
         }
       }
-      // the tail's weights for outputs 0-3 now (under the exchange), for 4-7 after these are used
+      // the tail's weights for outputs 0-3 now (under the exchange), for every further group of four after these are used
+      // (fragment order: [wave][tile][row j of Jp = 8 ceil((A + 1) / 8)][lane][4])
       f32x4 wc[4][2];
-      const unsigned ow = static_cast<unsigned>(lane2 * 16);  // (fragment order: rows of pixels past the image are zero)
+      const unsigned ow = static_cast<unsigned>(lane2 * 16);  // (rows of pixels past the image are zero)
+      const int Jp = (a.A + 8) & ~7;
       if (!TRAIN && a.Wc) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            wc[j][m] = j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + ((wave_s * 2 + m) * 8 + j) * 256, ow)) : zero4;
+            wc[j][m] = j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + ((wave_s * 2 + m) * Jp + j) * 256, ow)) : zero4;
       }
       // (the exchange scratch lies behind the y1 planes: no wave is still reading what it overwrites)
       if (kh2 == 0) give_tiles<2, 2>(red, wave, lane, acc);
@@ -322,19 +324,17 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
         // ---- the policy's tail: out[j] = sum over (pixel, channel) of y2 Wc[j] + beff[j]; lane sums, wave sums
         // (DPP), the eight waves' sums meet in LDS in wave order, wave 0 samples (heads.hip: tail_act_block) ----
         float mine = 0.f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          if (half == 1) {
-            if (a.A < 4) break;  // uniform
+        for (int grp = 0; 4 * grp <= a.A; ++grp) {  // groups of four outputs (uniform trip count: 2 for Breakout, 5 for 18 actions)
+          if (grp > 0) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
               for (int j = 0; j < 4; ++j)
-                wc[j][m] = 4 + j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + ((wave_s * 2 + m) * 8 + 4 + j) * 256, ow)) : zero4;
+                wc[j][m] = 4 * grp + j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + ((wave_s * 2 + m) * Jp + 4 * grp + j) * 256, ow)) : zero4;
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (4 * half + j > a.A) continue;  // uniform: rows beyond A + 1 are zero
+            if (4 * grp + j > a.A) continue;  // uniform: rows beyond A + 1 are zero
             float part = 0.f;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -346,11 +346,11 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
               part += ok ? d : 0.f;
             }
             const float tot = wave_sum_all(part);
-            mine = lane == 4 * half + j ? tot : mine;
+            mine = lane == 4 * grp + j ? tot : mine;
           }
         }
         const int lane3 = opaque(lane);
-        if (lane3 < 8) tailred[(t & 1) * 64 + wave * 8 + lane3] = mine;  // sampled by wave 7 under the next step's conv0
+        if (lane3 <= a.A) tailred[(t & 1) * (8 * kTailOut) + wave * kTailOut + lane3] = mine;  // sampled by wave 7 under the next step's conv0
       }
     }
     DX_CS_MARK(6)
@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256) void convstack_pack_kernel(const uint16_t *Wb1
 
 }  // namespace
 
-long long convstack_pack_elems(int which) { return which == 0 ? kPieces1 * 8LL : which == 1 ? kPieces2 * 8LL : kPiecesC * 4LL; }
+// (the Wc copy: room for 24 padded output rows -- up to 18 actions + the value, launch_tail_pack writes it)
+long long convstack_pack_elems(int which) { return which == 0 ? kPieces1 * 8LL : which == 1 ? kPieces2 * 8LL : kPiecesC * 4LL * (kTailOut / 8); }
 
 int launch_convstack_pack(const uint16_t *Wb1, const uint16_t *Wb2, const float *Wc, uint16_t *Wf1, uint16_t *Wf2, float *Wcf,
                           hipStream_t stream) {
@@ -425,8 +426,8 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
                  (a.Wc == nullptr || aligned(a.Wc, 16)),
              "convstack: frames, weight planes, biases, Wc and y2 must be 16-byte aligned");
   DX_REQUIRE(a.y2 != nullptr || a.Wc != nullptr, "convstack: neither y2 nor the tail requested");
-  DX_REQUIRE(a.Wc == nullptr || (a.beff && a.actions && a.log_prob && a.values && a.A >= 1 && a.A + 1 <= 8),
-             "convstack: the in-kernel tail needs beff, the three outputs and <= 7 actions");
+  DX_REQUIRE(a.Wc == nullptr || (a.beff && a.actions && a.log_prob && a.values && a.A >= 1 && a.A + 1 <= 19),
+             "convstack: the in-kernel tail needs beff, the three outputs and <= 18 actions");
   DX_REQUIRE(a.env == 0 ? a.T == 1 : (a.Wc != nullptr && a.row_stride >= a.B && a.uniforms == nullptr),
              "convstack: T > 1 only against the synthetic env, with the tail in the kernel");
   DX_REQUIRE(a.train ? (a.env == 0 && a.Wc == nullptr && a.y0 && a.y1 && a.y2 && aligned(a.y0, 16) && aligned(a.y1, 16))
@@ -435,22 +436,14 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
   if (a.row_stride < a.B) a.row_stride = a.B;
   a.stamps = nullptr;
   a.stamp_step = 0;
-  static int configured_device = -1;
-  int dev = 0;
-  DX_HIP(hipGetDevice(&dev));
-  if (configured_device != dev) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(convstack_image_kernel<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(convstack_image_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    configured_device = dev;
-  }
-  static int cus = 0;
-  if (cus == 0) DX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  DX_LDS_OPT_IN(convstack_image_kernel<false>, kLdsBytes);
+  DX_LDS_OPT_IN(convstack_image_kernel<true>, kLdsBytes);
+  int cus = 0;
+  if (int rc = device_cus(&cus)) return rc;
   // a training forward: one workgroup per CU (the LDS holds one image), each walks its share of the minibatch
   const int B = a.train ? (a.B < cus ? a.B : cus) : a.B;  // workgroups
   // (default: the role-specialised kernel of convstack_train.hip; DX_CONVSTACK_TRAIN_ROLES=0: this file's one-role-for-all flavour)
-  static const bool roles = [] { const char *v = getenv("DX_CONVSTACK_TRAIN_ROLES"); return !(v && atoi(v) == 0); }();
+  const bool roles = DX_ENV("DX_CONVSTACK_TRAIN_ROLES", 1) != 0;
   if (a.train && roles) return launch_convstack_train(a, B, stream);
 #if DX_DIAG
   if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one step (DX_CS_STEP, default 0) of wave DX_CS_DIAG, on stderr (synchronous)

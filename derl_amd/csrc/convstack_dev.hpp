@@ -24,7 +24,7 @@ constexpr int kY1P = 160, kY1R = 9 * kY1P + 192, kY1Plane = 9 * kY1R;    // byte
 constexpr int kWRowB = 528, kWPlaneB = 32 * kWRowB;                // conv0 weight planes in LDS: 256 bf16 + 16 B pad
 // LDS: [conv0 weight planes][region B].  Region B holds, in turn: the frame (at its end) while conv0
 // multiplies, the three y0 planes, then the three y1 planes (at its start) + the K halves' exchange.
-constexpr int oW0 = 0, oB = oW0 + 3 * kWPlaneB, kRegionB = 3 * kY0Plane, oTail = oB + kRegionB, kLdsBytes = oTail + 2 * 8 * 8 * 4;
+constexpr int oW0 = 0, oB = oW0 + 3 * kWPlaneB, kRegionB = 3 * kY0Plane, oTail = oB + kRegionB, kTailOut = 24, kLdsBytes = oTail + 2 * 8 * kTailOut * 4;  // (tail: [step parity][8 waves][up to 24 padded outputs])
 constexpr int oFrame = oB + kRegionB - kFrameB, oY0 = oB, oY1 = oB, oRed = oB + 3 * kY1Plane;
 constexpr int kRedBytes = 8 * 3 * 64 * 16;  // every wave hands up to three accumulator tiles (16 bytes per lane each) to its partner
 static_assert(oB % 16 == 0 && oFrame % 16 == 0 && oRed % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS layout");

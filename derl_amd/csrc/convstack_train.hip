@@ -352,9 +352,8 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
   } else {
     // =================================== A: conv0 of image t + 1 ===================================
     const int aw = wave - 4;  // tiles 4 + aw, 8 + aw (and 12 for aw = 0) of the 13 tiles of 32 pixels; tile b is B wave b's
-    // (the younger wave of a SIMD pair loses every arbitration at equal priority: with its two conv1 tiles it ended
-    // 1,300 cycles behind B's four)
-    __builtin_amdgcn_s_setprio(1);
+    // (measured and not kept: s_setprio 1 for these, the younger waves of the SIMD pairs -- they then finish conv1 in 6,300
+    // cycles and their conv0 tiles in 7,700, but the B waves' loops stretch to 12,600 and 16,300: 615 us against 572)
     // conv0's bias for this lane's 16 accumulator rows (channels 8 q + 4 (lane >> 5) + j): fetched per image (L2), not
     // kept in 16 registers across the conv1 phase
     auto load_bias0 = [&](f32x4 (&bias0)[4], int l) {
@@ -363,7 +362,7 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
     };
     // conv1's tiles 4 and 5 for the channels of this SIMD's B wave (nt = aw), over the whole contraction: its own
     // fragment buffer cycles taps 0-7 -> taps 8-15 -> the next image's taps 0-7
-    const int n16 = lane & 15, kq = lane >> 4, oc0 = 16 * aw + 4 * kq;
+    const int kq = lane >> 4, oc0 = 16 * aw + 4 * kq;
     const uint16_t *w1h0 = a.Wf1 + aw * (8 * 3 * 512), *w1h1 = a.Wf1 + (aw + 4) * (8 * 3 * 512);
     u32x4 R[9][3];
 #pragma unroll
@@ -466,20 +465,14 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
 // the forward of a training minibatch (ConvStackArgs::train): a.B images over `blocks` workgroups (one per CU)
 int launch_convstack_train(const ConvStackArgs &args, int blocks, hipStream_t stream) {
   ConvStackArgs a = args;
-  static bool configured[64] = {};
-  int dev = 0;
-  DX_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !configured[dev]) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(convstack_train_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kLdsBytes));
+  DX_LDS_OPT_IN(convstack_train_kernel<0>, kLdsBytes);
 #if DX_DIAG
-    for (const void *f : {reinterpret_cast<const void *>(convstack_train_kernel<1>), reinterpret_cast<const void *>(convstack_train_kernel<2>),
-                          reinterpret_cast<const void *>(convstack_train_kernel<3>), reinterpret_cast<const void *>(convstack_train_kernel<4>),
-                          reinterpret_cast<const void *>(convstack_train_kernel<7>)})
-      DX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+  DX_LDS_OPT_IN(convstack_train_kernel<1>, kLdsBytes);
+  DX_LDS_OPT_IN(convstack_train_kernel<2>, kLdsBytes);
+  DX_LDS_OPT_IN(convstack_train_kernel<3>, kLdsBytes);
+  DX_LDS_OPT_IN(convstack_train_kernel<4>, kLdsBytes);
+  DX_LDS_OPT_IN(convstack_train_kernel<7>, kLdsBytes);
 #endif
-    if (dev >= 0 && dev < 64) configured[dev] = true;
-  }
 #if DX_DIAG
   if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one image (DX_CS_STEP) as seen by wave DX_CS_DIAG, on stderr (synchronous)
     unsigned long long *dev_stamps = nullptr;

@@ -38,6 +38,36 @@ TraceRange::~TraceRange() {
 
 namespace {
 std::atomic<long long> g_launches{0};
+std::atomic<int> g_env_generation{0};
+}
+int lds_opt_in(DeviceFlags &flags, const void *kernel, int bytes) {
+  int dev = 0;
+  DX_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && flags.seen[dev]) return DX_OK;
+  DX_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (dev >= 0 && dev < 64) flags.seen[dev] = true;
+  return DX_OK;
+}
+int device_cus(int *cus_out) {
+  static int table[64] = {};
+  int dev = 0;
+  DX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || table[dev] == 0) {
+    int cus = 0;
+    DX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) table[dev] = cus;
+    *cus_out = cus;
+    return DX_OK;
+  }
+  *cus_out = table[dev];
+  return DX_OK;
+}
+int env_generation() { return g_env_generation.load(std::memory_order_relaxed); }
+void env_read(EnvSlot &slot, const char *name, int dflt) {
+  const char *e = getenv(name);
+  slot.set = e != nullptr;
+  slot.value = e ? atoi(e) : dflt;
+  slot.generation = env_generation();
 }
 void count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 
@@ -50,6 +80,11 @@ char *error_buffer() {
 extern "C" int dx_abi_version(void) { return DX_ABI_VERSION; }
 
 extern "C" const char *dx_last_error(void) { return dx::error_buffer(); }
+
+extern "C" int dx_reload_env(void) {
+  dx::g_env_generation.fetch_add(1, std::memory_order_relaxed);
+  return DX_OK;
+}
 
 extern "C" long long dx_launch_count(void) { return dx::g_launches.load(std::memory_order_relaxed); }
 

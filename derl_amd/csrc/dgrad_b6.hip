@@ -314,11 +314,7 @@ template <int L>
 int launch_dg(const DgradB6Args &a, int nwg, hipStream_t stream) {
   constexpr int lds = DgLayout<L>::END;
   auto kernel = conv_dgrad_b6_kernel<L>;
-  static bool configured = false;  // per instantiation
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
+  DX_LDS_OPT_IN(kernel, lds);
   hipLaunchKernelGGL(kernel, dim3(nwg), dim3(512), lds, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -328,12 +324,7 @@ int launch_dg(const DgradB6Args &a, int nwg, hipStream_t stream) {
 
 // DX_DGRAD_B6=0: the fp32-MFMA kernels (ntp.hip / igemm_pix)
 bool dgrad_b6_on() {
-  static int on = -1;
-  if (on < 0) {
-    const char *e = getenv("DX_DGRAD_B6");
-    on = e ? atoi(e) : 1;
-  }
-  return on != 0;
+  return DX_ENV("DX_DGRAD_B6", 1) != 0;
 }
 // uint16 elements of the fragment-ordered dgrad weights of layer 1 / 2
 long long dgrad_b6_pack_elems(int layer) { return (layer == 1 ? 8LL * 8 : 8LL * 9) * 3 * 512; }
@@ -352,12 +343,8 @@ int launch_dgrad_b6_pack(const float *const c1d[4], const float *c2d, uint16_t *
 int launch_dgrad_b6(int layer, const float *g, const uint16_t *Wf, const float *mask_src, float *out, int B, hipStream_t stream) {
   DX_REQUIRE((layer == 1 || layer == 2) && g && Wf && mask_src && out && B > 0, "dgrad_b6: bad arguments");
   DX_REQUIRE(aligned(g, 16) && aligned(Wf, 16) && aligned(mask_src, 16) && aligned(out, 16), "dgrad_b6: operands must be 16-byte aligned");
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    DX_HIP(hipGetDevice(&dev));
-    DX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  int cus = 0;
+  if (int rc = device_cus(&cus)) return rc;
   const DgradB6Args a{g, Wf, mask_src, out, B};
   const int nwg = B < cus ? B : cus;
   return layer == 1 ? launch_dg<1>(a, nwg, stream) : launch_dg<2>(a, nwg, stream);

@@ -123,14 +123,7 @@ bool fc_rollout_supported(int M, int N, int K) { return M >= 1 && N == kN && K =
 int launch_fc_rollout(const float *A, const float *W, const float *bias, float *slabs, int M, hipStream_t stream) {
   DX_REQUIRE(A && W && bias && slabs && M >= 1, "fc_rollout: bad arguments");
   DX_REQUIRE(aligned(A, 16) && aligned(W, 16), "fc_rollout: operands must be 16-byte aligned");
-  static int configured_device = -1;
-  int dev = 0;
-  DX_HIP(hipGetDevice(&dev));
-  if (configured_device != dev) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_rollout_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    configured_device = dev;
-  }
+  DX_LDS_OPT_IN(fc_rollout_kernel, kLdsBytes);
   const FcRolloutArgs a{A, W, bias, slabs, M};
   hipLaunchKernelGGL(fc_rollout_kernel, dim3(kParts * (kN / 32)), dim3(512), kLdsBytes, stream, a);
   DX_LAUNCH_CHECK();

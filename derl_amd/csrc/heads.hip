@@ -797,10 +797,12 @@ __global__ __launch_bounds__(64 * kHlWaves) void heads_loss_fused_kernel(const H
 constexpr int kTailK = 3136;   // floats per flattened conv output (7 x 7 x 64, NHWC order)
 constexpr int kTailQ = 12;     // float4 per lane of a row held by one wave (12 x 64 x 4 = 3072) + one float
 constexpr int kTlWaves = 8;
+constexpr int kTailLdsRows = 12;  // rows of Wc a workgroup keeps in LDS (150 KB); with 13 .. 19 outputs (more than 11 actions)
+                                  // the rows beyond come straight from L2 -- every workgroup reads the same 88 KB
 
 struct TailLossArgs {
   const float *y2;         // [B][3136]
-  const float *Wc, *beff;  // [8][3136] (rows 0..A-1 policy, row A value, the rest zero), [8]
+  const float *Wc, *beff;  // [Jp][3136] (rows 0..A-1 policy, row A value, the rest zero), [Jp]: Jp = 8 ceil((A + 1) / 8)
   const int64_t *actions;
   const float *old_log_prob, *advantages, *old_values, *value_targets;
   const double *stats;     // optional {sum, sumsq, n} of the raw advantages: normalise here
@@ -817,10 +819,10 @@ struct TailLossArgs {
 // the A + 1 dot products of NR rows held in registers (y: 12 float4 + 1 float per lane and row) with
 // the rows of Wc in LDS: lane j (and j + 32) of x[u] ends up with output j of row u
 template <int NR>
-__device__ __forceinline__ void tail_dots(const float *wc_lds, int NJ, const float4 (&y)[NR][kTailQ], const float (&yt)[NR],
-                                          int lane, int col, float (&x)[NR]) {
+__device__ __forceinline__ void tail_dots(const float *wc_lds, const float *wc_global, int NJ, const float4 (&y)[NR][kTailQ],
+                                          const float (&yt)[NR], int lane, int col, float (&x)[NR]) {
   for (int j = 0; j < NJ; ++j) {  // uniform
-    const float *w = wc_lds + j * kTailK;
+    const float *w = j < kTailLdsRows ? wc_lds + j * kTailK : wc_global + j * kTailK;
     float part[NR];
 #pragma unroll
     for (int u = 0; u < NR; ++u) part[u] = 0.f;
@@ -849,13 +851,13 @@ __device__ __forceinline__ void tail_dots(const float *wc_lds, int NJ, const flo
 __global__ __launch_bounds__(64 * kTlWaves) void tail_loss_kernel(const TailLossArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tl_smem[];  // Wc rows, then [waves][8] doubles
   __shared__ unsigned ticket;
-  double *lsum = reinterpret_cast<double *>(tl_smem + 8 * kTailK);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31;
-  const int A = a.A, NJ = A + 1;
+  const int A = a.A, NJ = A + 1, lds_rows = NJ < kTailLdsRows ? NJ : kTailLdsRows;
+  double *lsum = reinterpret_cast<double *>(tl_smem + (lds_rows < 8 ? 8 : lds_rows) * kTailK);
   const LossParams lparams{a.A, a.mode, a.stats != nullptr, a.cliprange, a.value_loss_coef, a.entropy_coef, a.inv_batch};
-  for (int i = threadIdx.x; i < NJ * (kTailK / 4); i += 64 * kTlWaves)
+  for (int i = threadIdx.x; i < lds_rows * (kTailK / 4); i += 64 * kTlWaves)
     reinterpret_cast<float4 *>(tl_smem)[i] = reinterpret_cast<const float4 *>(a.Wc)[i];
-  const float bias_col = col < 8 ? a.beff[col] : 0.f;
+  const float bias_col = col <= A ? a.beff[col] : 0.f;
   float meanf = 0.f, denom = 1.f;
   if (a.stats) {  // adv_apply_kernel's expression
     const double cnt = a.stats[2], mean = a.stats[0] / cnt;
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(64 * kTlWaves) void tail_loss_kernel(const TailLoss
     float x[kAhead];
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) x[u] = 0.f;
-    tail_dots<kAhead>(tl_smem, NJ, y, yt, lane, col, x);
+    tail_dots<kAhead>(tl_smem, a.Wc, NJ, y, yt, lane, col, x);
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) {
       const bool ok = r0 + kTlWaves * u < row_end;  // uniform
@@ -943,14 +945,15 @@ __device__ __forceinline__ void tail_act_block(const TailActArgs &p, int block, 
 #pragma unroll
   for (int q = 0; q < kTailQ; ++q) y[0][q] = reinterpret_cast<const float4 *>(base)[lane + 64 * q];
   yt[0] = base[64 * 4 * kTailQ + lane];
-  const float bias_col = col < 8 ? p.beff[col] : 0.f;
+  const float bias_col = col <= A ? p.beff[col] : 0.f;
   const float u_given = p.uniforms ? p.uniforms[row] : 0.f;
-  for (int i = threadIdx.x; i < NJ * (kTailK / 4); i += 256)
+  const int lds_rows = NJ < kTailLdsRows ? NJ : kTailLdsRows;
+  for (int i = threadIdx.x; i < lds_rows * (kTailK / 4); i += 256)
     reinterpret_cast<float4 *>(wc_lds)[i] = reinterpret_cast<const float4 *>(p.Wc)[i];
   __syncthreads();
   if (b >= p.B) return;  // whole wave exits together (after the barrier)
   float xs[1] = {0.f};
-  tail_dots<1>(wc_lds, NJ, y, yt, lane, col, xs);
+  tail_dots<1>(wc_lds, p.Wc, NJ, y, yt, lane, col, xs);
   const float x = xs[0] + bias_col;
   // categorical head (see heads_act_fused_block); lane indices below are uniform -> v_readlane
   float mx = -INFINITY;
@@ -1143,12 +1146,7 @@ int launch_heads_loss_fused(const float *hid, const float *Wh, const float *bh, 
                         rows_per_slab, mode, cliprange, value_loss_coef, entropy_coef,
                         1.0f / static_cast<float>(global_batch)};
   constexpr int lds = (kHlWaves * 8 * 512 + kHlWaves * 32) * 4 + kHlWaves * 8 * 8;
-  static bool configured = false;
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(heads_loss_fused_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
+  DX_LDS_OPT_IN(heads_loss_fused_kernel, lds);
   hipLaunchKernelGGL(heads_loss_fused_kernel, dim3(nslab), dim3(64 * kHlWaves), lds, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -1183,14 +1181,14 @@ int launch_heads_act_synth(const float *hid_slabs, int nslab, long long slab_str
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
-// forward + loss of the factored tail (tail_loss_kernel); DX_ENOSUP for more than 7 actions
+// forward + loss of the factored tail (tail_loss_kernel); DX_ENOSUP for more than 18 actions
 int launch_tail_loss(const float *y2, const float *Wc, const float *beff, const int64_t *actions,
                      const float *old_log_prob, const float *advantages, const float *old_values,
                      const float *value_targets, const double *stats, float norm_eps, float *adv_norm_out, float *head,
                      float *dhead, int B, int A, int mode, float cliprange, float value_loss_coef, float entropy_coef,
                      long long global_batch, double *partials, int partials_capacity, unsigned *counter,
                      float *loss_out, hipStream_t stream) {
-  if (A + 1 > 8) return DX_ENOSUP;
+  if (A + 1 > 19) return DX_ENOSUP;
   DX_REQUIRE(B >= 1 && A >= 1, "tail_loss: bad shape B=%d A=%d", B, A);
   DX_REQUIRE(mode == 0 || mode == 1, "tail_loss: mode must be 0 (PPO) or 1 (A2C)");
   DX_REQUIRE(y2 && Wc && beff && actions && advantages && value_targets && head && dhead && partials && counter && loss_out,
@@ -1205,39 +1203,28 @@ int launch_tail_loss(const float *y2, const float *Wc, const float *beff, const 
   const TailLossArgs a{y2, Wc, beff, actions, old_log_prob, advantages, old_values, value_targets, stats, norm_eps,
                        adv_norm_out, head, dhead, partials, counter, loss_out, B, A, rows, mode, cliprange,
                        value_loss_coef, entropy_coef, 1.0f / static_cast<float>(global_batch)};
-  constexpr int lds = 8 * kTailK * 4 + kTlWaves * 8 * 8;
-  static int configured_device = -1;
-  int dev = 0;
-  DX_HIP(hipGetDevice(&dev));
-  if (configured_device != dev) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tail_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured_device = dev;
-  }
+  const int lds_rows = A + 1 < 8 ? 8 : (A + 1 < kTailLdsRows ? A + 1 : kTailLdsRows);
+  const int lds = lds_rows * kTailK * 4 + kTlWaves * 8 * 8;
+  DX_LDS_OPT_IN(tail_loss_kernel, kTailLdsRows * kTailK * 4 + kTlWaves * 8 * 8);
   hipLaunchKernelGGL(tail_loss_kernel, dim3(nwg), dim3(64 * kTlWaves), lds, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
 
 static int configure_tail_act() {
-  static int configured_device = -1;
-  int dev = 0;
-  DX_HIP(hipGetDevice(&dev));
-  if (configured_device != dev) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tail_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kTailK * 4));
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tail_act_synth_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kTailK * 4));
-    configured_device = dev;
-  }
+  DX_LDS_OPT_IN(tail_act_kernel, kTailLdsRows * kTailK * 4);
+  DX_LDS_OPT_IN(tail_act_synth_kernel, kTailLdsRows * kTailK * 4);
   return DX_OK;
 }
 
 // the rollout's factored tail: y2 (B, 3136) -> actions / log_prob / values
 int launch_tail_act(const float *y2, const float *Wc, const float *beff, int B, int A, const float *uniforms, uint64_t seed,
                     uint64_t counter, int64_t *actions, float *log_prob, float *values, hipStream_t stream) {
-  DX_REQUIRE(B >= 1 && A >= 1 && A + 1 <= 8, "tail_act: bad shape B=%d A=%d", B, A);
+  DX_REQUIRE(B >= 1 && A >= 1 && A + 1 <= 19, "tail_act: bad shape B=%d A=%d", B, A);
   DX_REQUIRE(y2 && Wc && beff && actions && log_prob && values, "tail_act: null pointer");
   if (int rc = configure_tail_act()) return rc;
   const TailActArgs p{y2, Wc, beff, B, A, uniforms, seed, counter, actions, log_prob, values, 0};
-  hipLaunchKernelGGL(tail_act_kernel, dim3(cdiv(B, 4)), dim3(256), (A + 1) * kTailK * 4, stream, p);
+  hipLaunchKernelGGL(tail_act_kernel, dim3(cdiv(B, 4)), dim3(256), (A + 1 < kTailLdsRows ? A + 1 : kTailLdsRows) * kTailK * 4, stream, p);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -1246,7 +1233,7 @@ int launch_tail_act_synth(const float *y2, const float *Wc, const float *beff, i
                           int64_t *actions, float *log_prob, float *values, void *frames, long long frame_bytes,
                           float *rewards, uint8_t *resets, uint64_t env_seed, uint64_t env_counter, float p_reward,
                           float p_reset, int env0, long long vec0, hipStream_t stream) {
-  DX_REQUIRE(B >= 1 && A >= 1 && A + 1 <= 8, "tail_act_synth: bad shape B=%d A=%d", B, A);
+  DX_REQUIRE(B >= 1 && A >= 1 && A + 1 <= 19, "tail_act_synth: bad shape B=%d A=%d", B, A);
   DX_REQUIRE(y2 && Wc && beff && actions && log_prob && values, "tail_act_synth: null pointer");
   DX_REQUIRE(frames && frame_bytes > 0 && frame_bytes % 16 == 0 && aligned(frames, 16),
              "tail_act_synth: frames must be 16-byte aligned, size a multiple of 16");
@@ -1255,7 +1242,7 @@ int launch_tail_act_synth(const float *y2, const float *Wc, const float *beff, i
   const SynthArgs e{static_cast<uint4 *>(frames), frame_bytes / 16, rewards, resets, B, env_seed, env_counter,
                     p_reward, p_reset, vec0, env0};
   const int ab = cdiv(B, 4);
-  hipLaunchKernelGGL(tail_act_synth_kernel, dim3(ab + synth_blocks(e.nvec, B)), dim3(256), (A + 1) * kTailK * 4, stream, p, e, ab);
+  hipLaunchKernelGGL(tail_act_synth_kernel, dim3(ab + synth_blocks(e.nvec, B)), dim3(256), (A + 1 < kTailLdsRows ? A + 1 : kTailLdsRows) * kTailK * 4, stream, p, e, ab);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

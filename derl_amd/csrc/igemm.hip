@@ -577,8 +577,7 @@ int launch_nt_small(const NTArgs &a, hipStream_t stream) {
 }
 
 int tn_swizzle() {  // DX_TN_SWIZZLE=0: plain 3-D grid for the wgrad kernels
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_TN_SWIZZLE"); v = e ? atoi(e) : 1; }
+  const int v = DX_ENV("DX_TN_SWIZZLE", 1);
   return v;
 }
 
@@ -604,19 +603,16 @@ int launch_tn_as(const TNArgs &a_in, hipStream_t stream) {
 //   N >= 64 : 256x64 (4 waves of 64x64)   |  128x64 (4 waves of 64x32)  |  64x64 (4 waves of 32x32)
 #ifdef DX_EXPERIMENT_B3
 static int split_bf16() {  // DX_SPLIT_BF16=1: big NT stages on the bf16 matrix cores (3-way split)
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_SPLIT_BF16"); v = e ? atoi(e) : 0; }
+  const int v = DX_ENV("DX_SPLIT_BF16", 0);
   return v;
 }
 static int split_min_m() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_SPLIT_MIN_M"); v = e ? atoi(e) : 65536; }
+  const int v = DX_ENV("DX_SPLIT_MIN_M", 65536);
   return v;
 }
 #endif
 static int nt_big_min_m() {  // DX_NT_BIG_MIN_M: rows from which the N=64 stages use 128x64 tiles
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NT_BIG_MIN_M"); v = e ? atoi(e) : 65536; }
+  const int v = DX_ENV("DX_NT_BIG_MIN_M", 65536);
   return v;
 }
 // Small problems (rollout batches) are latency-bound: 64-deep K steps halve the number of

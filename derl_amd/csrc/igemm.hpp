@@ -266,9 +266,10 @@ int fc_rollout_parts();
 bool fc_rollout_supported(int M, int N, int K);
 int launch_fc_rollout(const float *A, const float *W, const float *bias, float *slabs, int M, hipStream_t stream);
 // the factored tail: linear layer + heads as one affine map of y2 (tail.hip, heads.hip)
-bool tail_supported(int flat, int num_actions);
-long long tail_pack_scratch_floats();
-long long tail_slab_floats(int B);
+bool tail_supported(int flat, int num_actions);  // 84 x 84 frames' conv output (3136 wide) and up to 18 actions
+int tail_rows(int num_actions);                   // the A + 1 outputs padded to groups of eight (8, 16 or 24 rows)
+long long tail_pack_scratch_floats(int num_actions);
+long long tail_slab_floats(int B, int num_actions);
 int launch_tail_pack(const float *params, const long long *off_w, const long long *off_b, int A, float *Wc, float *beff,
                      float *scratch, float *Wcf, hipStream_t stream);  // Wcf (optional): Wc in convstack.hip's fragment order
 // the bf16 planes every conv stage of the default route reads, straight from the canonical parameters (pack_direct.hip)

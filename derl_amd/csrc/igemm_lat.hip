@@ -143,8 +143,7 @@ int launch_lat_as(const NTArgs &a, hipStream_t stream) {
 // LDS-tiled kernels on MI355X: conv0 wins up to 3200+ tiles, conv1 at 1296, conv2 / linear lose
 // from ~800).  DX_LAT_MAX_TILES overrides all of them (0 = off).
 int lat_max_tiles(int stage) {
-  static int env = -2;
-  if (env == -2) { const char *e = getenv("DX_LAT_MAX_TILES"); env = e ? atoi(e) : -1; }
+  const int env = DX_ENV("DX_LAT_MAX_TILES", -1);
   if (env >= 0) return env;
   switch (stage) {
     case ST_CONV0_FWD: return 4096;

@@ -183,8 +183,7 @@ int launch_pix_as(const NTArgs &a, int nimg, hipStream_t stream) {
 }
 
 bool pix_enabled() {  // DX_DGRAD_PIX=0: dgrads on the generic kernel (zero taps multiplied)
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_DGRAD_PIX"); v = e ? atoi(e) : 1; }
+  const int v = DX_ENV("DX_DGRAD_PIX", 1);
   return v != 0;
 }
 

@@ -53,8 +53,7 @@ int msplit_bound(long long M) {  // >= the msplit of every batch <= M
 
 // DX_MLP_UNFUSED=1: the layer-by-layer implicit-GEMM path also for narrow observations
 bool use_fused(const dx_mlp_ctx *c) {
-  static int off = -1;
-  if (off < 0) { const char *e = getenv("DX_MLP_UNFUSED"); off = (e && atoi(e)) ? 1 : 0; }
+  const bool off = DX_ENV("DX_MLP_UNFUSED", 0) != 0;
   return !off && mlp_fused_supported(c->obs_pad);
 }
 

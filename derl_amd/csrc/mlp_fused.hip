@@ -437,12 +437,7 @@ int rollout_as(const MlpRolloutArgs &a, hipStream_t s) {
   constexpr int R = 8;
   constexpr size_t bytes = sizeof(float) * (2 * (kH * (DP + 4) + kH * kLdT + kHeadLd * kLdT + 160) + R * DP + 4 * R * kH + 2 * R * kHeadLd);
   static_assert(bytes <= 160 * 1024, "LDS");
-  static bool configured = false;
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_rollout_synth_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(bytes)));
-    configured = true;
-  }
+  DX_LDS_OPT_IN(mlp_rollout_synth_kernel<DP>, static_cast<int>(bytes));
   hipLaunchKernelGGL((mlp_rollout_synth_kernel<DP>), dim3(cdiv(a.f.B, R)), dim3(2 * kThreads), bytes, s, a);
   DX_LAUNCH_CHECK();
   return DX_OK;

@@ -746,14 +746,7 @@ long long mlp_persist_workspace_bytes(int G) {
 bool comm_active();  // comm.hip
 
 static int configure_persist_kernel() {
-  static int configured_device = -1;  // per device: the attribute belongs to the device's code object
-  int dev = 0;
-  DX_HIP(hipGetDevice(&dev));
-  if (configured_device != dev) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(persist_lds_bytes())));
-    configured_device = dev;
-  }
+  DX_LDS_OPT_IN(mlp_persist_kernel, static_cast<int>(persist_lds_bytes()));
   return DX_OK;
 }
 

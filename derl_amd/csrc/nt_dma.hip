@@ -156,12 +156,7 @@ __global__ __launch_bounds__(512, 2) void nt_dma_kernel(const NtDmaArgs a, unsig
 template <int EPI, int STAGES>
 int launch_as(const NtDmaArgs &a, hipStream_t stream) {
   constexpr int lds = STAGES * kStageFloats * 4;
-  static bool configured = false;
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nt_dma_kernel<EPI, STAGES>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
+  DX_LDS_OPT_IN((nt_dma_kernel<EPI, STAGES>), lds);
   const int grid = (a.M / kBM) * cdiv(a.N, kBN);
 #if DX_DIAG
   static const int diag = getenv("DX_NT_DIAG") ? atoi(getenv("DX_NT_DIAG")) : 0;

@@ -476,28 +476,24 @@ __global__ __launch_bounds__(64 * ((BM / (32 * TM)) * (BN / (32 * TN)) + NLOAD),
 }
 
 bool ntp_on() {  // DX_NTP=0: these stages on the per-tile kernels
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NTP"); v = e ? atoi(e) : 1; }
+  const int v = DX_ENV("DX_NTP", 1);
   return v != 0;
 }
 
 // DX_NTP_MIN_TILES: fewest tiles a stage must have to take these kernels (below it a workgroup per
 // CU is not reached and the per-tile kernels' finer tiles win)
 int ntp_min_tiles() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NTP_MIN_TILES"); v = e ? atoi(e) : 256; }
+  const int v = DX_ENV("DX_NTP_MIN_TILES", 256);
   return v;
 }
 
 bool rows_inner_on() {  // DX_NTP_ROWS_INNER=0: the linear layer's tiles walked column tiles innermost
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NTP_ROWS_INNER"); v = e ? atoi(e) : 1; }
+  const int v = DX_ENV("DX_NTP_ROWS_INNER", 1);
   return v != 0;
 }
 
 bool ntp_small_on() {  // DX_NTP_SMALL=0: rollout-sized forward stages on the latency kernels
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NTP_SMALL"); v = e ? atoi(e) : 1; }
+  const int v = DX_ENV("DX_NTP_SMALL", 1);
   return v != 0;
 }
 
@@ -514,12 +510,7 @@ int ntp_workgroups(int per_cu) {  // every CU full (diag build: DX_NTP_NWG force
 
 template <int TAG, int MODE, int EPI, class S>
 int launch_as(const NtpArgs &p, hipStream_t stream) {
-  static bool configured = false;
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TM, S::TN, S::RING, S::NLOAD, S::WGS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES));
-    configured = true;
-  }
+  DX_LDS_OPT_IN((ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TM, S::TN, S::RING, S::NLOAD, S::WGS>), S::LDS_BYTES);
   const int grid = ntp_workgroups(S::WGS);
 #if DX_DIAG
   static const int diag = getenv("DX_NTP_DIAG") ? atoi(getenv("DX_NTP_DIAG")) : 0;
@@ -659,7 +650,7 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
   p.nt = a;
   p.ntiles = p.diag = p.rows_inner = 0;
   p.kparts = 1; p.div_kparts = make_fastdiv(1); p.slab_bytes = 0;
-  static const bool blocked_on = [] { const char *e = getenv("DX_NTP_BLOCKED"); return !(e && atoi(e) == 0); }();
+  const bool blocked_on = DX_ENV("DX_NTP_BLOCKED", 1) != 0;
   p.blocked = blocked_on ? 1 : 0;
   p.groups_per_xcd = 1; p.div_groups = make_fastdiv(1);
   p.TA = TA; p.TB = TB; p.PA = g.seg_off[TB]; p.PB = g.seg_off[1];
@@ -678,8 +669,7 @@ int launch_ntp_pix(const NTArgs &a, int nimg, int TA, int TB, hipStream_t stream
 // config 5's shard) that is 64-80 workgroups walking 98 K steps each on a 256-CU chip -- 197 us for
 // 2,560 rows where the 8,192-row minibatch takes 202 us; 128-160 ring-kernel tiles use twice the CUs.
 int ntp_fc_fwd_min_tiles() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("DX_NTP_FC_FWD_MIN_TILES"); v = e ? atoi(e) : 128; }
+  const int v = DX_ENV("DX_NTP_FC_FWD_MIN_TILES", 128);
   return v;
 }
 
@@ -693,7 +683,7 @@ int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, 
   // 3,072 rows the doubled tiles share CUs and it loses (118 -> 131, 121 -> 137 us).  Seven parts (the
   // other divisor of the 98 steps) for <= 8 row groups, where halves would fill a quarter of the chip.
   // DX_NTP_FC_FWD_KSPLIT=0: off; =2: halves only; =7: seven parts wherever the scratch allows (experiments).
-  static const int ksplit_mode = [] { const char *e = getenv("DX_NTP_FC_FWD_KSPLIT"); return e ? atoi(e) : 1; }();
+  const int ksplit_mode = DX_ENV("DX_NTP_FC_FWD_KSPLIT", 1);
   const long long whole_tiles = (M % ShapeS::BM || N % ShapeS::BN) ? 0 : 1LL * (M / ShapeS::BM) * (N / ShapeS::BN);
   int kparts = 1;
   if (ksplit_mode != 0 && bias != nullptr && whole_tiles > 0 && ksplit_slabs && whole_tiles < ntp_min_tiles()) {
@@ -731,7 +721,7 @@ int launch_ntp_rows(const float *A, int lda, const float *W, const float *mask, 
   // every XCD must own the same number of row groups
   p.rows_inner = mask != nullptr && p.ngroups % 8 == 0 && rows_inner_on();
   // a row-group count that is not a multiple of 8: contiguous eighths of the tile list (see NtpArgs::blocked)
-  static const bool blocked_on = [] { const char *e = getenv("DX_NTP_BLOCKED"); return !(e && atoi(e) == 0); }();
+  const bool blocked_on = DX_ENV("DX_NTP_BLOCKED", 1) != 0;
   p.blocked = (blocked_on && !p.rows_inner && p.ngroups % 8 != 0) ? 1 : 0;
   if (p.blocked) p.tiles_per_xcd = static_cast<int>((1LL * p.ngroups * gn + 7) / 8);
   p.groups_per_xcd = p.ngroups / 8 > 0 ? p.ngroups / 8 : 1;

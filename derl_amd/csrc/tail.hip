@@ -25,7 +25,12 @@
 namespace dx {
 namespace {
 
-constexpr int kK = 3136, kNH = 512, kP = 49, kJ = 8;  // flat width (49 pixels x 64 channels), hidden width, pixels, padded outputs
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kK = 3136, kNH = 512, kP = 49;  // flat width (49 pixels x 64 channels), hidden width, pixels
+// The A + 1 outputs are padded to Jp = 8, 16 or 24 rows (groups of eight: up to 18 actions + the value -- the full Atari
+// action set, derl/env/make_env.py:94-106); every per-output array below has Jp rows, rows beyond A + 1 are zero.
+constexpr int kJ = 8, kJMax = 24, kMaxOutputs = 19;
 constexpr int kChunks = 8;                                       // n chunks of the Wc product
 constexpr int kBwdThreads = 448, kBwdCols = kK / kBwdThreads;    // 7 columns per thread
 
@@ -40,13 +45,13 @@ __device__ __forceinline__ float head_weight(const TailWeights &w, int j, int n)
   return j < w.A ? w.Wp[j * kNH + n] : (j == w.A ? w.Wv[n] : 0.f);
 }
 
-// partial[chunk][j][kc] = sum over the chunk's 64 hidden units n of Wh[j][n] Wfc[n][kc]
-__global__ __launch_bounds__(256) void tail_pack_partial_kernel(const TailWeights w, float *partial) {
+// partial[chunk][j][kc] = sum over the chunk's 64 hidden units n of Wh[j][n] Wfc[n][kc]; blockIdx.y = group of eight outputs
+__global__ __launch_bounds__(256) void tail_pack_partial_kernel(const TailWeights w, float *partial, int Jp) {
   __shared__ float sWh[kJ][64];
   __shared__ float red[4][kJ][64];
   const int t = threadIdx.x, col = t & 63, ng = t >> 6;
-  const int colblk = blockIdx.x % kP, chunk = blockIdx.x / kP;
-  for (int i = t; i < kJ * 64; i += 256) sWh[i >> 6][i & 63] = head_weight(w, i >> 6, chunk * 64 + (i & 63));
+  const int colblk = blockIdx.x % kP, chunk = blockIdx.x / kP, j0 = 8 * blockIdx.y;
+  for (int i = t; i < kJ * 64; i += 256) sWh[i >> 6][i & 63] = head_weight(w, j0 + (i >> 6), chunk * 64 + (i & 63));
   const int kc = colblk * 64 + col;
   float v[16];
 #pragma unroll
@@ -64,62 +69,63 @@ __global__ __launch_bounds__(256) void tail_pack_partial_kernel(const TailWeight
   __syncthreads();
   for (int i = t; i < kJ * 64; i += 256) {
     const int j = i >> 6, c = i & 63;
-    partial[static_cast<long long>(chunk * kJ + j) * kK + colblk * 64 + c] = ((red[0][j][c] + red[1][j][c]) + red[2][j][c]) + red[3][j][c];
+    partial[static_cast<long long>(chunk * Jp + j0 + j) * kK + colblk * 64 + c] = ((red[0][j][c] + red[1][j][c]) + red[2][j][c]) + red[3][j][c];
   }
 }
 
 // Wc[j][p * 64 + c] = sum of the chunks' partial[.][j][c * 49 + p]; last block: beff[j] = Wh[j] . bfc + bh[j]
 // (Wcf, optional: the same values in the fragment order of the rollout's conv-stack kernel, convstack.hip --
-// [wave = 4 (p / 32) + c / 16][tile (p % 32) / 16][row j][lane = 16 ((c % 16) / 4) + p % 16][c % 4]; the rows of
+// [wave = 4 (p / 32) + c / 16][tile (p % 32) / 16][row j of Jp][lane = 16 ((c % 16) / 4) + p % 16][c % 4]; the rows of
 // pixels 49 .. 63 are never written: `packed` is zero-filled once by its owner)
 __global__ __launch_bounds__(256) void tail_pack_finish_kernel(const float *partial, const TailWeights w, float *Wc, float *beff,
-                                                               float *Wcf) {
+                                                               float *Wcf, int Jp) {
   const int t = threadIdx.x;
   if (blockIdx.x == gridDim.x - 1) {
-    __shared__ float red[4][kJ];
-    float part[kJ];
+    __shared__ float red[4][kJMax];
+    float part[kJMax];
 #pragma unroll
-    for (int j = 0; j < kJ; ++j) part[j] = 0.f;
+    for (int j = 0; j < kJMax; ++j) part[j] = 0.f;
     for (int n = t; n < kNH; n += 256) {
       const float b = w.bfc[n];
 #pragma unroll
-      for (int j = 0; j < kJ; ++j) part[j] = fmaf(head_weight(w, j, n), b, part[j]);
+      for (int j = 0; j < kJMax; ++j)
+        if (j < Jp) part[j] = fmaf(head_weight(w, j, n), b, part[j]);  // (uniform)
     }
 #pragma unroll
-    for (int j = 0; j < kJ; ++j) {
+    for (int j = 0; j < kJMax; ++j) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) part[j] += __shfl_xor(part[j], o);
       if ((t & 63) == 0) red[t >> 6][j] = part[j];
     }
     __syncthreads();
-    if (t < kJ) {
+    if (t < Jp) {
       const float bh = t < w.A ? w.bp[t] : (t == w.A ? w.bv[0] : 0.f);
       beff[t] = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) + bh;
     }
     return;
   }
   const int i = blockIdx.x * 256 + t;
-  if (i >= kJ * kK) return;
+  if (i >= Jp * kK) return;
   const int j = i / kK, k = i - j * kK, p = k >> 6, c = k & 63;
   const int kc = c * kP + p;
   float v = 0.f;
 #pragma unroll
-  for (int chunk = 0; chunk < kChunks; ++chunk) v += partial[static_cast<long long>(chunk * kJ + j) * kK + kc];
+  for (int chunk = 0; chunk < kChunks; ++chunk) v += partial[static_cast<long long>(chunk * Jp + j) * kK + kc];
   Wc[i] = v;
   if (Wcf) {
     const int wave = 4 * (p >> 5) + (c >> 4), m = (p >> 4) & 1, lane = 16 * ((c >> 2) & 3) + (p & 15);
-    Wcf[((wave * 2 + m) * 8 + j) * 256 + lane * 4 + (c & 3)] = v;
+    Wcf[((wave * 2 + m) * Jp + j) * 256 + lane * 4 + (c & 3)] = v;
   }
 }
 
 struct TailBwdArgs {
   const float *y2;     // [B][3136]
   const float *dhead;  // [B][32]: dL/dout in columns 0..A
-  const float *Wc;     // [8][3136]
+  const float *Wc;     // [Jp][3136]
   float *dy2;          // [B][3136]
-  float *gslab;        // [gridDim.x][8][3136] partial G
-  float *sslab;        // [gridDim.x][8] partial s
-  int B, rows_per_wg;
+  float *gslab;        // [gridDim.x][Jp][3136] partial G
+  float *sslab;        // [gridDim.x][Jp] partial s
+  int B, rows_per_wg, Jp;
 };
 
 // One pass over y2: dy2 = relu'(y2) * (dout Wc) and this workgroup's partial G = dout^T y2, s = sum dout.
@@ -168,20 +174,76 @@ __global__ __launch_bounds__(kBwdThreads) void tail_bwd_kernel(const TailBwdArgs
       for (int j = 0; j < NJ; ++j) sacc[j] += d[u][j];
     }
   }
-  float *slab = a.gslab + static_cast<long long>(blockIdx.x) * kJ * kK;
+  float *slab = a.gslab + static_cast<long long>(blockIdx.x) * a.Jp * kK;
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < kBwdCols; ++i) slab[j * kK + t + kBwdThreads * i] = g[j][i];
   if (t == 0) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) a.sslab[blockIdx.x * kJ + j] = sacc[j];
+    for (int j = 0; j < NJ; ++j) a.sslab[blockIdx.x * a.Jp + j] = sacc[j];
+  }
+}
+
+// The same pass for 9 .. 19 outputs (up to 18 actions + the value): 2 NJ registers per column no longer fit seven
+// columns per thread, so a workgroup takes HALF of a row (blockIdx.y; 392 threads x one float4 = 1,568 columns) and two
+// rows in flight; the outputs' gradients of a row are uniform (scalar loads), y2 and dy2 move as 16-byte accesses.
+constexpr int kWideThreads = 392;  // x 4 columns x 2 halves = 3136
+template <int NJ>
+__global__ __launch_bounds__(448) void tail_bwd_wide_kernel(const TailBwdArgs a) {
+  const int t = threadIdx.x;
+  if (t >= kWideThreads) return;
+  const int q = kWideThreads * blockIdx.y + t;  // float4 index within a row
+  f32x4 wc[NJ], g[NJ];
+  float sacc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    sacc[j] = 0.f;
+    wc[j] = reinterpret_cast<const f32x4 *>(a.Wc + j * kK)[q];
+    g[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int r0 = blockIdx.x * a.rows_per_wg, r1 = min(a.B, r0 + a.rows_per_wg);
+  constexpr int kRows = 2;  // rows in flight
+  for (int r = r0; r < r1; r += kRows) {
+    f32x4 y[kRows];
+    float d[kRows][NJ];
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const long long row = min(r + u, a.B - 1);
+      y[u] = reinterpret_cast<const f32x4 *>(a.y2 + row * kK)[q];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) d[u][j] = a.dhead[row * 32 + j];  // the same address in every lane
+    }
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      if (r + u >= r1) break;  // uniform
+      f32x4 dsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dsum[i] = fmaf(d[u][j], wc[j][i], dsum[i]);
+          g[j][i] = fmaf(d[u][j], y[u][i], g[j][i]);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dsum[i] = y[u][i] > 0.f ? dsum[i] : 0.f;
+      reinterpret_cast<f32x4 *>(a.dy2 + static_cast<long long>(r + u) * kK)[q] = dsum;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) sacc[j] += d[u][j];
+    }
+  }
+  float *slab = a.gslab + static_cast<long long>(blockIdx.x) * a.Jp * kK;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) reinterpret_cast<f32x4 *>(slab + j * kK)[q] = g[j];
+  if (t == 0 && blockIdx.y == 0) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) a.sslab[blockIdx.x * a.Jp + j] = sacc[j];
   }
 }
 
 // G[j][k] = sum over the workgroups' partials (fixed order), in y2's column order and in the canonical
 // order of Wfc's columns (k = p * 64 + c  ->  c * 49 + p); block (0, j) also sums s[j]
-__global__ __launch_bounds__(256) void tail_greduce_kernel(const float *gslab, const float *sslab, int nslab, int nj, float *Gc, float *s) {
+__global__ __launch_bounds__(256) void tail_greduce_kernel(const float *gslab, const float *sslab, int nslab, int nj, int Jp, float *Gc, float *s) {
   __shared__ float red[4][64];
   __shared__ float sred[256];
   const int t = threadIdx.x, c = t & 63, sg = t >> 6;
@@ -197,7 +259,7 @@ __global__ __launch_bounds__(256) void tail_greduce_kernel(const float *gslab, c
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int z = z0 + 4 * u;
-      x[u] = z < nslab ? gslab[(static_cast<long long>(z) * kJ + j) * kK + p * 64 + c] : 0.f;
+      x[u] = z < nslab ? gslab[(static_cast<long long>(z) * Jp + j) * kK + p * 64 + c] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) v += x[u];
@@ -205,7 +267,7 @@ __global__ __launch_bounds__(256) void tail_greduce_kernel(const float *gslab, c
   red[sg][c] = v;
   if (p == 0) {
     float sv = 0.f;
-    for (int z = t; z < nslab; z += 256) sv += sslab[z * kJ + j];
+    for (int z = t; z < nslab; z += 256) sv += sslab[z * Jp + j];
     sred[t] = sv;
   }
   __syncthreads();
@@ -219,8 +281,8 @@ __global__ __launch_bounds__(256) void tail_greduce_kernel(const float *gslab, c
 
 struct TailGradArgs {
   TailWeights w;
-  const float *Gc;  // [8][3136] canonical column order
-  const float *s;   // [8]
+  const float *Gc;  // [Jp][3136] canonical column order
+  const float *s;   // [Jp]
   float *dWfc, *dbfc, *dWp, *dbp, *dWv, *dbv;  // views of the flat gradient buffer (canonical layout)
   int nj;           // A + 1
 };
@@ -243,18 +305,19 @@ __global__ __launch_bounds__(256) void tail_grads_kernel(const TailGradArgs a) {
     return;
   }
   if (blk < kGradBlocksW + kNH) {
-    __shared__ float red[4][kJ];
+    __shared__ float red[4][kJMax];
     const int n = blk - kGradBlocksW;
-    float part[kJ];
+    float part[kJMax];
 #pragma unroll
-    for (int j = 0; j < kJ; ++j) part[j] = 0.f;
+    for (int j = 0; j < kJMax; ++j) part[j] = 0.f;
     for (int kc = t; kc < kK; kc += 256) {
       const float wfc = a.w.Wfc[static_cast<long long>(n) * kK + kc];
 #pragma unroll
-      for (int j = 0; j < kJ; ++j) part[j] = fmaf(a.Gc[j * kK + kc], wfc, part[j]);  // rows >= A + 1 of Gc are zero
+      for (int j = 0; j < kJMax; ++j)
+        if (j < a.nj) part[j] = fmaf(a.Gc[j * kK + kc], wfc, part[j]);  // (uniform)
     }
 #pragma unroll
-    for (int j = 0; j < kJ; ++j) {
+    for (int j = 0; j < kJMax; ++j) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) part[j] += __shfl_xor(part[j], o);
       if ((t & 63) == 0) red[t >> 6][j] = part[j];
@@ -278,7 +341,8 @@ __global__ __launch_bounds__(256) void tail_grads_kernel(const TailGradArgs a) {
 
 template <int NJ>
 int launch_tail_bwd_as(const TailBwdArgs &a, int nwg, hipStream_t stream) {
-  hipLaunchKernelGGL(tail_bwd_kernel<NJ>, dim3(nwg), dim3(kBwdThreads), 0, stream, a);
+  if constexpr (NJ <= 8) hipLaunchKernelGGL(tail_bwd_kernel<NJ>, dim3(nwg), dim3(kBwdThreads), 0, stream, a);
+  else hipLaunchKernelGGL(tail_bwd_wide_kernel<NJ>, dim3(nwg, 2), dim3(448), 0, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -290,24 +354,28 @@ TailWeights tail_weights(const float *params, const long long *off_w, const long
 
 }  // namespace
 
-bool tail_supported(int flat, int num_actions) { return flat == kK && num_actions + 1 <= kJ; }
+bool tail_supported(int flat, int num_actions) { return flat == kK && num_actions >= 1 && num_actions + 1 <= kMaxOutputs; }
+int tail_rows(int num_actions) { return 8 * cdiv(num_actions + 1, 8); }  // Jp: the outputs padded to groups of eight
 
 // floats of scratch: Wc product partials (inside `packed`), and G slabs + Gc + s (inside `slabs`)
-long long tail_pack_scratch_floats() { return static_cast<long long>(kChunks) * kJ * kK; }
+long long tail_pack_scratch_floats(int num_actions) { return static_cast<long long>(kChunks) * tail_rows(num_actions) * kK; }
 int tail_bwd_workgroups(int B) {
   const int nwg = cdiv(B, 8) < 256 ? cdiv(B, 8) : 256;  // >= 8 rows per workgroup, one workgroup per CU at most
   return cdiv(B, cdiv(B, nwg));
 }
-long long tail_slab_floats(int B) { return (static_cast<long long>(tail_bwd_workgroups(B)) + 2) * kJ * kK + 64; }
+long long tail_slab_floats(int B, int num_actions) {
+  return (static_cast<long long>(tail_bwd_workgroups(B)) + 2) * tail_rows(num_actions) * kK + 64;
+}
 
-// Wc [8][3136] (y2's column order), beff [8] from the canonical parameters; scratch: tail_pack_scratch_floats()
+// Wc [Jp][3136] (y2's column order), beff [Jp] from the canonical parameters; scratch: tail_pack_scratch_floats(A)
 int launch_tail_pack(const float *params, const long long *off_w, const long long *off_b, int A, float *Wc, float *beff,
                      float *scratch, float *Wcf, hipStream_t stream) {
-  DX_REQUIRE(params && Wc && beff && scratch && A >= 1 && A + 1 <= kJ, "tail_pack: bad arguments");
+  DX_REQUIRE(params && Wc && beff && scratch && A >= 1 && A + 1 <= kMaxOutputs, "tail_pack: bad arguments");
   const TailWeights w = tail_weights(params, off_w, off_b, A);
-  hipLaunchKernelGGL(tail_pack_partial_kernel, dim3(kP * kChunks), dim3(256), 0, stream, w, scratch);
+  const int Jp = tail_rows(A);
+  hipLaunchKernelGGL(tail_pack_partial_kernel, dim3(kP * kChunks, Jp / 8), dim3(256), 0, stream, w, scratch, Jp);
   DX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tail_pack_finish_kernel, dim3(cdiv(kJ * kK, 256) + 1), dim3(256), 0, stream, scratch, w, Wc, beff, Wcf);
+  hipLaunchKernelGGL(tail_pack_finish_kernel, dim3(cdiv(Jp * kK, 256) + 1), dim3(256), 0, stream, scratch, w, Wc, beff, Wcf, Jp);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -316,9 +384,9 @@ int launch_tail_pack(const float *params, const long long *off_w, const long lon
 // launch_tail_grads turns them into the linear layer's and the heads' gradients
 int launch_tail_bwd(const float *y2, const float *dhead, const float *Wc, float *dy2, float *scratch, int B, int A,
                     hipStream_t stream) {
-  DX_REQUIRE(y2 && dhead && Wc && dy2 && scratch && B >= 1 && A >= 1 && A + 1 <= kJ, "tail_bwd: bad arguments");
-  const int nwg = tail_bwd_workgroups(B);
-  const TailBwdArgs a{y2, dhead, Wc, dy2, scratch, scratch + static_cast<long long>(nwg) * kJ * kK, B, cdiv(B, nwg)};
+  DX_REQUIRE(y2 && dhead && Wc && dy2 && scratch && B >= 1 && A >= 1 && A + 1 <= kMaxOutputs, "tail_bwd: bad arguments");
+  const int nwg = tail_bwd_workgroups(B), Jp = tail_rows(A);
+  const TailBwdArgs a{y2, dhead, Wc, dy2, scratch, scratch + static_cast<long long>(nwg) * Jp * kK, B, cdiv(B, nwg), Jp};
   switch (A + 1) {
     case 2: return launch_tail_bwd_as<2>(a, nwg, stream);
     case 3: return launch_tail_bwd_as<3>(a, nwg, stream);
@@ -326,18 +394,29 @@ int launch_tail_bwd(const float *y2, const float *dhead, const float *Wc, float 
     case 5: return launch_tail_bwd_as<5>(a, nwg, stream);
     case 6: return launch_tail_bwd_as<6>(a, nwg, stream);
     case 7: return launch_tail_bwd_as<7>(a, nwg, stream);
-    default: return launch_tail_bwd_as<8>(a, nwg, stream);
+    case 8: return launch_tail_bwd_as<8>(a, nwg, stream);
+    case 9: return launch_tail_bwd_as<9>(a, nwg, stream);
+    case 10: return launch_tail_bwd_as<10>(a, nwg, stream);
+    case 11: return launch_tail_bwd_as<11>(a, nwg, stream);
+    case 12: return launch_tail_bwd_as<12>(a, nwg, stream);
+    case 13: return launch_tail_bwd_as<13>(a, nwg, stream);
+    case 14: return launch_tail_bwd_as<14>(a, nwg, stream);
+    case 15: return launch_tail_bwd_as<15>(a, nwg, stream);
+    case 16: return launch_tail_bwd_as<16>(a, nwg, stream);
+    case 17: return launch_tail_bwd_as<17>(a, nwg, stream);
+    case 18: return launch_tail_bwd_as<18>(a, nwg, stream);
+    default: return launch_tail_bwd_as<19>(a, nwg, stream);
   }
 }
 
 int launch_tail_grads(const float *params, float *grads, const long long *off_w, const long long *off_b, int A,
                       float *scratch, int B, hipStream_t stream) {
-  DX_REQUIRE(params && grads && scratch && B >= 1 && A >= 1 && A + 1 <= kJ, "tail_grads: bad arguments");
-  const int nwg = tail_bwd_workgroups(B);
-  const float *gslab = scratch, *sslab = scratch + static_cast<long long>(nwg) * kJ * kK;
-  float *Gc = scratch + (static_cast<long long>(nwg) + 1) * kJ * kK;
-  float *s = Gc + kJ * kK;
-  hipLaunchKernelGGL(tail_greduce_kernel, dim3(kP, kJ), dim3(256), 0, stream, gslab, sslab, nwg, A + 1, Gc, s);
+  DX_REQUIRE(params && grads && scratch && B >= 1 && A >= 1 && A + 1 <= kMaxOutputs, "tail_grads: bad arguments");
+  const int nwg = tail_bwd_workgroups(B), Jp = tail_rows(A);
+  const float *gslab = scratch, *sslab = scratch + static_cast<long long>(nwg) * Jp * kK;
+  float *Gc = scratch + (static_cast<long long>(nwg) + 1) * Jp * kK;
+  float *s = Gc + Jp * kK;
+  hipLaunchKernelGGL(tail_greduce_kernel, dim3(kP, Jp), dim3(256), 0, stream, gslab, sslab, nwg, A + 1, Jp, Gc, s);
   DX_LAUNCH_CHECK();
   const TailGradArgs a{tail_weights(params, off_w, off_b, A), Gc, s, grads + off_w[3], grads + off_b[3], grads + off_w[4],
                        grads + off_b[4], grads + off_w[5], grads + off_b[5], A + 1};

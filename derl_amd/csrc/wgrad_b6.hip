@@ -213,11 +213,7 @@ template <int L>
 int launch_b6(const WgradDirectArgs &a, int nwg, hipStream_t stream) {
   constexpr int lds = B6Layout<L>::END;
   auto kernel = conv_wgrad_b6_kernel<L>;
-  static bool configured = false;  // per instantiation
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
+  DX_LDS_OPT_IN(kernel, lds);
   hipLaunchKernelGGL(kernel, dim3(nwg), dim3(512), lds, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -227,12 +223,7 @@ int launch_b6(const WgradDirectArgs &a, int nwg, hipStream_t stream) {
 
 // DX_WGRAD_B6=0: the fp32-MFMA kernels of wgrad_direct.hip
 bool wgrad_b6_on() {
-  static int on = -1;
-  if (on < 0) {
-    const char *e = getenv("DX_WGRAD_B6");
-    on = e ? atoi(e) : 1;
-  }
-  return on != 0;
+  return DX_ENV("DX_WGRAD_B6", 1) != 0;
 }
 
 // conv1 (stage ST_CONV1_WGRAD) / conv2 weight gradient of an 84 x 84 observation's conv stack; nwg <= one per CU

@@ -259,12 +259,7 @@ int launch_as(const WgradDirectArgs &a, int nwg, hipStream_t stream) {
   constexpr int lds = WdLayout<IC, OC, IH, IW, OH, OW, NW>::END * 4;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kernel = conv_wgrad_direct_kernel<TAG, IC, OC, KH, KW, S, IH, IW, OH, OW, NW>;
-  static bool configured = false;  // per instantiation
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
+  DX_LDS_OPT_IN(kernel, lds);
   hipLaunchKernelGGL(kernel, dim3(nwg), dim3(64 * NW), lds, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;

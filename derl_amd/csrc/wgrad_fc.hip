@@ -199,12 +199,7 @@ int launch_fc_wgrad(const FcWgradArgs &a_in, hipStream_t stream) {
   a.diag = 0;
 #endif
   constexpr int lds = kStages * kStageFloats * 4;
-  static bool configured = false;
-  if (!configured) {
-    DX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fc_wgrad_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
+  DX_LDS_OPT_IN(fc_wgrad_kernel, lds);
   hipLaunchKernelGGL(fc_wgrad_kernel, dim3(a.gk * a.msplit), dim3(512), lds, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;

@@ -43,6 +43,10 @@ extern "C" {
 #define DX_ABI_VERSION 6
 
 int dx_abi_version(void);
+/* The DX_* environment switches ("Diagnostic switches") are parsed when a call first needs them and cached.
+ * dx_reload_env drops the cache: every switch is read again at its next use (a host that changes a switch at run time;
+ * the test suite, which walks the switch settings in one process). */
+int dx_reload_env(void);
 const char *dx_last_error(void);
 /* Kernels this library has launched in this process so far (every entry point counts its own
  * launches; RCCL's and the caller's are not included): measurement aid, e.g. launches per update. */
@@ -273,7 +277,8 @@ int dx_cnn_backward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
  * normalised here with {sum, sumsq, n} (derl/runners/trajectory_transforms.py:89-92), written to
  * adv_normalized_out if given.  `counter`: one word, zero before the first call (the launch leaves
  * it zero).  `partials`: >= 8 * ceil(B / 8) doubles covers every route (the factored tail asks for
- * 8 * min(ceil(B / 16), 256), the layer-by-layer heads for 8 * ceil(B / 64); less is DX_EINVAL).  DX_ENOSUP for more than 7 actions.
+ * 8 * min(ceil(B / 16), 256), the layer-by-layer heads for 8 * ceil(B / 64); less is DX_EINVAL).  DX_ENOSUP where
+ * dx_cnn_fused_heads(ctx) is 0 (more than 18 actions; more than 7 on the layer-by-layer route).
  *
  * Routes (same outputs and gradients, other association / arithmetic; csrc/cnn.hip):
  *  - 84 x 84 uint8 frames: the three conv layers of the whole minibatch are ONE launch of the image-resident
@@ -389,8 +394,13 @@ const char *dx_cnn_last_route(int stage);
  * Wc = Wh Wfc; dx_cnn_forward_trunk then ends at y2, dx_cnn_heads_loss_f32 reads y2, dx_cnn_backward_part
  * (2 / 3) forms dL/dWfc = Wh^T (dout^T y2), dL/dWh, dL/dbfc, dL/dbh and dL/dy2 = dout Wc, and
  * dx_cnn_act / dx_cnn_rollout_synth sample from y2 Wc^T -- the same outputs and gradients as the
- * layer-by-layer route to fp32 rounding.  84 x 84 frames, <= 7 actions; DX_FC_FACTORED=0 turns it off. */
+ * layer-by-layer route to fp32 rounding.  84 x 84 frames, <= 18 actions (the A + 1 outputs padded to 8, 16 or 24 rows);
+ * DX_FC_FACTORED=0 turns it off. */
 int dx_cnn_tail_factored(const dx_cnn_ctx *ctx);
+/* 1 when dx_cnn_forward_trunk + dx_cnn_heads_loss_f32 apply to this ctx: up to 18 actions (the full Atari action set,
+ * derl/env/make_env.py:94-106 builds heads of any width, derl/models.py:186-203) where the tail is factored, up to 7 on
+ * the layer-by-layer route; 0: dx_cnn_forward + dx_categorical_loss_f32 + dx_cnn_backward. */
+int dx_cnn_fused_heads(const dx_cnn_ctx *ctx);
 int dx_cnn_stage(const dx_cnn_ctx *ctx, int stage, const void *obs, int obs_is_u8,
                  const int32_t *sample_idx, int B, void *stream);
 

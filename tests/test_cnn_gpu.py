@@ -191,8 +191,35 @@ def test_loss_and_gradients_match_reference_golden(name, route):
 @pytest.mark.parametrize("route", ["layers", "update"])
 @pytest.mark.parametrize("batch", [1, 5, 37, 130, 1024, 1152, 2048, 2100, 2560, 8192])  # 8192 = BASELINE minibatch; 2560 = config 5's shard (K-split linear forward, uneven row groups per XCD)
 def test_backward_ragged_batches_with_gather(batch, route):
+  check_backward_against_float64(batch, route, 6)
+
+
+@pytest.mark.parametrize("A,batch", [(8, 37), (9, 130), (12, 1024), (18, 300), (18, 2048)])
+def test_wide_action_sets_stay_on_the_factored_tail(A, batch):
+  """derl builds heads of any width (derl/models.py:186-203) for any Atari id (derl/env/make_env.py:94-106: the full
+  action set has 18 actions).  Up to 18 actions the linear layer + heads stay ONE affine map of y2 (csrc/tail.hip: the
+  A + 1 outputs padded to 16 or 24 rows; tail_bwd's half-row workgroups from 9 outputs on; Wc rows beyond 12 read from L2
+  in the loss pass) and heads + loss + the heads' backward stay one launch: loss and every gradient against the float64
+  oracle on the engine's ReLU branch, and the routes the library reports."""
+  import ctypes
+  from derl_amd import _lib
+  eng = check_backward_against_float64(batch, "update", A)
+  lib = _lib.load()
+  assert lib.dx_cnn_tail_factored(ctypes.byref(eng.ctx)) == 1 and lib.dx_cnn_fused_heads(ctypes.byref(eng.ctx)) == 1
+  assert eng.fused_heads()
+  for stage in (3, 4, 5, 6, 7, 8):  # linear layer and heads: forward, weight and data gradients
+    assert lib.dx_cnn_last_route(stage).decode() == "tail_factored", (stage, lib.dx_cnn_last_route(stage))
+  obs = torch.from_numpy(gi.frames(64, 5)).to(DEV)
+  actions = torch.empty(64, dtype=torch.int64, device=DEV)
+  log_prob, values = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+  eng.act(obs, actions, log_prob, values)
+  assert lib.dx_cnn_last_route(3).decode() == "convstack (tail_factored)"  # the rollout's tail inside the conv-stack launch
+  wide = make_engine(19, gi.nature_cnn_weights(19, 3), max_batch=64)  # beyond 18 actions: layer by layer again
+  assert lib.dx_cnn_tail_factored(ctypes.byref(wide.ctx)) == 0 and not wide.fused_heads()
+
+
+def check_backward_against_float64(batch, route, A):
   rs = np.random.RandomState(batch)
-  A = 6
   weights = gi.nature_cnn_weights(A, 31)
   pool = gi.frames(batch + 7, 1000 + batch)
   idx = rs.permutation(batch + 7)[:batch].astype(np.int32)
@@ -223,6 +250,7 @@ def test_backward_ragged_batches_with_gather(batch, route):
   for k, og in ograds.items():
     scale = np.abs(og).max()
     nt.assert_allclose(grads[k].cpu().numpy(), og, rtol=1e-4, atol=1e-5 + 1e-5 * scale, err_msg=k)
+  return eng
 
 
 @pytest.mark.parametrize("route", ["layers", "update"])
@@ -591,31 +619,58 @@ def test_side_stream_routes_are_bit_identical_to_the_serial_ones():
   assert len(set(digests.values())) == 1, digests
 
 
-@pytest.mark.parametrize("switch", ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_TN_SWIZZLE=0", "DX_LAT_MAX_TILES=0", "DX_WGRAD_DIRECT=0",
-                                    "DX_WGRAD_DIRECT_MIN_B=1", "DX_NT_DMA=0", "DX_NTP=0",
-                                    "DX_FC_FACTORED=0",                           # linear layer + heads layer by layer in updates and rollouts
-                                    "DX_CONVSTACK=0", "DX_CONVSTACK=0 DX_FC_FACTORED=0 DX_FC_ROLLOUT=0",  # the rollout's layer-by-layer kernels
-                                    "DX_CONVSTACK_TRAIN=0 DX_WGRAD_B6=0 DX_DGRAD_B6=0",  # the update's fp32-MFMA conv stages
-                                    "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
-                                    "DX_BWD_OVERLAP=0 DX_C0_WAVES=4 DX_C0_GROUP4=0"])  # and their serial / round-2 twins
-def test_diagnostic_switches_keep_parity(switch):
-  """Every alternative kernel route behind an environment switch (diagnostic switches)
-  passes the same golden / oracle comparisons: the switches are read once per process, so a subset
-  of this file runs in a child process per setting."""
+SWITCH_SETTINGS = ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_TN_SWIZZLE=0", "DX_LAT_MAX_TILES=0", "DX_WGRAD_DIRECT=0",
+                   "DX_WGRAD_DIRECT_MIN_B=1", "DX_NT_DMA=0", "DX_NTP=0",
+                   "DX_FC_FACTORED=0",                           # linear layer + heads layer by layer in updates and rollouts
+                   "DX_CONVSTACK=0", "DX_CONVSTACK=0 DX_FC_FACTORED=0 DX_FC_ROLLOUT=0",  # the rollout's layer-by-layer kernels
+                   "DX_CONVSTACK_TRAIN=0 DX_WGRAD_B6=0 DX_DGRAD_B6=0",  # the update's fp32-MFMA conv stages
+                   "DX_CONVSTACK_TRAIN_ROLES=0",                 # the training forward's one-role-for-all flavour (convstack.hip)
+                   "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
+                   "DX_BWD_OVERLAP=0 DX_C0_WAVES=4 DX_C0_GROUP4=0"]  # and their serial / round-2 twins
+
+
+def test_diagnostic_switches_keep_parity():
+  """Every alternative kernel route behind an environment switch (diagnostic switches) passes the same
+  golden / oracle comparisons.  The library caches a switch at first use and dx_reload_env() drops the cache, so ONE
+  child process walks all settings (tests/switch_walk.py: environment edited, cache dropped, a subset of this file run
+  again); until round 5 each setting was its own process and the 14 of them took 230 s of the suite."""
   import subprocess
   import sys
-  env = dict(os.environ)
-  for item in switch.split():
-    key, val = item.split("=")
-    env[key] = val
-  here = os.path.abspath(__file__)
-  subset = ("test_forward_matches_reference_golden or test_loss_and_gradients_match_reference_golden or "
-            "(test_backward_ragged_batches_with_gather and (130 or 1024)) or test_fused_rollout_act_matches_unfused_path")
-  out = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-k", subset],
-                       env=env, capture_output=True, text=True, timeout=900,
-                       cwd=os.path.dirname(os.path.dirname(here)))
-  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
-  assert " passed" in out.stdout and "failed" not in out.stdout
+  here = os.path.dirname(os.path.abspath(__file__))
+  out = subprocess.run([sys.executable, os.path.join(here, "switch_walk.py")] + SWITCH_SETTINGS, capture_output=True, text=True,
+                       timeout=1500, cwd=os.path.dirname(here))
+  verdicts = [line for line in out.stdout.splitlines() if line.startswith("SWITCH ")]
+  assert out.returncode == 0 and len(verdicts) == len(SWITCH_SETTINGS) and all(v.endswith("-> 0") for v in verdicts), \
+      "\n".join(verdicts) + "\n" + out.stdout[-3000:] + out.stderr[-1500:]
+
+
+def test_switch_cache_is_dropped_by_dx_reload_env():
+  """The mechanism the walk rests on: a switch changed after its first use only takes effect behind dx_reload_env, and
+  the route the library reports follows it (dx_cnn_last_route)."""
+  from derl_amd import _lib
+  lib = _lib.load()
+  eng = make_engine(4, gi.nature_cnn_weights(4, 3), max_batch=64)
+  obs = torch.randint(0, 256, (64, 84, 84, 4), dtype=torch.uint8, device=DEV)
+  saved = os.environ.get("DX_CONVSTACK_TRAIN")
+  try:
+    os.environ.pop("DX_CONVSTACK_TRAIN", None)
+    assert lib.dx_reload_env() == 0
+    eng.forward_trunk(obs)
+    assert lib.dx_cnn_last_route(1).decode() == "convstack_train"
+    os.environ["DX_CONVSTACK_TRAIN"] = "0"
+    eng.forward_trunk(obs)
+    assert lib.dx_cnn_last_route(1).decode() == "convstack_train"  # cached: not read again
+    assert lib.dx_reload_env() == 0
+    eng.mark_dirty()
+    eng.forward_trunk(obs)
+    assert lib.dx_cnn_last_route(1).decode() != "convstack_train"
+  finally:
+    if saved is None:
+      os.environ.pop("DX_CONVSTACK_TRAIN", None)
+    else:
+      os.environ["DX_CONVSTACK_TRAIN"] = saved
+    lib.dx_reload_env()
+    eng.mark_dirty()
 
 
 def test_baseline_minibatches_take_the_fast_kernel_families():

@@ -514,6 +514,22 @@ def test_bench_line_contract():
   assert d["value"] > 10 * base["value"]  # BASELINE.json: >= 10x the reference CPU path
   assert d["gae_roofline"]["asymptote"]["frac"] > 0.55
 
+  def fractions(node, path=""):  # every key named `frac` anywhere in the line is a fraction OF A CEILING: never above 1
+    if isinstance(node, dict):
+      for key, val in node.items():
+        if key == "frac" and isinstance(val, (int, float)):
+          yield path + "/frac", val
+        else:
+          yield from fractions(val, path + "/" + str(key))
+    elif isinstance(node, list):
+      for i, val in enumerate(node):
+        yield from fractions(val, f"{path}[{i}]")
+
+  over = [(where, val) for where, val in fractions(d) if not 0.0 <= val <= 1.0]
+  assert not over, over
+  assert "action" in d["roofline"]["native_rollout"]["note"]  # the one-launch rollout states what it leans on
+  assert isinstance(d["roofline"]["power"], dict)  # read from profiles/ (or says that no probe is committed), never a literal
+
 
 def test_a2c_cnn_learns_image_bandit():
   """The A2C route (GAE with lambda 1, fused A2C loss, RMSprop with the annealed rate) as a learner

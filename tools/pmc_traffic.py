@@ -29,10 +29,17 @@ STAGE_OF = [  # substring of the kernel name -> stage
     ("tail_grads_kernel", "tail_grads"),
     # round 4: the update's conv stages on the bf16 matrix cores (convstack.hip `train`, wgrad_b6.hip, dgrad_b6.hip)
     ("convstack_image_kernel<true>", "conv_stack_fwd"), ("convstack_image_kernel<(bool)1>", "conv_stack_fwd"),
+    ("convstack_train_kernel", "conv_stack_fwd"),  # round 5: the role-specialised training forward (convstack_train.hip)
     ("conv_wgrad_b6_kernel<1>", "conv1_wgrad"), ("conv_wgrad_b6_kernel<2>", "conv2_wgrad"),
     ("conv_dgrad_b6_kernel<1>", "conv1_dgrad"), ("conv_dgrad_b6_kernel<2>", "conv2_dgrad"),
 ]
-ROLLOUT_STEP = "rollout_step (convstack, 256 images, one step)"
+ROLLOUT_STEP = "rollout_step (convstack_image_kernel<false>, 256 images, one step)"
+
+
+def is_rollout_kernel(name):
+  """The ROLLOUT flavour of the conv-stack kernel only (round 4's file took any `convstack_image` symbol, and the
+  training flavour -- launched by the same tool's warm-up -- won)."""
+  return "convstack_image_kernel<false>" in name or "convstack_image_kernel<(bool)0>" in name
 
 
 def mean_per_kernel(root, counter):
@@ -52,8 +59,8 @@ def main(fetch_dir, write_dir, out_path, commit=None, act_fetch_dir=None, act_wr
   write = mean_per_kernel(write_dir, "WRITE_SIZE")
   stages = {}
   if act_fetch_dir and act_write_dir:  # the passes over tools/act_bench.py 256 (the rollout's act step: the same kernel symbol)
-    af = {k: v for k, v in mean_per_kernel(act_fetch_dir, "FETCH_SIZE").items() if "convstack_image" in k}
-    aw = {k: v for k, v in mean_per_kernel(act_write_dir, "WRITE_SIZE").items() if "convstack_image" in k}
+    af = {k: v for k, v in mean_per_kernel(act_fetch_dir, "FETCH_SIZE").items() if is_rollout_kernel(k)}
+    aw = {k: v for k, v in mean_per_kernel(act_write_dir, "WRITE_SIZE").items() if is_rollout_kernel(k)}
     for kernel in af:
       raw, wr = af[kernel] * 1024, aw.get(kernel, 0.0) * 1024
       stages[ROLLOUT_STEP] = {"kernel": kernel, "FETCH_SIZE_bytes_raw": int(raw), "FETCH_SIZE_bytes_x2_gfx950": int(2 * raw),
