@@ -97,6 +97,12 @@ __device__ __forceinline__ u32x4 load_piece(const uint16_t *base, int elems, uns
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ReLU that keeps a NaN a NaN (`x > 0 ? x : 0` and v_max_f32 turn it into 0).  The exact split of an overflowed (Inf)
+// activation is (Inf, NaN, NaN) -- an fp32 chain would have kept Inf -- so the next layer's sums over it are NaN: they
+// must stay NaN down to the outputs instead of being zeroed one ReLU later (tests/test_cnn_gpu.py:
+// test_exact_split_keeps_extreme_magnitudes_and_never_hides_a_non_finite_value)
+__device__ __forceinline__ float relu_keep_nan(float x) { return x < 0.f ? 0.f : x; }
+
 // four activations (consecutive channels of one pixel) -> 8 bytes in each of the three bf16 planes
 __device__ __forceinline__ void store_planes4(uint8_t *smem, int off, int plane_bytes, f32x4 v) {
   const Split4 s = split4(v);
@@ -172,7 +178,7 @@ __device__ __forceinline__ void conv0_store(uint8_t *smem, int tile0, int lane, 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x = cs_div255(acc[t][4 * q + j]) + bias[q][j];
-        v[j] = x > 0.f ? x : 0.f;
+        v[j] = relu_keep_nan(x);
       }
       store_planes4(smem, oY0 + (p / 20) * kY0R + (p % 20) * kY0P + (8 * q + 4 * kg) * 2, kY0Plane, v);
       if (gy0) *reinterpret_cast<f32x4 *>(gy0 + p * 32 + 8 * q + 4 * kg) = v;  // (training: kept for the backward)
@@ -280,7 +286,7 @@ __device__ __forceinline__ f32x4 finish_tile(const float *red, int partner, int 
 #pragma unroll
     for (int t = 0; t < NT - KEEP; ++t) mine = t == m ? acc[KEEP + t][j] : mine;  // m is a constant after unrolling
     const float x = (mine + theirs[j]) + bias[j];
-    v[j] = x > 0.f ? x : 0.f;
+    v[j] = relu_keep_nan(x);
   }
   return v;
 }

@@ -191,7 +191,7 @@ __device__ __forceinline__ void finish_conv1(uint8_t *smem, f32x4 sum, f32x4 bia
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float x = sum[j] + bias[j];
-    v[j] = x > 0.f ? x : 0.f;
+    v[j] = relu_keep_nan(x);
   }
   if (p < kP1) {
     store_planes4(smem, oY1 + (p / 9) * kY1R + (p % 9) * kY1P + oc0 * 2, kY1Plane, v);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float x = acc2[m][j] + bias2[j];
-          v[j] = x > 0.f ? x : 0.f;
+          v[j] = relu_keep_nan(x);
         }
         if (p < kP2) *reinterpret_cast<f32x4 *>(out + p * 64 + oc0) = v;
       }

@@ -129,11 +129,21 @@ __device__ __forceinline__ void dg_units(const uint8_t *img, const int (&pb)[DgG
   constexpr DgUnits<L, KH2> units{};
   constexpr int S = units.s[I], T = units.t[I];
   u32x4 x2[3];
-  acc[T] = dg_mac_first(acc[T], w[S], x0);
-  __builtin_amdgcn_sched_barrier(0);
+  // one scheduling region per unit: its six MFMAs with the three fragment reads of the unit two ahead INTERLEAVED, one
+  // read behind each of the first three MFMAs (as a burst behind the first MFMA the reads held the wave's in-order stream
+  // while the LDS took them and no MFMA issued meanwhile: convstack_train.hip)
   if constexpr (I + 2 < units.n) dg_load<L, KH2, units.s[I + 2]>(img, pb[units.t[I + 2]], x2);
-  __builtin_amdgcn_sched_barrier(0);
+  acc[T] = dg_mac_first(acc[T], w[S], x0);
   acc[T] = dg_mac_rest(acc[T], w[S], x0);
+  if constexpr (I + 2 < units.n) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   if constexpr (I + 1 < units.n) dg_units<L, KH2, I + 1>(img, pb, w, acc, x1, x2);
 }
 

@@ -85,6 +85,8 @@ struct PersistArgs {
   float *moments;         // [G][2][kTotalA] every workgroup's own exp_avg / exp_avg_sq (aligned layout)
   double *lossp, *sumsqp;  // [G][40], [G]
   unsigned *counter, *timeout, *sticky;
+  unsigned *exits;         // workgroups that have left the launch: the last one out resets the barrier words
+  unsigned *status_host;   // the caller's pinned status word as the device sees it (or NULL: copied behind the launch)
   unsigned spin_limit;
   int G;
   unsigned long long *stamps;  // optional (DX_MLP_PERSIST_STAMPS=1): [G][5] 100 MHz ticks spent in A, barrier, B, barrier, C
@@ -249,7 +251,10 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
   // a workspace poisoned by an earlier give-up: nothing runs on it again.  (The word is only ever written at the
   // END of a launch; a workgroup that STARTS so late that the others have already given up on it and finished may
   // read their word and leave at once -- the launch has failed by then, and says so.)
-  if (__hip_atomic_load(a.sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  if (const unsigned poisoned = __hip_atomic_load(a.sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    if (t == 0 && a.status_host) __hip_atomic_store(a.status_host, poisoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   // ---- epoch start: the model into LDS, this thread's share of the Adam moments into registers ----
   for (int i = t; i < 2 * kNetLds + 32 + kR * kLd0 + 6 * kR * kLd1 + 3 * kR * kLd0; i += kT) Wl[i] = 0.f;
   if (t == 0) {
@@ -718,9 +723,23 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
     for (int i = 0; i < 5; ++i) a.stamps[wg * 5 + i] = tk[i];
   if (gave_up(a, dead)) {  // a barrier gave up: NaN losses, and the workspace is poisoned for good
     if (wg == G - 1 && t < 8 * a.nmb) a.loss_out[t] = __builtin_nanf("");
-    if (t == 0)
-      __hip_atomic_store(a.sticky, __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | 0x80000000u,
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) {  // (every workgroup that saw the give-up writes the same word: to the workspace and to the host's status word)
+      const unsigned word = __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | 0x80000000u;
+      __hip_atomic_store(a.sticky, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.status_host) __hip_atomic_store(a.status_host, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // The last workgroup out leaves the workspace ready for the next epoch's launch -- barrier counter and timeout word
+  // zero (the sticky word stays); together with the status word written straight to the host's pinned memory on the
+  // failure paths that is one memset launch and one 4-byte copy launch per epoch less (14 us of a 1.3 ms epoch, counting
+  // their boundaries).  Every workgroup has made its own gave_up() check above before it counts itself out; after a
+  // give-up a workgroup may never get here, the words stay as they are, and the sticky word keeps every later launch out.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0 && __hip_atomic_fetch_add(a.exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(G - 1)) {
+    __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.timeout, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.exits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -813,7 +832,14 @@ int launch_mlp_persist_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, int G, 
   char *ws = static_cast<char *>(e->workspace);
   a.counter = reinterpret_cast<unsigned *>(ws);
   a.timeout = a.counter + 4;
-  a.sticky = a.counter + 8;  // survives the per-launch reset below
+  a.sticky = a.counter + 8;  // survives the reset at the end of every launch
+  a.exits = a.counter + 12;
+  a.status_host = nullptr;
+  if (e->status_host) {  // a pinned word is mapped into the device's address space: the kernel stores to it directly
+    void *mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, e->status_host, 0) == hipSuccess) a.status_host = static_cast<unsigned *>(mapped);
+    else (void)hipGetLastError();
+  }
   a.spin_limit = kSpinLimit;
 #if DX_DIAG
   // (diag flavour: DX_MLP_PERSIST_SPIN_LIMIT=0 makes every workgroup that does not arrive last give
@@ -837,13 +863,14 @@ int launch_mlp_persist_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, int G, 
     if (int rc = dx_adv_stats_segments_f32(e->advantages, nullptr, e->samples, e->mbsize, e->stats_all, stream)) return rc;
     a.stats = e->stats_all;
   }
-  DX_HIP(hipMemsetAsync(ws, 0, 32, stream));  // barrier counter and timeout word (NOT the sticky word)
+  // (no memset: the workspace starts zeroed -- include/derl_amd.h -- and the last workgroup of every launch zeroes the
+  // barrier counter and the timeout word again)
   const size_t lds = persist_lds_bytes();
   if (int rc = configure_persist_kernel()) return rc;
   hipLaunchKernelGGL(mlp_persist_kernel, dim3(G), dim3(kT), lds, stream, a);
   DX_LAUNCH_CHECK();
   mlp_note_route(1);
-  if (e->status_host)  // the sticky word follows the launch into the caller's pinned status word
+  if (e->status_host && a.status_host == nullptr)  // (not mapped: the sticky word follows the launch by a copy)
     DX_HIP(hipMemcpyAsync(e->status_host, a.sticky, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
   if (want_stamps) {  // measurement aid (synchronous): where an epoch's time goes, per update
     DX_HIP(hipStreamSynchronize(stream));

@@ -491,7 +491,8 @@ typedef struct dx_mlp_epoch {
   int grad_norm_stride;        /* 0: grad_norm_out[0] = the last minibatch's; 1: one each */
   int persistent;              /* 1: ONE persistent launch for the whole epoch where
                                   dx_mlp_persist_plan covers the shape (see below)        */
-  void *workspace;             /* persistent epoch: workspace_bytes from dx_mlp_persist_plan */
+  void *workspace;             /* persistent epoch: workspace_bytes from dx_mlp_persist_plan, ZERO before the first
+                                  call (every launch leaves its barrier words zero again)   */
   long long workspace_bytes;
   double *stats_all;           /* persistent epoch with normalize: (minibatches, 3) scratch */
   unsigned *status_host;       /* persistent epoch: ONE pinned host word, zero before the first call,

@@ -51,8 +51,11 @@ def make_alg(kind, native, nenvs, horizon, epochs, nmb):
     env = derl.env.make("HalfCheetah-v3", nenvs=nenvs, seed=3)
   elif kind == "cnn":
     env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=nenvs, seed=3)
-  elif kind == "cnn18":  # 18 actions: wider than the fused heads + loss launch covers (A + 1 <= 8)
+  elif kind == "cnn18":  # 18 actions: the full Atari set, still on the factored tail
     env = derl.env.make("SeaquestNoFrameskip-v4", nenvs=nenvs, seed=3)
+  elif kind == "cnn20":  # beyond it: linear layer and heads layer by layer, the loss as its own launch
+    from derl_amd.env.synthetic import SyntheticAtariEnv
+    env = SyntheticAtariEnv(nenvs, 20, 3)
   else:
     env = DeviceVectorEnv(nenvs, 11, 5, seed=3)
   kwargs = derl.PPOFactory.get_kwargs("atari" if kind.startswith("cnn") else "mujoco")
@@ -97,7 +100,7 @@ def run(kind, native, nenvs, horizon, epochs, nmb, rollouts, keep_host=False):
 
 
 # 33 envs x 16 steps = 528 samples in 5 minibatches of 105 + a ragged sixth of 3
-@pytest.mark.parametrize("kind", ["gaussian", "categorical", "cnn", "cnn18"])
+@pytest.mark.parametrize("kind", ["gaussian", "categorical", "cnn", "cnn18", "cnn20"])
 def test_native_epoch_equals_per_update_path_and_oracle(kind):
   nenvs, horizon, epochs, nmb, rollouts = 33, 16, 2, 5, 2
   fast = run(kind, True, nenvs, horizon, epochs, nmb, rollouts, keep_host=True)
@@ -114,8 +117,8 @@ def test_native_epoch_equals_per_update_path_and_oracle(kind):
   assert torch.equal(fast["params"], slow["params"])
   assert torch.equal(fast["m"], slow["m"]) and torch.equal(fast["v"], slow["v"])
   if kind.startswith("cnn"):  # the conv path's oracle parity: the golden Trainer.step tests (same native call)
-    if kind == "cnn18":
-      assert not fast["alg"].model.engine.fused_heads()  # forward + separate loss launch + whole backward
+    # up to 18 actions: heads + loss + the heads' backward in one launch; 20: forward + separate loss launch + whole backward
+    assert fast["alg"].model.engine.fused_heads() == (kind != "cnn20")
     return
   # the oracle on the first epoch's minibatches (incl. the ragged one), from the same start
   alg = fast["alg"]

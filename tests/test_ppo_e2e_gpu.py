@@ -590,11 +590,14 @@ def test_inplace_writes_through_parameters_refresh_packed_weights(kind):
   check("in-place op on one parameter")
 
 
-def test_two_lane_native_rollout_matches_per_step_loop():
-  """From 128 envs on, dx_cnn_rollout_synth runs the two halves of the envs as two chains on two
-  streams.  Against the Python per-step loop (whole batch per launch): observations, rewards and
-  resets bit-identical, samples from the same stream positions (a logit that differs in the last
-  bit may flip a sample on a CDF boundary), log-probs and values to float32 rounding."""
+@pytest.mark.parametrize("horizon,rollouts", [(5, 2), (128, 1)])  # 128 x 256 = the BASELINE rollout, as bench.py runs it
+def test_one_launch_native_rollout_matches_per_step_loop(horizon, rollouts):
+  """dx_cnn_rollout_synth against the synthetic device env is ONE persistent launch of the conv-stack kernel (csrc/
+  convstack.hip: one workgroup per env walks all `horizon` steps -- frame -> conv stack -> y2 Wc^T -> sample -> next
+  frame never leaves the workgroup).  Against the Python per-step loop (one dx_cnn_act + one env launch per step, whole
+  batch): observations, rewards and resets bit-identical at every step of every env, samples from the same stream
+  positions (a logit that differs in the last bit may flip a sample on a CDF boundary), log-probs and values to float32
+  rounding.  The 128-step case is the launch the benchmark times."""
   import derl_amd as derl
   from derl_amd.policies import ActorCriticPolicy
 
@@ -605,15 +608,16 @@ def test_two_lane_native_rollout_matches_per_step_loop():
     if not use_fused:
       policy.rollout_into = lambda *a, **k: False
     env = derl.env.make("BreakoutNoFrameskip-v4", nenvs=256, seed=2)
-    runner = derl.EnvRunner(env, policy, horizon=5, nsteps=256 * 5 * 2)
+    runner = derl.EnvRunner(env, policy, horizon=horizon, nsteps=256 * horizon * rollouts)
     outs = []
     for inter in runner.run():
       outs.append({k: v.clone() for k, v in inter.items() if isinstance(v, torch.Tensor)})
     return outs
 
   a, b = rollout(True), rollout(False)
-  assert len(a) == len(b) == 2
+  assert len(a) == len(b) == rollouts
   for x, y in zip(a, b):
+    assert x["observations"].shape[0] == horizon
     for k in ("observations", "rewards", "resets"):
       assert torch.equal(x[k], y[k]), k
     same = x["actions"] == y["actions"]
