@@ -43,20 +43,21 @@
 #include <cstdlib>
 #include <vector>
 
-#include "convstack_dev.hpp"
+#include "convstack_roles.hpp"
 
 namespace dx {
 namespace {
 
 // The sample of step t from the eight waves' partial outputs (one wave; heads.hip: tail_act_block's rule):
 // out[j] = the waves' sums in wave order + beff[j]; softmax over the A logits, inverse-CDF draw, log-prob, value.
+template <int NW = 8>
 __device__ __forceinline__ void sample_step(const ConvStackArgs &a, const float *tailred, int t, int e, int lane) {
   const int A = a.A, col = lane & 31;
   const float *part = tailred + (t & 1) * (8 * kTailOut);
   float x = 0.f;
   if (lane <= A) {  // output `lane`: the waves' sums in wave order + beff
 #pragma unroll
-    for (int w = 0; w < 8; ++w) x += part[w * kTailOut + lane];
+    for (int w = 0; w < NW; ++w) x += part[w * kTailOut + lane];
     x += a.beff[lane];
   }
   float mx = -INFINITY;
@@ -368,6 +369,304 @@ __global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArg
   }
 }
 
+// The rollout step / act with the waves SPECIALISED as in convstack_train.hip (read its header first) and the steps of
+// the horizon pipelined: waves 0-3 (B) run conv1 (tiles 0-3) and conv2 of step t over the whole contraction -- no K-half
+// exchange -- one conv0 tile of step t + 1, and the policy's tail (y2 Wc^T: four waves' partial sums instead of eight);
+// waves 4-7 (A) run conv1's tiles 4-5, generate the synthetic env's next frame (a hash: all vector ALU, done while the
+// B waves still multiply), conv0 of step t + 1 under B's conv2, and the sample of step t - 1.  Same LDS map, four
+// barriers per step (alpha .. delta).  T = 1 without env: one act step (dx_cnn_act), the A waves then only help with conv1.
+// The next frame does not wait for this step's action: the measurement env ignores it -- with an
+// action-dependent device env the step would serialise sample -> frame -> conv0.
+__global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool roleB = wave < 4;
+  const int e = blockIdx.x;  // the env
+  const int T = a.T;
+  const bool env = a.env != 0;
+  const long long step_bytes = static_cast<long long>(a.row_stride) * kFrameB;  // frames of one step of the whole batch
+  unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int stamp_wave = kDiag ? (a.env0 >> 24) & 7 : 0;
+  const int stamp_step = kDiag ? a.stamp_step : 0;
+  int t = 0;
+#define DX_CS_MARK(i) if (kDiag && a.stamps && t == stamp_step) tk[i] = __builtin_amdgcn_s_memtime();
+  if (kDiag && a.stamps) { tk[14] = __builtin_amdgcn_s_memrealtime(); tk[15] = __builtin_amdgcn_s_memtime(); }
+
+  // ---- step 0's frame and conv0's weight planes (resident for the whole launch): all eight waves ----
+  {
+    const uint8_t *src = a.obs + static_cast<long long>(e) * kFrameB;
+    u32x4 fr[4];  // the frame: 1,764 pieces of 16 bytes
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const u32x4 *>(src + 16 * min(tid + 512 * u, kFrameB / 16 - 1));
+    u32x4 wv[6];  // conv0's planes: 3 x 32 rows x 32 pieces
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = u * 512 + tid;
+      wv[u] = *reinterpret_cast<const u32x4 *>(a.Wb0 + (i >> 10) * 8192 + ((i >> 5) & 31) * 256 + (i & 31) * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (tid + 512 * u < kFrameB / 16) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * (tid + 512 * u)) = fr[u];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = u * 512 + tid;
+      *reinterpret_cast<u32x4 *>(smem + oW0 + (i >> 10) * kWPlaneB + ((i >> 5) & 31) * kWRowB + (i & 31) * 16) = wv[u];
+    }
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const unsigned lane16 = static_cast<unsigned>(lane * 16);
+  float *tailred = reinterpret_cast<float *>(smem + oTail);  // [step parity][8 waves][kTailOut outputs] (waves 0-3 write)
+  auto load_bias0 = [&](f32x4 (&bias0)[4], int l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (l >> 5));
+  };
+  // 16-byte unit `unit` of the synthetic env's frame after step t (synth_atari_block's hash of (seed, counter, position))
+  auto frame_unit = [&](int t_, int unit) {
+    const uint64_t key = synth_mix64(a.env_seed * 0x9E3779B97F4A7C15ull + (a.env_counter + t_));
+    const uint64_t p = static_cast<uint64_t>(a.env0 + e) * (kFrameB / 16) + unit;
+    const uint64_t x = synth_mix64(key + 2 * p * 0x9E3779B97F4A7C15ull);
+    const uint64_t y = synth_mix64(key + (2 * p + 1) * 0x9E3779B97F4A7C15ull);
+    return u32x4{static_cast<uint32_t>(x), static_cast<uint32_t>(x >> 32), static_cast<uint32_t>(y), static_cast<uint32_t>(y >> 32)};
+  };
+  // ... into the rollout buffer, and (when a step follows) into the LDS slot its conv0 reads
+  auto put_unit = [&](int t_, int unit, u32x4 v, bool to_lds) {
+    if (unit < kFrameB / 16) {
+      *reinterpret_cast<u32x4 *>(a.obs + (t_ + 1) * step_bytes + static_cast<long long>(e) * kFrameB + 16 * unit) = v;
+      if (to_lds) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * unit) = v;
+    }
+  };
+
+  if (roleB) {
+    // ============ B: conv1 (tiles 0-3), conv2, the tail of step t; conv0's tile nt of step t + 1 ============
+    const int nt = wave;
+    const int kq = lane >> 4, oc0 = 16 * nt + 4 * kq;
+    const uint16_t *w1h0 = a.Wf1 + nt * (8 * 3 * 512), *w1h1 = a.Wf1 + (nt + 4) * (8 * 3 * 512);
+    const uint16_t *w2h0 = a.Wf2 + nt * (9 * 3 * 512), *w2h1 = a.Wf2 + (nt + 4) * (9 * 3 * 512);
+    u32x4 R[9][3];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) R[s][pl] = load_piece(w1h0, (s * 3 + pl) * 512, lane16);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) R[8][pl] = R[7][pl];
+    const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);
+    const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
+    const int Jp = (a.A + 8) & ~7;
+    lds_barrier();  // p1: frame 0 and conv0's planes are in LDS
+    {
+      f32x16 accb[1];
+      conv0_mfma<1, 4, 1>(smem, nt, lane, accb);
+      lds_barrier();  // p2: every wave has read the frame
+      f32x4 bias0[4];
+      load_bias0(bias0, lane);
+      conv0_store<1, 4, 1>(smem, nt, lane, accb, bias0, nullptr);
+    }
+    for (t = 0; t < T; ++t) {
+      const bool next0 = env && t + 1 < T;  // (uniform) another step follows: its conv0 runs under this step's conv2
+      DX_CS_MARK(7)
+      lds_barrier();  // alpha: y0 of this step is complete
+      DX_CS_MARK(0)
+      int pb1[4];
+      {
+        const int l1 = opaque(lane), m16 = l1 & 15, k4 = l1 >> 4;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int p = min(16 * mt + m16, kP1 - 1), oy = p / 9, ox = p - 9 * oy;
+          pb1[mt] = oY0 + 2 * oy * kY0R + 2 * ox * kY0P + 16 * k4;
+        }
+      }
+      f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+      conv_run<0, 1, 4, 8, 9>(smem, pb1, R, acc, w1h1, w2h0, lane16);
+      u32x4 fr[3];  // pieces 16 + nt + 4 u of the env's next frame (the A waves make pieces 0 .. 15)
+      if (env) {
+        const int lf = opaque(lane);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) fr[u] = frame_unit(t, (16 + nt + 4 * u) * 64 + lf);
+      }
+      DX_CS_MARK(1)
+      lds_barrier();  // beta: every wave has read y0 -- the y1 planes may overwrite its start, the next frame its end
+      DX_CS_MARK(2)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) finish_conv1(smem, acc[m], bias1, 16 * m + (opaque(lane) & 15), oc0, nullptr);
+      if (env) {
+        const int lf = opaque(lane);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) put_unit(t, (16 + nt + 4 * u) * 64 + lf, fr[u], next0);
+      }
+      DX_CS_MARK(3)
+      lds_barrier();  // gamma: y1 and the next frame are complete
+      DX_CS_MARK(4)
+      int pb2[4];
+      {
+        const int l2 = opaque(lane), m16 = l2 & 15, k4 = l2 >> 4;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int p = min(16 * mt + m16, kP2 - 1), oy = p / 7, ox = p - 7 * oy;
+          pb2[mt] = oY1 + oy * kY1R + ox * kY1P + 16 * k4;
+        }
+      }
+      f32x4 acc2[4] = {zero4, zero4, zero4, zero4};
+      conv_run<0, 2, 4, 9, 8>(smem, pb2, R, acc2, w2h1, w1h0, lane16);
+      f32x16 accb[1];
+      if (next0) conv0_mfma_pipelined<1, 1>(smem, nt, opaque(lane), accb);
+      DX_CS_MARK(5)
+      lds_barrier();  // delta: every wave has read y1 and the frame -- the y0 planes may overwrite both
+      DX_CS_MARK(6)
+      const int l3 = opaque(lane), n16 = l3 & 15;
+      f32x4 v2[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v2[m][j] = relu_keep_nan(acc2[m][j] + bias2[j]);
+        if (a.y2 && 16 * m + n16 < kP2)
+          *reinterpret_cast<f32x4 *>(a.y2 + static_cast<long long>(e) * (kP2 * 64) + (16 * m + n16) * 64 + oc0) = v2[m];
+      }
+      if (a.Wc) {
+        // ---- the policy's tail: out[j] = sum over (pixel, channel) of y2 Wc[j] + beff[j].  Fragment order of the copy:
+        // [wave' = nt + 4 (tile / 2)][tile % 2][row j of Jp][lane][4] (launch_tail_pack) ----
+        const unsigned ow = static_cast<unsigned>(l3 * 16);
+        float mine = 0.f;
+        for (int grp = 0; 4 * grp <= a.A; ++grp) {  // groups of four outputs (uniform trip count)
+          f32x4 wc[4][4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              wc[j][m] = 4 * grp + j <= a.A
+                             ? __builtin_bit_cast(f32x4, load16(a.Wc + (((nt + 4 * (m >> 1)) * 2 + (m & 1)) * Jp + 4 * grp + j) * 256, ow))
+                             : zero4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (4 * grp + j > a.A) continue;  // uniform
+            float part = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              float d = v2[m][0] * wc[j][m][0];
+              d = __builtin_fmaf(v2[m][1], wc[j][m][1], d);
+              d = __builtin_fmaf(v2[m][2], wc[j][m][2], d);
+              d = __builtin_fmaf(v2[m][3], wc[j][m][3], d);
+              part += 16 * m + n16 < kP2 ? d : 0.f;
+            }
+            const float tot = wave_sum_all(part);
+            mine = l3 == 4 * grp + j ? tot : mine;
+          }
+        }
+        if (l3 <= a.A) tailred[(t & 1) * (8 * kTailOut) + nt * kTailOut + l3] = mine;  // sampled by wave 7 behind the next alpha
+      }
+      if (next0) {
+        f32x4 bias0[4];
+        load_bias0(bias0, l3);
+        conv0_store<1, 4, 1>(smem, nt, l3, accb, bias0, nullptr);
+      }
+    }
+  } else {
+    // ============ A: conv1's tiles 4-5 of step t; the env's next frame; conv0 of step t + 1; the sample of step t - 1 ============
+    const int aw = wave - 4;
+    const int kq = lane >> 4, oc0 = 16 * aw + 4 * kq;
+    const uint16_t *w1h0 = a.Wf1 + aw * (8 * 3 * 512), *w1h1 = a.Wf1 + (aw + 4) * (8 * 3 * 512);
+    u32x4 R[9][3];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) R[s][pl] = load_piece(w1h0, (s * 3 + pl) * 512, lane16);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) R[8][pl] = R[7][pl];
+    const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);
+    lds_barrier();  // p1
+    {
+      f32x16 acc0[3];
+      if (aw == 0) conv0_mfma<3, 4, 3>(smem, 4 + aw, lane, acc0);
+      else conv0_mfma<2, 4, 3>(smem, 4 + aw, lane, acc0);
+      lds_barrier();  // p2
+      f32x4 bias0[4];
+      load_bias0(bias0, lane);
+      if (aw == 0) conv0_store<3, 4, 3>(smem, 4 + aw, lane, acc0, bias0, nullptr);
+      else conv0_store<2, 4, 3>(smem, 4 + aw, lane, acc0, bias0, nullptr);
+    }
+    for (t = 0; t < T; ++t) {
+      const bool next0 = env && t + 1 < T;
+      f32x16 acc0[3];
+      DX_CS_MARK(7)
+      lds_barrier();  // alpha
+      DX_CS_MARK(0)
+      if (a.Wc && t > 0 && aw == 3) sample_step<4>(a, tailred, t - 1, e, opaque(lane));  // (its partial sums were complete before alpha)
+      int pb1[2];
+      {
+        const int l1 = opaque(lane), m16 = l1 & 15, k4 = l1 >> 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int p = min(16 * (4 + mt) + m16, kP1 - 1), oy = p / 9, ox = p - 9 * oy;
+          pb1[mt] = oY0 + 2 * oy * kY0R + 2 * ox * kY0P + 16 * k4;
+        }
+      }
+      f32x4 acc[2] = {zero4, zero4};
+      conv_run<0, 1, 2, 8, 0, 1>(smem, pb1, R, acc, w1h1, w1h0, lane16);
+      // The synthetic env's NEXT frame of this env: this wave's four KB of it, in registers until beta frees the LDS slot
+      u32x4 fr[4];  // pieces aw + 4 u (the B waves make pieces 16 .. 27 behind their four conv1 tiles)
+      if (env) {
+        const uint64_t key = synth_mix64(a.env_seed * 0x9E3779B97F4A7C15ull + (a.env_counter + t));
+        const int lf = opaque(lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fr[u] = frame_unit(t, (aw + 4 * u) * 64 + lf);
+        if (tid == 256) {
+          const uint64_t r = synth_mix64(~key + static_cast<uint64_t>(a.env0 + e) * 0xD1B54A32D192ED03ull);
+          const float u0 = static_cast<float>(r & 0xffffff) * (1.0f / 16777216.0f);
+          const float u1 = static_cast<float>((r >> 24) & 0xffffff) * (1.0f / 16777216.0f);
+          const long long row = static_cast<long long>(t) * a.row_stride + e;
+          if (a.rewards) a.rewards[row] = u0 < a.p_reward ? ((r >> 63) ? -1.f : 1.f) : 0.f;
+          if (a.resets) a.resets[row] = u1 < a.p_reset ? 1 : 0;
+        }
+      }
+      DX_CS_MARK(1)
+      lds_barrier();  // beta
+      DX_CS_MARK(2)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) finish_conv1(smem, acc[m], bias1, 16 * (4 + m) + (opaque(lane) & 15), oc0, nullptr);
+      if (env) {
+        const int lf = opaque(lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) put_unit(t, (aw + 4 * u) * 64 + lf, fr[u], next0);
+      }
+      DX_CS_MARK(3)
+      lds_barrier();  // gamma
+      DX_CS_MARK(4)
+      if (next0) {
+        const int l0 = opaque(lane);
+        if (aw == 0) conv0_mfma_pipelined<3, 3>(smem, 4 + aw, l0, acc0);
+        else conv0_mfma_pipelined<2, 3>(smem, 4 + aw, l0, acc0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)  // the next step's conv1 taps 0-7: under the epilogue
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) R[s][pl] = load_piece(w1h0, (s * 3 + pl) * 512, lane16);
+      }
+      DX_CS_MARK(5)
+      lds_barrier();  // delta
+      DX_CS_MARK(6)
+      if (next0) {
+        const int l0 = opaque(lane);
+        f32x4 bias0[4];
+        load_bias0(bias0, l0);
+        if (aw == 0) conv0_store<3, 4, 3>(smem, 4 + aw, l0, acc0, bias0, nullptr);
+        else conv0_store<2, 4, 3>(smem, 4 + aw, l0, acc0, bias0, nullptr);
+      }
+    }
+  }
+  if (a.Wc) {  // the last step's sample
+    lds_barrier();
+    if (wave == 7) sample_step<4>(a, tailred, T - 1, e, lane);
+  }
+#undef DX_CS_MARK
+  if (kDiag && a.stamps && tid == 64 * stamp_wave) {
+    tk[8] = __builtin_amdgcn_s_memtime();
+    tk[13] = __builtin_amdgcn_s_memrealtime();
+    tk[15] = tk[8] - tk[15];
+    tk[14] = tk[13] - tk[14];
+    for (int i = 0; i < 16; ++i) a.stamps[blockIdx.x * 16 + i] = tk[i];
+  }
+}
+
 // conv1 / conv2's bf16 planes and the tail's Wc in the order the kernel's waves read them: one thread per
 // 16-byte piece.  Wave (nt = wave & 3: 16 output channels, kh2 = wave >> 2: K half); lane (n16 = row of the
 // tile, kq = k group): the A fragment of v_mfma_f32_16x16x32_bf16 at K step s is 8 consecutive k of row n16.
@@ -445,6 +744,50 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
   // (default: the role-specialised kernel of convstack_train.hip; DX_CONVSTACK_TRAIN_ROLES=0: this file's one-role-for-all flavour)
   const bool roles = DX_ENV("DX_CONVSTACK_TRAIN_ROLES", 1) != 0;
   if (a.train && roles) return launch_convstack_train(a, B, stream);
+  // the rollout step / act: the role-specialised kernel too (DX_CONVSTACK_ROLES=0: the one-role-for-all flavour below)
+  if (!a.train && DX_ENV("DX_CONVSTACK_ROLES", 1) != 0) {
+    DX_LDS_OPT_IN(convstack_roll_kernel, kLdsBytes);
+#if DX_DIAG
+    if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one step (DX_CS_STEP) as seen by wave DX_CS_DIAG, on stderr (synchronous)
+      unsigned long long *dev_stamps = nullptr;
+      DX_HIP(hipMalloc(&dev_stamps, static_cast<size_t>(B) * 128));
+      a.stamps = dev_stamps;
+      const int stamp_wave = atoi(getenv("DX_CS_DIAG")) & 7;
+      a.env0 |= stamp_wave << 24;  // (timing build only: sampling positions are not what is looked at)
+      a.stamp_step = getenv("DX_CS_STEP") ? atoi(getenv("DX_CS_STEP")) : 0;
+      if (a.stamp_step >= a.T) a.stamp_step = a.T - 1;
+      hipLaunchKernelGGL(convstack_roll_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
+      DX_LAUNCH_CHECK();
+      DX_HIP(hipStreamSynchronize(stream));
+      std::vector<unsigned long long> h(static_cast<size_t>(B) * 16);
+      DX_HIP(hipMemcpy(h.data(), dev_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+      DX_HIP(hipFree(dev_stamps));
+      static const int order[8] = {7, 0, 1, 2, 3, 4, 5, 6};
+      const bool b = stamp_wave < 4;
+      const char *what[7] = {"wait at alpha (y0 complete)", b ? "conv1 loop, tiles 0-3" : "sample (wave 7), conv1 tiles 4-5, next frame's hash",
+                             "wait at beta (y0 read by all)", b ? "bias / ReLU / split -> y1" : "y1 of tiles 4-5, next frame -> LDS + rollout buffer",
+                             "wait at gamma (y1 and frame complete)", b ? "conv2 loop + one conv0 tile" : "conv0 tiles of the next step",
+                             "wait at delta (y1 and frame dead)"};
+      double total = 0;
+      fprintf(stderr, "[convstack_roll B=%d T=%d step %d wave %d] cycles per workgroup (mean):\n", B, a.T, a.stamp_step, stamp_wave);
+      for (int i = 0; i < 7; ++i) {
+        double d = 0;
+        for (int k = 0; k < B; ++k) d += static_cast<double>(h[k * 16 + order[i + 1]] - h[k * 16 + order[i]]) / B;
+        total += d;
+        fprintf(stderr, "  %-58s %8.0f\n", what[i], d);
+      }
+      fprintf(stderr, "  %-58s %8.0f\n", "total (alpha wait .. delta passed; the tail / epilogue follow)", total);
+      double cyc = 0, ticks = 0;
+      for (int k = 0; k < B; ++k) { cyc += static_cast<double>(h[k * 16 + 15]); ticks += static_cast<double>(h[k * 16 + 14]); }
+      fprintf(stderr, "  whole launch: %.0f cycles per workgroup (%.0f per step) in %.2f us: shader clock %.0f MHz\n", cyc / B, cyc / B / a.T,
+              ticks / B / 100.0, cyc / ticks * 100.0);
+      return DX_OK;
+    }
+#endif
+    hipLaunchKernelGGL(convstack_roll_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
+    DX_LAUNCH_CHECK();
+    return DX_OK;
+  }
 #if DX_DIAG
   if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one step (DX_CS_STEP, default 0) of wave DX_CS_DIAG, on stderr (synchronous)
     unsigned long long *dev_stamps = nullptr;
