@@ -1,39 +1,26 @@
-// The rollout's conv stack as ONE launch with ONE workgroup per image: conv(4->32, k8, s4) + ReLU ->
-// conv(32->64, k4, s2) + ReLU -> conv(64->64, k3, s1) + ReLU of derl/models.py:104-111 (the batched
-// Policy.act forward of derl/policies.py:61-80), for 84 x 84 x 4 uint8 frames.
+// The rollout's conv stack -- and, with the policy's tail inside, the whole act step, or T steps against the synthetic
+// device env -- as ONE launch with ONE workgroup per env: conv(4->32, k8, s4) + ReLU -> conv(32->64, k4, s2) + ReLU ->
+// conv(64->64, k3, s1) + ReLU of derl/models.py:104-111 (the batched Policy.act forward of derl/policies.py:61-80, inside
+// derl/runners/env_runner.py:41-69's loop), for 84 x 84 x 4 uint8 frames.
 //
-// Why: at rollout sizes (128-256 images) the layer-by-layer kernels (igemm_lat.hip: one 32x32 tile per
-// workgroup) stream every operand of every tile through L2 -- 128 KB for 0.5 MMAC -- and ran at
-// 0.21-0.29 of the fp32-MFMA peak, three dependent launches per step.  The whole conv stack of an image
-// is image-local, and 256 images are 256 CUs: here a workgroup keeps ITS image's frame, y0 (20 x 20 x
-// 32) and y1 (9 x 9 x 64) in LDS, never writes them to memory, and only y2 (7 x 7 x 64) leaves the CU.
+// Why: at rollout sizes (32-256 images) the layer-by-layer kernels (igemm_lat.hip: one 32x32 tile per workgroup) stream
+// every operand of every tile through L2 and ran at 0.21-0.29 of the fp32-MFMA peak, three dependent launches per step.
+// The whole conv stack of an image is image-local, and 256 envs are 256 CUs: a workgroup keeps ITS env's frame, y0
+// (20 x 20 x 32) and y1 (9 x 9 x 64) in LDS as exact three-term bf16 planes, never writes them to memory, and the step's
+// chain frame -> conv stack -> y2 Wc^T -> sample -> next frame never leaves the CU.
 //
-// ALL THREE layers run on the bf16 matrix cores at fp32 accuracy:
-//   * conv0 as in conv0_b16.hip: a uint8 pixel is exact in bf16, the fp32 weight splits EXACTLY into
-//     three bf16 terms (hi + mid + lo, pre-split by dx_cnn_pack), every product is exact in fp32,
-//     v_mfma_f32_32x32x16_bf16 accumulates in fp32; the 1/255 is applied once to the finished sum;
-//   * conv1 / conv2: BOTH operands are fp32 values, so both are split exactly into three bf16 terms
-//     (activations when the previous layer's epilogue writes them to LDS, weights by dx_cnn_pack) and
-//     x w = sum of nine exact products.  The six largest -- hi hi, hi mid, mid hi, hi lo, lo hi, mid mid
-//     -- are multiplied (v_mfma_f32_16x16x32_bf16: each product exact in fp32, fp32 accumulation,
-//     smallest terms first); the three dropped ones (mid lo, lo mid, lo lo) are below 2^-23 of the
-//     product, i.e. below the rounding an fp32 fma chain commits on the same sum (kTerms = 9 multiplies
-//     them too).  Six bf16 MFMAs of 16 cycles replace sixteen cycles x 16 of fp32 MFMA: 2.7x less
-//     matrix time than v_mfma_f32_16x16x4_f32 (the first version of this kernel: 30 us per launch,
-//     its conv1 + conv2 loops AT the fp32 matrix rate; stamps in the diag flavour, DX_CS_DIAG).
-// Operands: the activations are read by the matrix instructions straight from the LDS planes (a lane's
-// address is its pixel's base + a compile-time tap offset: one ds_read_b128 per plane, pixel and row
-// pitches keep the 16-lane read groups on distinct banks); the weights of conv1 / conv2 never
-// touch LDS: wave (16-channel tile, K half) is the ONLY reader of its slice of the three planes and
-// loads it straight into the A-fragment layout (lane (channel, k group) = 8 consecutive k of one row),
-// all loads of a layer issued while the previous layer computes (L2-resident: every workgroup reads
-// the same 417 KB).  The matrix products are formed as D[channel][pixel], so a lane ends up with FOUR
-// consecutive channels of its pixel: one 8-byte LDS store per plane, one 16-byte store of y2.
-//   conv0: 13 pixel tiles of 32 over 8 waves (waves 0-4 two tiles: every weight fragment read from LDS
-//          once for both), next chunk's operands read before this chunk's MFMAs.
-//   conv1: M = 81 pixels in 6 tiles of 16, N = 4 tiles of 16 channels, K = 16 taps of 32 in two halves
-//          over the 8 waves; the halves swap three tiles each way through LDS and finish three each.
-//   conv2: M = 49 in 4 tiles, K = 18 steps of 32 in two halves, the same way.
+// ALL THREE layers run on the bf16 matrix cores at fp32 accuracy (convstack_dev.hpp):
+//   * conv0: a uint8 pixel is exact in bf16, the fp32 weight splits EXACTLY into three bf16 terms (hi + mid + lo,
+//     pre-split by dx_cnn_pack), every product is exact in fp32, v_mfma_f32_32x32x16_bf16 accumulates in fp32; the 1/255
+//     is applied once to the finished sum;
+//   * conv1 / conv2: BOTH operands are split exactly into three bf16 terms (activations when the previous layer's
+//     epilogue writes them to LDS, weights by dx_cnn_pack) and x w = sum of nine exact products, of which the six
+//     largest are multiplied (v_mfma_f32_16x16x32_bf16, smallest terms first); the three dropped ones are below 2^-23 of
+//     the product (kTerms = 9 multiplies them too).
+// Round 5: the eight waves are SPECIALISED (convstack_roll_kernel below; convstack_train.hip is the training forward's
+// twin and explains the roles, the four barriers per step and the measurements behind them).  The one-role-for-all
+// kernel of round 4 -- every wave running conv0 | epilogue | conv1 (K halves) | exchange | conv2 | exchange in lockstep:
+// 43,000 cycles per step for 22,000 of matrix time -- is gone: 18.4 -> 14.4 us per step at 32 envs, 18.9 -> 17.0 at 256.
 // Results equal the layer-by-layer path to fp32 rounding (other summation order).
 #include "bf16_split.hpp"
 #include "heads_dev.hpp"
@@ -82,290 +69,6 @@ __device__ __forceinline__ void sample_step(const ConvStackArgs &a, const float 
     a.actions[row] = act;
     a.log_prob[row] = la;
     a.values[row] = val;
-  }
-}
-
-// TRAIN: the forward of a training minibatch (its own kernel symbol: a profile tells the update's launches from
-// the rollout's, and the rollout-only parts -- the tail, the sample, the env's frame -- are compiled out of it)
-template <bool TRAIN>
-__global__ __launch_bounds__(512) void convstack_image_kernel(const ConvStackArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nt = wave & 3, kh2 = wave >> 2;  // conv1 / conv2: output-channel tile and K half of this wave
-  int e = blockIdx.x;  // the env (rollout) or, in a training forward, the image: blockIdx + t grid
-  const int steps = TRAIN ? (a.B - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x) : a.T;
-  const long long step_bytes = static_cast<long long>(a.row_stride) * kFrameB;  // frames of one step of the whole batch
-  unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define DX_CS_MARK(i) if (kDiag && a.stamps && t == stamp_step) tk[i] = __builtin_amdgcn_s_memtime();
-  const int stamp_wave = kDiag ? (a.env0 >> 24) & 7 : 0;  // (diag: DX_CS_DIAG=<wave> picks the stamping wave)
-  const int stamp_step = kDiag ? a.stamp_step : 0;              // (diag: DX_CS_STEP=<t> picks the stamped step)
-  int t = 0;
-  if (kDiag && a.stamps && stamp_step == 0) tk[0] = __builtin_amdgcn_s_memtime();
-  if (kDiag && a.stamps) { tk[14] = __builtin_amdgcn_s_memrealtime(); tk[15] = __builtin_amdgcn_s_memtime(); }
-
-  // ---- step 0's frame and conv0's weight planes (resident for the whole launch): issued at once ----
-  {
-    const uint8_t *src = a.obs + static_cast<long long>(a.sample_idx ? a.sample_idx[e] : e) * kFrameB;
-    u32x4 fr[4];  // the frame: 1,764 pieces of 16 bytes
-#pragma unroll
-    for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const u32x4 *>(src + 16 * min(tid + 512 * u, kFrameB / 16 - 1));
-    u32x4 wv[6];  // conv0's planes: 3 x 32 rows x 32 pieces
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int i = u * 512 + tid;
-      wv[u] = *reinterpret_cast<const u32x4 *>(a.Wb0 + (i >> 10) * 8192 + ((i >> 5) & 31) * 256 + (i & 31) * 8);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (tid + 512 * u < kFrameB / 16) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * (tid + 512 * u)) = fr[u];
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int i = u * 512 + tid;
-      *reinterpret_cast<u32x4 *>(smem + oW0 + (i >> 10) * kWPlaneB + ((i >> 5) & 31) * kWRowB + (i & 31) * 16) = wv[u];
-    }
-  }
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  float *red = reinterpret_cast<float *>(smem + oRed);
-  float *tailred = reinterpret_cast<float *>(smem + oTail);  // [step parity][8 waves][kTailOut outputs]
-  // the weights come in fragment order (launch_convstack_pack): piece (wave, step, plane) is one KB, 16 bytes per lane
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const unsigned off1 = static_cast<unsigned>(lane * 16), off2 = off1;
-
-  // conv1's weight fragments: A fragment of v_mfma_f32_16x16x32_bf16 = 8 consecutive k of row (channel) 16 nt + n16:
-  // plane pl, tap 8 kh2 + s, k group kq.  Taps 0-5 travel while conv0 runs (a rollout step fetches them at its top, a
-  // training image's arrive under the previous image's conv2 loop), taps 6-7 after conv0, whose two-tile waves need
-  // the registers.
-  u32x4 w1[8][3];
-  auto fetch_w1_head = [&]() {
-    const unsigned o1 = static_cast<unsigned>(opaque(static_cast<int>(off1)));
-#pragma unroll
-    for (int s = 0; s < 6; ++s)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load_piece(a.Wf1, ((wave_s * 8 + s) * 3 + pl) * 512, o1);
-  };
-  if (TRAIN) fetch_w1_head();
-  for (t = 0; t < steps; ++t) {
-    if (t > 0) { DX_CS_MARK(0) }
-    if (TRAIN && t > 0) {
-      e += gridDim.x;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the image's frame (LDS-DMA, below) have landed
-    }
-    if (!TRAIN) fetch_w1_head();
-    lds_barrier();  // this step's frame (and, at step 0, conv0's planes) are in LDS
-    DX_CS_MARK(1)
-
-    // ---- conv0: 13 tiles of 32 pixels, waves 0-4 take two ----
-    {
-      const int lane0 = opaque(lane);
-      f32x16 acc0[2];  // (waves 5-7 use the first only)
-      if (wave < 5) conv0_mfma<2>(smem, wave, lane0, acc0);
-      else conv0_mfma<1>(smem, wave, lane0, acc0);
-      // wave 7 has one conv0 tile where waves 0-4 have two: the PREVIOUS step's sample fits in that slack
-      if (!TRAIN && a.Wc && t > 0 && wave == 7) sample_step(a, tailred, t - 1, e, lane0);
-      f32x4 bias0[4];  // conv0's bias for this lane's 16 accumulator rows (channels 8 q + 4 (lane >> 5) + j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (lane0 >> 5));
-      DX_CS_MARK(11)
-      lds_barrier();  // every wave has read the frame: the y0 planes may overwrite it
-      float *gy0 = TRAIN && a.y0 ? a.y0 + static_cast<long long>(e) * (kP0 * 32) : nullptr;
-      if (wave < 5) conv0_store<2>(smem, wave, lane0, acc0, bias0, gy0);
-      else conv0_store<1>(smem, wave, lane0, acc0, bias0, gy0);
-    }
-    lds_barrier();  // y0 complete
-    DX_CS_MARK(2)
-
-    u32x4 w2[9][3];  // conv2's weight fragments: steps 9 kh2 + s
-    {  // ---- conv1 ----
-      {
-        const unsigned o1 = static_cast<unsigned>(opaque(static_cast<int>(off1)));
-#pragma unroll
-        for (int s = 6; s < 8; ++s)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) w1[s][pl] = load_piece(a.Wf1, ((wave_s * 8 + s) * 3 + pl) * 512, o1);
-      }
-      const int lane1 = opaque(lane), n16 = lane1 & 15, kq = lane1 >> 4;
-      int pb[6];
-#pragma unroll
-      for (int mt = 0; mt < 6; ++mt) {
-        const int p = min(16 * mt + n16, kP1 - 1), oy = p / 9, ox = p - 9 * oy;
-        pb[mt] = oY0 + 2 * oy * kY0R + 2 * ox * kY0P + 16 * kq;
-      }
-      f32x4 acc[6] = {zero4, zero4, zero4, zero4, zero4, zero4};
-      DX_CS_MARK(12)
-      if constexpr (TRAIN) {  // conv2's fragments travel under this loop, K step s fetching step s of them
-        const NextWeights<9, 8> nw2{a.Wf2 + wave_s * (9 * 3 * 512), static_cast<unsigned>(opaque(static_cast<int>(off2))), w2};
-        if (kh2 == 0) conv_half<1, 0, 6, 8>(smem, pb, w1, acc, nw2);
-        else conv_half<1, 1, 6, 8>(smem, pb, w1, acc, nw2);
-      } else {
-        const NextWeights<9, 0> none{nullptr, 0u, w2};
-        if (kh2 == 0) conv_half<1, 0, 6, 8>(smem, pb, w1, acc, none);
-        else conv_half<1, 1, 6, 8>(smem, pb, w1, acc, none);
-      }
-      DX_CS_MARK(13)
-      const int oc0 = 16 * nt + 4 * kq;  // the four channels of this lane's D rows
-      const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);  // (ahead of the 27 loads below: vmcnt returns in order)
-      __builtin_amdgcn_sched_barrier(0);
-      // conv2's fragments travel under the exchange (conv1's have just freed their registers)
-      const unsigned o2 = static_cast<unsigned>(opaque(static_cast<int>(off2)));
-#pragma unroll
-      for (int s = TRAIN ? 8 : 0; s < 9; ++s)  // (training: steps 0-7 came under the loop above)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w2[s][pl] = load_piece(a.Wf2, ((wave_s * 9 + s) * 3 + pl) * 512, o2);
-      DX_CS_MARK(3)
-      lds_barrier();  // every wave has read y0: the exchange scratch and the y1 planes may overwrite it
-      // the K halves swap: half 0 finishes tiles 0-2, half 1 tiles 3-5; each hands the other's three over
-      DX_CS_MARK(8)
-      if (kh2 == 0) give_tiles<3, 3>(red, wave, lane, acc);
-      else give_tiles<0, 3>(red, wave, lane, acc);
-      lds_barrier();
-      DX_CS_MARK(9)
-      const int partner = wave ^ 4;
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {  // C/D layout: column (pixel) = lane & 15, rows (channels) 4 (lane >> 4) + j
-        const int p = 16 * ((kh2 == 0 ? 0 : 3) + m) + n16;
-        const f32x4 v = kh2 == 0 ? finish_tile<0>(red, partner, lane, acc, m, bias1) : finish_tile<3>(red, partner, lane, acc, m, bias1);
-        if (p < kP1) store_planes4(smem, oY1 + (p / 9) * kY1R + (p % 9) * kY1P + oc0 * 2, kY1Plane, v);
-        if (TRAIN && a.y1 && p < kP1) *reinterpret_cast<f32x4 *>(a.y1 + static_cast<long long>(e) * (kP1 * 64) + p * 64 + oc0) = v;
-      }
-      DX_CS_MARK(10)
-      lds_barrier();
-      DX_CS_MARK(4)
-    }
-    if (!TRAIN && a.env && t + 1 <= a.T) {
-      // The synthetic env's NEXT frame of this env (synth_atari_block's hash of (seed, counter, position): the
-      // measurement env ignores the action, so the frame does not wait for this step's sample): into the
-      // rollout buffer and straight into the LDS slot the next step's conv0 reads (free since y0 is dead).
-      // Vector-ALU work placed where the other waves' conv2 keeps the matrix pipe busy.
-      const uint64_t key = synth_mix64(a.env_seed * 0x9E3779B97F4A7C15ull + (a.env_counter + t));
-      uint8_t *dst = a.obs + (t + 1) * step_bytes + static_cast<long long>(e) * kFrameB;
-      for (int v = opaque(tid); v < kFrameB / 16; v += 512) {
-        const uint64_t p = static_cast<uint64_t>(a.env0 + e) * (kFrameB / 16) + v;
-        const uint64_t x = synth_mix64(key + 2 * p * 0x9E3779B97F4A7C15ull);
-        const uint64_t y = synth_mix64(key + (2 * p + 1) * 0x9E3779B97F4A7C15ull);
-        const u32x4 vec = {static_cast<uint32_t>(x), static_cast<uint32_t>(x >> 32), static_cast<uint32_t>(y), static_cast<uint32_t>(y >> 32)};
-        *reinterpret_cast<u32x4 *>(dst + 16 * v) = vec;
-        *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * v) = vec;
-      }
-      if (tid == 0) {
-        const uint64_t r = synth_mix64(~key + static_cast<uint64_t>(a.env0 + e) * 0xD1B54A32D192ED03ull);
-        const float u0 = static_cast<float>(r & 0xffffff) * (1.0f / 16777216.0f);
-        const float u1 = static_cast<float>((r >> 24) & 0xffffff) * (1.0f / 16777216.0f);
-        const long long row = static_cast<long long>(t) * a.row_stride + e;
-        if (a.rewards) a.rewards[row] = u0 < a.p_reward ? ((r >> 63) ? -1.f : 1.f) : 0.f;
-        if (a.resets) a.resets[row] = u1 < a.p_reset ? 1 : 0;
-      }
-    }
-    {  // ---- conv2 ----
-      const int lane2 = opaque(lane), n16 = lane2 & 15, kq = lane2 >> 4;
-      int pb[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const int p = min(16 * mt + n16, kP2 - 1), oy = p / 7, ox = p - 7 * oy;
-        pb[mt] = oY1 + oy * kY1R + ox * kY1P + 16 * kq;
-      }
-      f32x4 acc[4] = {zero4, zero4, zero4, zero4};
-      if constexpr (TRAIN) {  // the next image's conv1 fragments, taps 0-5 (also behind the last image: nobody reads them)
-        const NextWeights<8, 6> nw1{a.Wf1 + wave_s * (8 * 3 * 512), static_cast<unsigned>(opaque(static_cast<int>(off1))), w1};
-        if (kh2 == 0) conv_half<2, 0, 4, 9>(smem, pb, w2, acc, nw1);
-        else conv_half<2, 1, 4, 9>(smem, pb, w2, acc, nw1);
-      } else {
-        const NextWeights<8, 0> none{nullptr, 0u, w1};
-        if (kh2 == 0) conv_half<2, 0, 4, 9>(smem, pb, w2, acc, none);
-        else conv_half<2, 1, 4, 9>(smem, pb, w2, acc, none);
-      }
-      DX_CS_MARK(5)
-      __builtin_amdgcn_sched_barrier(0);  // (conv2's fragments are dead from here: room for the tail's weights)
-      const int p_keep0 = 16 * (kh2 == 0 ? 0 : 2) + n16;
-      const int oc0 = 16 * nt + 4 * kq;
-      f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
-      if (TRAIN && t + 1 < steps) {
-        // The NEXT image's frame, straight into the LDS slot conv0 reads (free since y0 died), by LDS-DMA: piece
-        // wave + 8 u is one KB of both.  Nothing this wave loaded is waited for between here and the next step's
-        // top (the compiler would drain the DMA with it): the bias is made to arrive first.
-        asm volatile("" : "+v"(bias2));
-        const int next = e + static_cast<int>(gridDim.x);
-        const uint8_t *src = a.obs + static_cast<long long>(a.sample_idx ? a.sample_idx[next] : next) * kFrameB;
-        const int lane3 = opaque(lane);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int piece = wave_s + 8 * u;
-          if (piece < 28 && piece * 64 + lane3 < kFrameB / 16)
-            __builtin_amdgcn_global_load_lds(src + 1024 * piece + 16 * lane3, smem + oFrame + 1024 * piece, 16, 0, 0);
-        }
-      }
-      // the tail's weights for outputs 0-3 now (under the exchange), for every further group of four after these are used
-      // (fragment order: [wave][tile][row j of Jp = 8 ceil((A + 1) / 8)][lane][4])
-      f32x4 wc[4][2];
-      const unsigned ow = static_cast<unsigned>(lane2 * 16);  // (rows of pixels past the image are zero)
-      const int Jp = (a.A + 8) & ~7;
-      if (!TRAIN && a.Wc) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            wc[j][m] = j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + ((wave_s * 2 + m) * Jp + j) * 256, ow)) : zero4;
-      }
-      // (the exchange scratch lies behind the y1 planes: no wave is still reading what it overwrites)
-      if (kh2 == 0) give_tiles<2, 2>(red, wave, lane, acc);
-      else give_tiles<0, 2>(red, wave, lane, acc);
-      lds_barrier();
-      const int partner = wave ^ 4;
-      f32x4 v2[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-        v2[m] = kh2 == 0 ? finish_tile<0>(red, partner, lane, acc, m, bias2) : finish_tile<2>(red, partner, lane, acc, m, bias2);
-      if (a.y2) {
-        float *out = a.y2 + static_cast<long long>(e) * (kP2 * 64);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-          if (p_keep0 + 16 * m < kP2) *reinterpret_cast<f32x4 *>(out + (p_keep0 + 16 * m) * 64 + oc0) = v2[m];
-      }
-      if (!TRAIN && a.Wc) {
-        // ---- the policy's tail: out[j] = sum over (pixel, channel) of y2 Wc[j] + beff[j]; lane sums, wave sums
-        // (DPP), the eight waves' sums meet in LDS in wave order, wave 0 samples (heads.hip: tail_act_block) ----
-        float mine = 0.f;
-        for (int grp = 0; 4 * grp <= a.A; ++grp) {  // groups of four outputs (uniform trip count: 2 for Breakout, 5 for 18 actions)
-          if (grp > 0) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                wc[j][m] = 4 * grp + j <= a.A ? __builtin_bit_cast(f32x4, load16(a.Wc + ((wave_s * 2 + m) * Jp + 4 * grp + j) * 256, ow)) : zero4;
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (4 * grp + j > a.A) continue;  // uniform: rows beyond A + 1 are zero
-            float part = 0.f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              const bool ok = p_keep0 + 16 * m < kP2;
-              float d = v2[m][0] * wc[j][m][0];
-              d = __builtin_fmaf(v2[m][1], wc[j][m][1], d);
-              d = __builtin_fmaf(v2[m][2], wc[j][m][2], d);
-              d = __builtin_fmaf(v2[m][3], wc[j][m][3], d);
-              part += ok ? d : 0.f;
-            }
-            const float tot = wave_sum_all(part);
-            mine = lane == 4 * grp + j ? tot : mine;
-          }
-        }
-        const int lane3 = opaque(lane);
-        if (lane3 <= a.A) tailred[(t & 1) * (8 * kTailOut) + wave * kTailOut + lane3] = mine;  // sampled by wave 7 under the next step's conv0
-      }
-    }
-    DX_CS_MARK(6)
-  }
-  if (!TRAIN && a.Wc) {  // the last step's sample
-    lds_barrier();
-    if (wave == 7) sample_step(a, tailred, a.T - 1, e, lane);
-  }
-#undef DX_CS_MARK
-  if (kDiag && a.stamps && tid == 64 * stamp_wave) {
-    tk[7] = __builtin_amdgcn_s_memrealtime();
-    tk[15] = __builtin_amdgcn_s_memtime() - tk[15];  // the whole launch in shader cycles,
-    tk[14] = tk[7] - tk[14];                         // and in ticks of the constant 100 MHz clock
-    for (int i = 0; i < 16; ++i) a.stamps[blockIdx.x * 16 + i] = tk[i];
   }
 }
 
@@ -735,17 +438,12 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
   if (a.row_stride < a.B) a.row_stride = a.B;
   a.stamps = nullptr;
   a.stamp_step = 0;
-  DX_LDS_OPT_IN(convstack_image_kernel<false>, kLdsBytes);
-  DX_LDS_OPT_IN(convstack_image_kernel<true>, kLdsBytes);
   int cus = 0;
   if (int rc = device_cus(&cus)) return rc;
   // a training forward: one workgroup per CU (the LDS holds one image), each walks its share of the minibatch
   const int B = a.train ? (a.B < cus ? a.B : cus) : a.B;  // workgroups
-  // (default: the role-specialised kernel of convstack_train.hip; DX_CONVSTACK_TRAIN_ROLES=0: this file's one-role-for-all flavour)
-  const bool roles = DX_ENV("DX_CONVSTACK_TRAIN_ROLES", 1) != 0;
-  if (a.train && roles) return launch_convstack_train(a, B, stream);
-  // the rollout step / act: the role-specialised kernel too (DX_CONVSTACK_ROLES=0: the one-role-for-all flavour below)
-  if (!a.train && DX_ENV("DX_CONVSTACK_ROLES", 1) != 0) {
+  if (a.train) return launch_convstack_train(a, B, stream);  // waves specialised by layer, two images in flight
+  {
     DX_LDS_OPT_IN(convstack_roll_kernel, kLdsBytes);
 #if DX_DIAG
     if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one step (DX_CS_STEP) as seen by wave DX_CS_DIAG, on stderr (synchronous)
@@ -788,47 +486,6 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
     DX_LAUNCH_CHECK();
     return DX_OK;
   }
-#if DX_DIAG
-  if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one step (DX_CS_STEP, default 0) of wave DX_CS_DIAG, on stderr (synchronous)
-    unsigned long long *dev_stamps = nullptr;
-    DX_HIP(hipMalloc(&dev_stamps, static_cast<size_t>(B) * 128));
-    a.stamps = dev_stamps;
-    const int stamp_wave = atoi(getenv("DX_CS_DIAG")) & 7;
-    a.env0 |= stamp_wave << 24;  // (timing build only: sampling positions are not what is looked at)
-    a.stamp_step = getenv("DX_CS_STEP") ? atoi(getenv("DX_CS_STEP")) : 0;
-    const int steps = a.train ? a.B / B : a.T;  // (training: images per workgroup)
-    if (a.stamp_step >= steps) a.stamp_step = steps - 1;
-    if (a.train) hipLaunchKernelGGL(convstack_image_kernel<true>, dim3(B), dim3(512), kLdsBytes, stream, a);
-    else hipLaunchKernelGGL(convstack_image_kernel<false>, dim3(B), dim3(512), kLdsBytes, stream, a);
-    DX_LAUNCH_CHECK();
-    DX_HIP(hipStreamSynchronize(stream));
-    std::vector<unsigned long long> h(static_cast<size_t>(B) * 16);
-    DX_HIP(hipMemcpy(h.data(), dev_stamps, h.size() * 8, hipMemcpyDeviceToHost));
-    DX_HIP(hipFree(dev_stamps));
-    static const int order[13] = {0, 1, 11, 2, 12, 13, 3, 8, 9, 10, 4, 5, 6};
-    static const char *what[12] = {"step top: w1 loads (6 taps) + barrier", "conv0 MFMA loop (+ deferred sample)", "conv0 bias, barrier, y0 stores, barrier",
-                                   "w1 loads (2 taps) + addresses", "conv1 loop", "bias1 + w2 loads issued", "barrier (all conv1 loops done)",
-                                   "hand-over + barrier", "finish + y1 stores", "barrier (y1 complete)", "next frame + conv2 loop",
-                                   "conv2 exchange + tail"};
-    double total = 0;
-    fprintf(stderr, "[convstack B=%d T=%d step %d wave %d] cycles per workgroup (mean):\n", B, a.T, a.stamp_step, stamp_wave);
-    for (int i = 0; i < 12; ++i) {
-      double d = 0;
-      for (int b = 0; b < B; ++b) d += static_cast<double>(h[b * 16 + order[i + 1]] - h[b * 16 + order[i]]) / B;
-      total += d;
-      fprintf(stderr, "  %-44s %8.0f\n", what[i], d);
-    }
-    fprintf(stderr, "  %-44s %8.0f\n", "total", total);
-    double cyc = 0, ticks = 0;
-    for (int b = 0; b < B; ++b) { cyc += static_cast<double>(h[b * 16 + 15]); ticks += static_cast<double>(h[b * 16 + 14]); }
-    fprintf(stderr, "  whole launch: %.0f cycles per workgroup in %.2f us: shader clock %.0f MHz\n", cyc / B, ticks / B / 100.0, cyc / ticks * 100.0);
-    return DX_OK;
-  }
-#endif
-  if (a.train) hipLaunchKernelGGL(convstack_image_kernel<true>, dim3(B), dim3(512), kLdsBytes, stream, a);
-  else hipLaunchKernelGGL(convstack_image_kernel<false>, dim3(B), dim3(512), kLdsBytes, stream, a);
-  DX_LAUNCH_CHECK();
-  return DX_OK;
 }
 
 }  // namespace dx

@@ -22,13 +22,12 @@ constexpr int kP0 = 400, kP1 = 81, kP2 = 49;                       // output pix
 constexpr int kY0P = 80, kY0R = 20 * kY0P + 16, kY0Plane = 20 * kY0R;    // bytes per y0 pixel / row / plane (32 bf16 + pad)
 constexpr int kY1P = 160, kY1R = 9 * kY1P + 192, kY1Plane = 9 * kY1R;    // bytes per y1 pixel / row / plane (64 bf16 + pad)
 constexpr int kWRowB = 528, kWPlaneB = 32 * kWRowB;                // conv0 weight planes in LDS: 256 bf16 + 16 B pad
-// LDS: [conv0 weight planes][region B].  Region B holds, in turn: the frame (at its end) while conv0
-// multiplies, the three y0 planes, then the three y1 planes (at its start) + the K halves' exchange.
+// LDS: [conv0 weight planes][region B][tail sums].  Region B holds, in turn: the frame (at its end) while conv0
+// multiplies, the three y0 planes, then the three y1 planes (at its start) beside the NEXT image's frame (at its end).
 constexpr int oW0 = 0, oB = oW0 + 3 * kWPlaneB, kRegionB = 3 * kY0Plane, oTail = oB + kRegionB, kTailOut = 24, kLdsBytes = oTail + 2 * 8 * kTailOut * 4;  // (tail: [step parity][8 waves][up to 24 padded outputs])
-constexpr int oFrame = oB + kRegionB - kFrameB, oY0 = oB, oY1 = oB, oRed = oB + 3 * kY1Plane;
-constexpr int kRedBytes = 8 * 3 * 64 * 16;  // every wave hands up to three accumulator tiles (16 bytes per lane each) to its partner
-static_assert(oB % 16 == 0 && oFrame % 16 == 0 && oRed % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS layout");
-static_assert(oRed + kRedBytes <= kLdsBytes, "exchange scratch inside region B");
+constexpr int oFrame = oB + kRegionB - kFrameB, oY0 = oB, oY1 = oB;
+static_assert(oB % 16 == 0 && oFrame % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS layout");
+static_assert(3 * kY1Plane <= oFrame - oB, "the y1 planes (region B's start) and the next frame (its end) are live together");
 
 // two bytes -> two bf16 (exact: the fp32 of an integer < 256 has a zero low half)
 __device__ __forceinline__ uint32_t cs_bytes_to_bf16x2(float f0, float f1) {
@@ -220,75 +219,6 @@ __device__ __forceinline__ void load_pair(const uint8_t *smem, const int (&pb)[N
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) x[h][pl] = *reinterpret_cast<const u32x4 *>(smem + pb[2 * PR + h] + off + pl * plane);
-}
-
-// The NEXT phase's weight fragments can ride along: K step S of the loop issues the three loads of step S of `next`
-// (COUNT steps, unconditionally: a branch per load would cut the MFMA stream into basic blocks).  Used by the training
-// forward only (conv2's fragments under conv1, the next image's conv1 taps 0-5 under conv2: the bursts of 18-27
-// loads between the layers stall the issuing wave for ~4,000 cycles per image); in the rollout flavour the 72 extra
-// live registers next to the policy's tail spill.
-template <int NN, int COUNT>
-struct NextWeights {
-  const uint16_t *base;  // this wave's first piece (uniform)
-  unsigned lane_bytes;
-  u32x4 (&w)[NN][3];     // (a reference: a pointer would send the fragments through scratch memory)
-};
-
-template <int LAYER, int KH, int NT, int NS, int S, int PR, int NN, int COUNT>
-__device__ __forceinline__ void conv_half_from(const uint8_t *smem, const int (&pb)[NT], const u32x4 (&w)[NS][3], f32x4 (&acc)[NT],
-                                               u32x4 (&x)[2][3], const NextWeights<NN, COUNT> &next) {
-  constexpr bool last = S == NS - 1 && PR == NT / 2 - 1;
-  constexpr int SN = PR + 1 < NT / 2 ? S : S + 1, PN = PR + 1 < NT / 2 ? PR + 1 : 0;
-  u32x4 xn[2][3];
-  acc[2 * PR] = mac_first(acc[2 * PR], w[S], x[0]);
-  __builtin_amdgcn_sched_barrier(0);
-  // the NEXT pair's six fragment reads travel under this pair's eleven remaining MFMAs (one tile ahead left a
-  // wave waiting for LDS after every five: 40 cycles per MFMA where the pipe needs 16, and the older wave of a
-  // SIMD kept the pipe from the younger -- the halves of conv1 finished 7,000 cycles apart)
-  if constexpr (!last) load_pair<LAYER, KH, SN, PN, NT>(smem, pb, xn);
-  if constexpr (PR == NT / 2 - 1 && S < COUNT) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) next.w[S][pl] = load_piece(next.base, (S * 3 + pl) * 512, next.lane_bytes);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  acc[2 * PR] = mac_rest(acc[2 * PR], w[S], x[0]);
-  acc[2 * PR + 1] = mac_rest(mac_first(acc[2 * PR + 1], w[S], x[1]), w[S], x[1]);
-  if constexpr (!last) conv_half_from<LAYER, KH, NT, NS, SN, PN, NN, COUNT>(smem, pb, w, acc, xn, next);
-}
-
-// One K half of conv1 (KH: taps 8 KH .. 8 KH + 7) or conv2 (KH: steps 9 KH .. 9 KH + 8 of 18) for this wave's
-// 16 channels: NT pixel tiles two at a time, activations from the LDS planes (pb = byte address of the
-// lane's pixel and k group in plane 0).
-template <int LAYER, int KH, int NT, int NS, int NN, int COUNT>
-__device__ __forceinline__ void conv_half(const uint8_t *smem, const int (&pb)[NT], const u32x4 (&w)[NS][3], f32x4 (&acc)[NT],
-                                          const NextWeights<NN, COUNT> &next) {
-  static_assert(NT % 2 == 0, "tiles go in pairs");
-  u32x4 x[2][3];
-  load_pair<LAYER, KH, 0, 0, NT>(smem, pb, x);
-  conv_half_from<LAYER, KH, NT, NS, 0, 0, NN, COUNT>(smem, pb, w, acc, x, next);
-}
-
-// the K halves' exchange: tiles FROM .. FROM + N - 1 of this wave's accumulators go to its partner
-// (constant indices: a dynamically indexed accumulator array would live in scratch memory)
-template <int FROM, int N, int NT>
-__device__ __forceinline__ void give_tiles(float *red, int wave, int lane, const f32x4 (&acc)[NT]) {
-#pragma unroll
-  for (int m = 0; m < N; ++m) reinterpret_cast<f32x4 *>(red)[(wave * 3 + m) * 64 + lane] = acc[FROM + m];  // 16 bytes per lane
-}
-// tile KEEP + m of this wave + what its partner handed over + bias, ReLU
-template <int KEEP, int NT>
-__device__ __forceinline__ f32x4 finish_tile(const float *red, int partner, int lane, const f32x4 (&acc)[NT], int m, f32x4 bias) {
-  const f32x4 theirs = reinterpret_cast<const f32x4 *>(red)[(partner * 3 + m) * 64 + lane];
-  f32x4 v;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float mine = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT - KEEP; ++t) mine = t == m ? acc[KEEP + t][j] : mine;  // m is a constant after unrolling
-    const float x = (mine + theirs[j]) + bias[j];
-    v[j] = relu_keep_nan(x);
-  }
-  return v;
 }
 
 }  // namespace

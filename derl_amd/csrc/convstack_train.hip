@@ -1,34 +1,45 @@
 // The forward of a TRAINING minibatch through the conv stack of derl/models.py:104-111 as one launch, one workgroup
-// per CU walking its share of the images -- the image-resident kernel of convstack.hip with its eight waves
-// SPECIALISED and two images in flight:
+// per CU walking its share of the images -- the image-resident arithmetic of convstack_dev.hpp with the eight waves
+// SPECIALISED and two images in flight (convstack.hip's convstack_roll_kernel is the rollout's twin):
 //
-//   waves 0-3 ("B": one per SIMD, the older wave of each SIMD pair): conv1 and conv2 of image i.  Wave b owns output
-//     channels 16 b .. 16 b + 15 of both layers over the WHOLE contraction (16 taps / 18 steps), so nothing is
-//     exchanged between waves: one accumulator per tile from the first tap to the bias.  Its weight fragments live in
-//     ONE buffer of 9 x 3 fragments (108 registers) that cycles through conv1 taps 0-7 -> conv1 taps 8-15 -> conv2
-//     steps 0-8 -> conv2 steps 9-17 -> the next image's conv1 taps 0-7: K step s of a half is overwritten by step s of the
-//     next half right after its last MFMA has issued (three 1-KB loads from the fragment-ordered copies in L2 under the
-//     MFMAs of step s + 1; no load bursts between the layers).
-//   waves 4-7 ("A"): conv0 of image i + 1.  Its frame arrives by LDS-DMA while B finishes conv1 of image i, its 13 pixel
-//     tiles (4 + 3 + 3 + 3) multiply UNDER B's conv2 loop on the same matrix pipes, and its epilogue (1 / 255, bias,
-//     ReLU, the exact three-way split into the y0 planes: the most vector-ALU work of the whole stack) runs beside B's
-//     conv2 epilogue.
+//   waves 0-3 ("B": one per SIMD, the older wave of each SIMD pair): conv1 (pixel tiles 0-3) and conv2 of image i, and
+//     ONE conv0 tile of image i + 1.  Wave b owns output channels 16 b .. 16 b + 15 of both layers over the WHOLE
+//     contraction (16 taps / 18 steps), so nothing is exchanged between waves: one accumulator per tile from the first
+//     tap to the bias.  Its weight fragments live in ONE buffer of 9 x 3 fragments (108 registers) that cycles through
+//     conv1 taps 0-7 -> taps 8-15 -> conv2 steps 0-8 -> steps 9-17 -> the next image's conv1 taps 0-7: K step s of a half
+//     is overwritten by step s of the next half right after its last MFMA has issued (three 1-KB loads from the
+//     fragment-ordered copies in L2, each behind one MFMA of step s + 1; no load bursts between the layers).
+//   waves 4-7 ("A"): conv1's pixel tiles 4-5 of image i for the channels of their SIMD's B wave (their own 96-register
+//     fragment buffer), and conv0 of image i + 1: 2-3 of its 13 pixel tiles multiply UNDER B's conv2 loop on the same
+//     matrix pipes (conv0_mfma_pipelined: the byte -> bf16 conversions of chunk c + 1 interleaved with chunk c's
+//     MFMAs), and the epilogue (1 / 255, bias, ReLU, the exact three-way split into the y0 planes: the most vector-ALU
+//     work of the whole stack) runs beside B's conv2 epilogue.  The next frame travels through registers: fetched from
+//     HBM (a gather by sample_idx) under the conv1 loops -- 4 KB per A wave, 3 KB per B wave -- and written to LDS when
+//     beta frees the slot (fetched by LDS-DMA behind beta it took 4,700 cycles and B waited for it).
 //
-// Why: in the one-role-for-all kernel every phase was serial -- conv0 MFMA | conv0 epilogue | conv1 | K-half exchange +
-// epilogue | conv2 | exchange + epilogue -- 42,400 cycles per image of which 22,200 are matrix time (stamps):
-// the matrix pipes idle through every epilogue and exchange, and the halves of a SIMD pair finish their loops 3,700
-// cycles apart (the older wave wins the arbitration).  Here a SIMD's pipe is fed by B's stream alone during conv1, by
-// B's and A's together during conv2, and the two epilogues overlap.
+// Why (stamps and same-box A/B: profiles/r05_ab_convstack.txt).  Round 4's one-role-for-all kernel ran every phase
+// serially in all eight waves -- conv0 MFMA | conv0 epilogue | conv1 | K-half exchange + epilogue | conv2 | exchange +
+// epilogue -- 42,400 cycles per image of which 22,200 are matrix time: the pipes idle through every epilogue and
+// exchange, and the K halves of a SIMD pair finish their loops 3,700 cycles apart (the older wave wins the arbitration).
+// Three measurements shaped this kernel: (1) ONE wave issues v_mfma_f32_16x16x32_bf16 every 16.5 cycles, TWO waves of
+// a SIMD together every 12.4 (tools/ubench/mfma_issue.hip; 32x32x16: 32 against 24) -- so both waves of a SIMD should
+// multiply in every phase, which is why A takes a third of conv1 and B one conv0 tile; (2) a burst of LDS reads or
+// global loads holds a wave's in-order stream while the LDS / the texture path takes it and no MFMA issues meanwhile
+// (conv1 alone on a SIMD: 13,600 cycles, 9,250 without the fragment re-reads, 6,400 without re-reads and weight loads)
+// -- so every read and load is pinned behind its own MFMA (sched_group_barrier, convstack_roles.hpp); (3) conv0 in
+// ONE wave per SIMD is vector-ALU bound (12 conversion instructions per tile and chunk): 16,300 cycles for four tiles
+// beside B's conv2 until the conversions were pipelined against the MFMAs and B took a tile.
+// Result: 33,800 cycles per image, 570-575 us at minibatch 8192 where round 4's kernel takes 621 on the same box.
 //
-// LDS map = convstack.hip's (148 KB): conv0's weight planes resident; region B holds y0 (image i) -> y1 (image i, at its
-// start) + the frame of image i + 1 (at its end) -> y0 (image i + 1).  Four workgroup barriers per image:
-//   alpha  y0(i) complete                 B: conv1 reads y0(i)                    A: -
-//   beta   every B wave has read y0(i)    B: bias / ReLU / split -> y1(i)         A: frame(i + 1) by LDS-DMA
-//   gamma  y1(i) complete, frame landed   B: conv2 reads y1(i)                    A: conv0 MFMAs of image i + 1
-//   delta  y1(i) and the frame are dead   B: bias / ReLU -> y2(i) (global)        A: epilogue -> y0(i + 1)
-// Arithmetic: the same exact splits and the same six products per fp32 product as convstack.hip (kTerms); a tile's sum
-// runs over all taps in one accumulator instead of two K halves added at the end, so results differ from the rollout
-// flavour's in the last bits (summation order), like every other route.
+// LDS map = convstack_dev.hpp's (149 KB): conv0's weight planes resident; region B holds y0 (image i) -> y1 (image i,
+// at its start) + the frame of image i + 1 (at its end) -> y0 (image i + 1).  Four workgroup barriers per image:
+//   alpha  y0(i) complete                 B: conv1 tiles 0-3 of image i          A: conv1 tiles 4-5; frame(i + 1) -> registers
+//   beta   every wave has read y0(i)      B: bias / ReLU / split -> y1(i)        A: the same for its tiles; frame -> LDS
+//   gamma  y1(i), frame(i + 1) complete   B: conv2 of image i, conv0 tile b      A: conv0 tiles 4 + a, 8 + a (12) of image i + 1
+//   delta  y1(i) and the frame are dead   B: bias / ReLU -> y2(i); its y0 tile   A: epilogue -> y0(i + 1)
+// Arithmetic: the same exact splits and the same six products per fp32 product as everywhere (kTerms); a tile's sum
+// runs over all taps in one accumulator, so results differ from the layer-by-layer stages in the last bits (summation
+// order), like every other route.  ReLU keeps a NaN (relu_keep_nan).
 #include "convstack_roles.hpp"
 #include <cstdio>
 #include <cstdlib>

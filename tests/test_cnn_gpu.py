@@ -682,7 +682,6 @@ SWITCH_SETTINGS = ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_TN_SWIZZLE=0", "DX_LA
                    "DX_FC_FACTORED=0",                           # linear layer + heads layer by layer in updates and rollouts
                    "DX_CONVSTACK=0", "DX_CONVSTACK=0 DX_FC_FACTORED=0 DX_FC_ROLLOUT=0",  # the rollout's layer-by-layer kernels
                    "DX_CONVSTACK_TRAIN=0 DX_WGRAD_B6=0 DX_DGRAD_B6=0",  # the update's fp32-MFMA conv stages
-                   "DX_CONVSTACK_TRAIN_ROLES=0",                 # the training forward's one-role-for-all flavour (convstack.hip)
                    "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
                    "DX_BWD_OVERLAP=0 DX_C0_WAVES=4 DX_C0_GROUP4=0"]  # and their serial / round-2 twins
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the training forward's conv-stack kernels on one box: parity tests of the forward, phase stamps, trunk timing.
-# usage: bash tools/gpu_cs_train.sh <tag> [pytest -k expression]
+# usage: bash tools/gpu_cs_train.sh <tag> [pytest -k expression] [other library.so]
 TAG=${1:-cst}
 SEL=${2:-"training_forward or test_forward or conv_stack or loss_and_gradients"}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -14,7 +14,9 @@ for w in 0 4; do
   DX_CS_DIAG=$w DX_CS_STEP=5 timeout -k 10 120 python3 tools/cs_stamps.py 8192 0 2> gpurun_out/${TAG}_stamps_w$w.log || exit 1
   tail -12 gpurun_out/${TAG}_stamps_w$w.log
 done
-for roles in 1 0 1 0; do
-  DX_CONVSTACK_TRAIN_ROLES=$roles timeout -k 10 120 python3 tools/trunk_bench.py 8192 1024 >> gpurun_out/${TAG}_trunk_roles$roles.log 2>&1 || exit 1
-  echo "roles=$roles"; tail -2 gpurun_out/${TAG}_trunk_roles$roles.log
+# (A/B against another build of the library kept beside the default one: DERL_AMD_LIBRARY=<name>.so, see tools/gpu_stage_ab.sh)
+for lib in default ${3:-default}; do
+  if [ "$lib" = default ]; then unset DERL_AMD_LIBRARY; else export DERL_AMD_LIBRARY=$lib; fi
+  timeout -k 10 120 python3 tools/trunk_bench.py 8192 1024 >> gpurun_out/${TAG}_trunk_$lib.log 2>&1 || exit 1
+  echo "library $lib"; tail -2 gpurun_out/${TAG}_trunk_$lib.log
 done
