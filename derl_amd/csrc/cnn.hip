@@ -348,10 +348,11 @@ static int pack_part(const dx_cnn_ctx *c, int part, hipStream_t s, bool light = 
   float *wcf = convstack_supported(c->in_h, c->in_w, c->in_c) ? pk + c->ps_wc : nullptr;  // Wc in the conv-stack kernel's order
   if (direct) {
     // between two updates of an epoch on the default route nothing reads an fp32 mirror: Wc, and the bf16 planes
-    // of the three conv layers in the orders their kernels read, straight from the parameters (pack_direct.hip)
-    if (int rc = launch_tail_pack(w, c->off_w, c->off_b, A, pk + c->pk_wc, pk + c->pk_beff, pk + c->pk_wcs, wcf, s)) return rc;
-    return launch_pack_direct(w + c->off_w[0], w + c->off_w[1], w + c->off_w[2], planes(c, c->pb_c0f), planes(c, c->ps_c1f),
-                              planes(c, c->ps_c2f), planes(c, c->ps_c1d), planes(c, c->ps_c2d), s);
+    // of the three conv layers in the orders their kernels read, straight from the parameters (pack_direct_dev.hpp)
+    // (two launches: the conv planes ride in extra workgroups of the tail pack's first kernel)
+    const TailDirectPlanes direct_planes{planes(c, c->pb_c0f), planes(c, c->ps_c1f), planes(c, c->ps_c2f), planes(c, c->ps_c1d),
+                                         planes(c, c->ps_c2d)};
+    return launch_tail_pack(w, c->off_w, c->off_b, A, pk + c->pk_wc, pk + c->pk_beff, pk + c->pk_wcs, wcf, s, &direct_planes);
   }
   // The padded head rows / columns beyond A + 1 are never written: `packed` must be zero-filled
   // once by its owner (include/derl_amd.h), not on every parameter update.

@@ -270,11 +270,10 @@ bool tail_supported(int flat, int num_actions);  // 84 x 84 frames' conv output 
 int tail_rows(int num_actions);                   // the A + 1 outputs padded to groups of eight (8, 16 or 24 rows)
 long long tail_pack_scratch_floats(int num_actions);
 long long tail_slab_floats(int B, int num_actions);
+// (`direct`, optional: the conv layers' bf16 planes of pack_direct_dev.hpp written by extra workgroups of the same launch)
+struct TailDirectPlanes { uint16_t *p0, *f1, *f2, *d1, *d2; };
 int launch_tail_pack(const float *params, const long long *off_w, const long long *off_b, int A, float *Wc, float *beff,
-                     float *scratch, float *Wcf, hipStream_t stream);  // Wcf (optional): Wc in convstack.hip's fragment order
-// the bf16 planes every conv stage of the default route reads, straight from the canonical parameters (pack_direct.hip)
-int launch_pack_direct(const float *w0, const float *w1, const float *w2, uint16_t *p0, uint16_t *f1, uint16_t *f2, uint16_t *d1,
-                       uint16_t *d2, hipStream_t stream);
+                     float *scratch, float *Wcf, hipStream_t stream, const TailDirectPlanes *direct = nullptr);  // Wcf (optional): Wc in convstack.hip's fragment order
 int launch_tail_loss(const float *y2, const float *Wc, const float *beff, const int64_t *actions,
                      const float *old_log_prob, const float *advantages, const float *old_values,
                      const float *value_targets, const double *stats, float norm_eps, float *adv_norm_out, float *head,

@@ -1,16 +1,17 @@
-// Between two updates of a native epoch (dx_cnn_ppo_epoch), on the default route -- uint8 frames, factored
-// tail, every conv stage on the bf16 matrix cores -- nothing reads the fp32 weight mirrors: the forward
-// (convstack.hip), the data gradients (dgrad_b6.hip) and the first layer's kernels (conv0_b16.hip) read bf16
-// planes in their own orders, the weight gradients read no weights at all.  This ONE launch writes those planes
-// straight from the canonical parameters (derl/models.py:94-124's state_dict: OIHW), where dx_cnn_pack takes four
-// (mirrors, planes, two re-orderings): the exact three-term split of the same fp32 values, so every plane is
-// bit-identical to dx_cnn_pack's.
+// Between two updates of a native epoch (dx_cnn_ppo_epoch), on the default route -- uint8 frames, factored tail, every conv
+// stage on the bf16 matrix cores -- nothing reads the fp32 weight mirrors: the forward (convstack_train.hip), the rollout
+// (convstack.hip), the data gradients (dgrad_b6.hip) and the first layer's weight gradient (conv0_b16.hip) read bf16 planes
+// in their own orders, the weight gradients read no weights at all.  These pieces write those planes straight from the
+// canonical parameters (derl/models.py:94-124's state_dict: OIHW), where dx_cnn_pack takes four launches (mirrors, planes,
+// two re-orderings): the exact three-term split of the same fp32 values, so every plane is bit-identical to dx_cnn_pack's.
+// Round 5: no launch of their own any more -- they run in extra workgroups of launch_tail_pack's first kernel (tail.hip).
 //   thread = one 16-byte piece (8 consecutive k of one row) of one of five images:
-//   conv0 planes [3][32][256]            k = (kh, kw, c)                  (conv0_b16.hip, convstack.hip)
-//   Wf1 [wave][8 steps][3][64 lanes][8]   row oc, k = (kh, kw, ic)          (convstack.hip: launch_convstack_pack's order)
+//   conv0 planes [3][32][256]            k = (kh, kw, c)                  (conv0_b16.hip, the conv-stack kernels)
+//   Wf1 [wave][8 steps][3][64 lanes][8]   row oc, k = (kh, kw, ic)          (launch_convstack_pack's order)
 //   Wf2 [wave][9 steps][3][64][8]         row oc, k = (kh, kw, ic)
 //   Wd1 [wave = 2 parity + ic tile][8][3][64][8]   row ic, k = (a, b, oc), tap (py + 2 a, px + 2 b)   (dgrad_b6.hip)
 //   Wd2 [wave = ic tile + 4 K half][9][3][64][8]   row ic, k = (kh, kw, oc)
+#pragma once
 #include "bf16_split.hpp"
 #include "igemm.hpp"
 
@@ -19,7 +20,7 @@ namespace {
 
 constexpr int kN0 = 32 * 256 / 8;                  // pieces of a conv0 plane
 constexpr int kN1 = 8 * 8 * 64, kN2 = 8 * 9 * 64;  // (wave, step, lane) triples of conv1 / conv2
-constexpr int kTotal = kN0 + 2 * (kN1 + kN2);
+constexpr int kPackDirectPieces = kN0 + 2 * (kN1 + kN2);
 
 struct PackDirectArgs {
   const float *w0, *w1, *w2;  // canonical OIHW: (32, 4, 8, 8), (64, 32, 4, 4), (64, 64, 3, 3)
@@ -33,8 +34,8 @@ __device__ __forceinline__ void store3(uint16_t *dst, long long plane_stride, co
   *reinterpret_cast<u32x4 *>(dst + 2 * plane_stride) = u32x4{a.lo.x, a.lo.y, b.lo.x, b.lo.y};
 }
 
-__global__ __launch_bounds__(256) void pack_direct_kernel(const PackDirectArgs a) {
-  int q = blockIdx.x * 256 + threadIdx.x;
+// piece q (one 16-byte piece of one of the five images); q >= kPackDirectPieces: nothing
+__device__ __forceinline__ void pack_direct_piece(const PackDirectArgs &a, int q) {
   float v[8];
   if (q < kN0) {  // conv0: row oc, k = 8 q' .. : (kh, kw, c) with 4 channels -> two (kh, kw) taps of 4 channels
     const int oc = q >> 5, k0 = 8 * (q & 31);
@@ -85,15 +86,4 @@ __global__ __launch_bounds__(256) void pack_direct_kernel(const PackDirectArgs a
 }
 
 }  // namespace
-
-int launch_pack_direct(const float *w0, const float *w1, const float *w2, uint16_t *p0, uint16_t *f1, uint16_t *f2, uint16_t *d1,
-                       uint16_t *d2, hipStream_t stream) {
-  DX_REQUIRE(w0 && w1 && w2 && p0 && f1 && f2 && d1 && d2, "pack_direct: bad arguments");
-  DX_REQUIRE(aligned(p0, 16) && aligned(f1, 16) && aligned(f2, 16) && aligned(d1, 16) && aligned(d2, 16), "pack_direct: planes must be 16-byte aligned");
-  const PackDirectArgs a{w0, w1, w2, p0, f1, f2, d1, d2};
-  hipLaunchKernelGGL(pack_direct_kernel, dim3((kTotal + 255) / 256), dim3(256), 0, stream, a);
-  DX_LAUNCH_CHECK();
-  return DX_OK;
-}
-
 }  // namespace dx

@@ -20,7 +20,7 @@
 //   tail_loss_kernel (heads.hip) out, loss, dout
 //   tail_bwd_kernel  dy2 = relu'(y2) * (dout Wc), G partials, s partials: one pass over y2
 //   tail_greduce / tail_grads  G -> dWfc, dWh, dbfc, dbh straight into the flat gradient buffer
-#include "igemm.hpp"
+#include "pack_direct_dev.hpp"
 
 namespace dx {
 namespace {
@@ -31,6 +31,7 @@ constexpr int kK = 3136, kNH = 512, kP = 49;  // flat width (49 pixels x 64 chan
 // The A + 1 outputs are padded to Jp = 8, 16 or 24 rows (groups of eight: up to 18 actions + the value -- the full Atari
 // action set, derl/env/make_env.py:94-106); every per-output array below has Jp rows, rows beyond A + 1 are zero.
 constexpr int kJ = 8, kJMax = 24, kMaxOutputs = 19;
+static_assert(kMaxOutputs <= kJMax, "the padded row counts are 8, 16, 24");
 constexpr int kChunks = 8;                                       // n chunks of the Wc product
 constexpr int kBwdThreads = 448, kBwdCols = kK / kBwdThreads;    // 7 columns per thread
 
@@ -46,7 +47,13 @@ __device__ __forceinline__ float head_weight(const TailWeights &w, int j, int n)
 }
 
 // partial[chunk][j][kc] = sum over the chunk's 64 hidden units n of Wh[j][n] Wfc[n][kc]; blockIdx.y = group of eight outputs
-__global__ __launch_bounds__(256) void tail_pack_partial_kernel(const TailWeights w, float *partial, int Jp) {
+// Workgroups beyond the kP x kChunks of the product (first group only) run the direct pack's pieces (pack_direct_dev.hpp)
+// when `direct` has planes to write: between two updates of an epoch the two packs are then one launch.
+__global__ __launch_bounds__(256) void tail_pack_partial_kernel(const TailWeights w, float *partial, int Jp, const PackDirectArgs direct) {
+  if (blockIdx.x >= kP * kChunks) {
+    if (blockIdx.y == 0) pack_direct_piece(direct, (blockIdx.x - kP * kChunks) * 256 + threadIdx.x);
+    return;
+  }
   __shared__ float sWh[kJ][64];
   __shared__ float red[4][kJ][64];
   const int t = threadIdx.x, col = t & 63, ng = t >> 6;
@@ -77,22 +84,22 @@ __global__ __launch_bounds__(256) void tail_pack_partial_kernel(const TailWeight
 // (Wcf, optional: the same values in the fragment order of the rollout's conv-stack kernel, convstack.hip --
 // [wave = 4 (p / 32) + c / 16][tile (p % 32) / 16][row j of Jp][lane = 16 ((c % 16) / 4) + p % 16][c % 4]; the rows of
 // pixels 49 .. 63 are never written: `packed` is zero-filled once by its owner)
+template <int Jp>  // 8, 16 or 24: compile-time so that the common case (up to 7 actions) keeps eight registers per array
 __global__ __launch_bounds__(256) void tail_pack_finish_kernel(const float *partial, const TailWeights w, float *Wc, float *beff,
-                                                               float *Wcf, int Jp) {
+                                                               float *Wcf) {
   const int t = threadIdx.x;
   if (blockIdx.x == gridDim.x - 1) {
-    __shared__ float red[4][kJMax];
-    float part[kJMax];
+    __shared__ float red[4][Jp];
+    float part[Jp];
 #pragma unroll
-    for (int j = 0; j < kJMax; ++j) part[j] = 0.f;
+    for (int j = 0; j < Jp; ++j) part[j] = 0.f;
     for (int n = t; n < kNH; n += 256) {
       const float b = w.bfc[n];
 #pragma unroll
-      for (int j = 0; j < kJMax; ++j)
-        if (j < Jp) part[j] = fmaf(head_weight(w, j, n), b, part[j]);  // (uniform)
+      for (int j = 0; j < Jp; ++j) part[j] = fmaf(head_weight(w, j, n), b, part[j]);
     }
 #pragma unroll
-    for (int j = 0; j < kJMax; ++j) {
+    for (int j = 0; j < Jp; ++j) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) part[j] += __shfl_xor(part[j], o);
       if ((t & 63) == 0) red[t >> 6][j] = part[j];
@@ -290,6 +297,7 @@ struct TailGradArgs {
 constexpr int kGradBlocksW = kNH * (kK / 4) / 256;  // 1568: dWfc, one float4 per thread
 
 // dWfc = Wh^T G | dWh = G Wfc^T + s bfc^T | dbfc = Wh^T s, dbh = s -- three roles in one grid
+template <int Jp>  // 8, 16 or 24 (see tail_pack_finish_kernel)
 __global__ __launch_bounds__(256) void tail_grads_kernel(const TailGradArgs a) {
   const int t = threadIdx.x, blk = blockIdx.x;
   if (blk < kGradBlocksW) {
@@ -305,19 +313,18 @@ __global__ __launch_bounds__(256) void tail_grads_kernel(const TailGradArgs a) {
     return;
   }
   if (blk < kGradBlocksW + kNH) {
-    __shared__ float red[4][kJMax];
+    __shared__ float red[4][Jp];
     const int n = blk - kGradBlocksW;
-    float part[kJMax];
+    float part[Jp];
 #pragma unroll
-    for (int j = 0; j < kJMax; ++j) part[j] = 0.f;
+    for (int j = 0; j < Jp; ++j) part[j] = 0.f;
     for (int kc = t; kc < kK; kc += 256) {
       const float wfc = a.w.Wfc[static_cast<long long>(n) * kK + kc];
 #pragma unroll
-      for (int j = 0; j < kJMax; ++j)
-        if (j < a.nj) part[j] = fmaf(a.Gc[j * kK + kc], wfc, part[j]);  // (uniform)
+      for (int j = 0; j < Jp; ++j) part[j] = fmaf(a.Gc[j * kK + kc], wfc, part[j]);  // rows >= A + 1 of Gc are zero
     }
 #pragma unroll
-    for (int j = 0; j < kJMax; ++j) {
+    for (int j = 0; j < Jp; ++j) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) part[j] += __shfl_xor(part[j], o);
       if ((t & 63) == 0) red[t >> 6][j] = part[j];
@@ -369,13 +376,23 @@ long long tail_slab_floats(int B, int num_actions) {
 
 // Wc [Jp][3136] (y2's column order), beff [Jp] from the canonical parameters; scratch: tail_pack_scratch_floats(A)
 int launch_tail_pack(const float *params, const long long *off_w, const long long *off_b, int A, float *Wc, float *beff,
-                     float *scratch, float *Wcf, hipStream_t stream) {
+                     float *scratch, float *Wcf, hipStream_t stream, const TailDirectPlanes *direct) {
   DX_REQUIRE(params && Wc && beff && scratch && A >= 1 && A + 1 <= kMaxOutputs, "tail_pack: bad arguments");
   const TailWeights w = tail_weights(params, off_w, off_b, A);
   const int Jp = tail_rows(A);
-  hipLaunchKernelGGL(tail_pack_partial_kernel, dim3(kP * kChunks, Jp / 8), dim3(256), 0, stream, w, scratch, Jp);
+  PackDirectArgs d{};
+  int extra = 0;
+  if (direct) {  // the conv layers' bf16 planes ride in extra workgroups of the same launch
+    DX_REQUIRE(direct->p0 && direct->f1 && direct->f2 && direct->d1 && direct->d2, "tail_pack: direct planes missing");
+    d = PackDirectArgs{params + off_w[0], params + off_w[1], params + off_w[2], direct->p0, direct->f1, direct->f2, direct->d1, direct->d2};
+    extra = cdiv(kPackDirectPieces, 256);
+  }
+  hipLaunchKernelGGL(tail_pack_partial_kernel, dim3(kP * kChunks + extra, Jp / 8), dim3(256), 0, stream, w, scratch, Jp, d);
   DX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tail_pack_finish_kernel, dim3(cdiv(Jp * kK, 256) + 1), dim3(256), 0, stream, scratch, w, Wc, beff, Wcf, Jp);
+  const dim3 fgrid(cdiv(Jp * kK, 256) + 1);
+  if (Jp == 8) hipLaunchKernelGGL(tail_pack_finish_kernel<8>, fgrid, dim3(256), 0, stream, scratch, w, Wc, beff, Wcf);
+  else if (Jp == 16) hipLaunchKernelGGL(tail_pack_finish_kernel<16>, fgrid, dim3(256), 0, stream, scratch, w, Wc, beff, Wcf);
+  else hipLaunchKernelGGL(tail_pack_finish_kernel<24>, fgrid, dim3(256), 0, stream, scratch, w, Wc, beff, Wcf);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -420,7 +437,10 @@ int launch_tail_grads(const float *params, float *grads, const long long *off_w,
   DX_LAUNCH_CHECK();
   const TailGradArgs a{tail_weights(params, off_w, off_b, A), Gc, s, grads + off_w[3], grads + off_b[3], grads + off_w[4],
                        grads + off_b[4], grads + off_w[5], grads + off_b[5], A + 1};
-  hipLaunchKernelGGL(tail_grads_kernel, dim3(kGradBlocksW + kNH + 1), dim3(256), 0, stream, a);
+  const dim3 ggrid(kGradBlocksW + kNH + 1);
+  if (Jp == 8) hipLaunchKernelGGL(tail_grads_kernel<8>, ggrid, dim3(256), 0, stream, a);
+  else if (Jp == 16) hipLaunchKernelGGL(tail_grads_kernel<16>, ggrid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(tail_grads_kernel<24>, ggrid, dim3(256), 0, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
