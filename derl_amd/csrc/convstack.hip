@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (tid + 512 * u < kFrameB / 16) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * (tid + 512 * u)) = fr[u];
+      if (tid + 512 * u < kFrameB / 16) put_frame_unit(smem, tid + 512 * u, fr[u]);
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
       const int i = u * 512 + tid;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
   auto put_unit = [&](int t_, int unit, u32x4 v, bool to_lds) {
     if (unit < kFrameB / 16) {
       *reinterpret_cast<u32x4 *>(a.obs + (t_ + 1) * step_bytes + static_cast<long long>(e) * kFrameB + 16 * unit) = v;
-      if (to_lds) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * unit) = v;
+      if (to_lds) put_frame_unit(smem, unit, v);
     }
   };
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
       f32x4 acc2[4] = {zero4, zero4, zero4, zero4};
       conv_run<0, 2, 4, 9, 8>(smem, pb2, R, acc2, w2h1, w1h0, lane16);
       f32x16 accb[1];
-      if (next0) conv0_mfma_pipelined<1, 1>(smem, nt, opaque(lane), accb);
+      if (next0) conv0_mfma<1, 4, 1>(smem, nt, opaque(lane), accb);
       DX_CS_MARK(5)
       lds_barrier();  // delta: every wave has read y1 and the frame -- the y0 planes may overwrite both
       DX_CS_MARK(6)
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
       DX_CS_MARK(4)
       if (next0) {
         const int l0 = opaque(lane);
-        if (aw == 0) conv0_mfma_pipelined<3, 3>(smem, 4 + aw, l0, acc0);
-        else conv0_mfma_pipelined<2, 3>(smem, 4 + aw, l0, acc0);
+        if (aw == 0) conv0_mfma<3, 4, 3>(smem, 4 + aw, l0, acc0);
+        else conv0_mfma<2, 4, 3>(smem, 4 + aw, l0, acc0);
 #pragma unroll
         for (int s = 0; s < 8; ++s)  // the next step's conv1 taps 0-7: under the epilogue
 #pragma unroll

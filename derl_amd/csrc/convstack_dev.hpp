@@ -22,12 +22,17 @@ constexpr int kP0 = 400, kP1 = 81, kP2 = 49;                       // output pix
 constexpr int kY0P = 80, kY0R = 20 * kY0P + 16, kY0Plane = 20 * kY0R;    // bytes per y0 pixel / row / plane (32 bf16 + pad)
 constexpr int kY1P = 160, kY1R = 9 * kY1P + 192, kY1Plane = 9 * kY1R;    // bytes per y1 pixel / row / plane (64 bf16 + pad)
 constexpr int kWRowB = 528, kWPlaneB = 32 * kWRowB;                // conv0 weight planes in LDS: 256 bf16 + 16 B pad
-// LDS: [conv0 weight planes][region B][tail sums].  Region B holds, in turn: the frame (at its end) while conv0
-// multiplies, the three y0 planes, then the three y1 planes (at its start) beside the NEXT image's frame (at its end).
-constexpr int oW0 = 0, oB = oW0 + 3 * kWPlaneB, kRegionB = 3 * kY0Plane, oTail = oB + kRegionB, kTailOut = 24, kLdsBytes = oTail + 2 * 8 * kTailOut * 4;  // (tail: [step parity][8 waves][up to 24 padded outputs])
-constexpr int oFrame = oB + kRegionB - kFrameB, oY0 = oB, oY1 = oB;
-static_assert(oB % 16 == 0 && oFrame % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS layout");
-static_assert(3 * kY1Plane <= oFrame - oB, "the y1 planes (region B's start) and the next frame (its end) are live together");
+// LDS: [conv0 weight planes][region B][tail sums].  Region B holds, in turn: the frame while conv0 multiplies, the three
+// y0 planes (from its start), then the three y1 planes (at its start) beside the NEXT image's frame (behind them).  The
+// frame lies there as BF16 (a uint8 pixel is exact in bf16): every byte is converted ONCE, when the frame is written,
+// instead of once per use -- each byte is an operand of four 8 x 8 patches, and the conversion (1.5 vector-ALU
+// instructions per byte and use) was the bulk of the conv0 loops' instructions (one wave per SIMD ran four tiles in
+// 16,300 cycles for 4,600 of matrix time).
+constexpr int kFrame16B = 2 * kFrameB;  // 84 x 84 x 4 bf16
+constexpr int oW0 = 0, oB = oW0 + 3 * kWPlaneB, oY0 = oB, oY1 = oB, oFrame = oB + 3 * kY1Plane;
+constexpr int kRegionB = 3 * kY0Plane > 3 * kY1Plane + kFrame16B ? 3 * kY0Plane : 3 * kY1Plane + kFrame16B;
+constexpr int oTail = oB + kRegionB, kTailOut = 24, kLdsBytes = oTail + 2 * 8 * kTailOut * 4;  // (tail: [step parity][8 waves][up to 24 padded outputs])
+static_assert(oB % 16 == 0 && oFrame % 16 == 0 && oTail % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS layout");
 
 // two bytes -> two bf16 (exact: the fp32 of an integer < 256 has a zero low half)
 __device__ __forceinline__ uint32_t cs_bytes_to_bf16x2(float f0, float f1) {
@@ -110,9 +115,16 @@ __device__ __forceinline__ void store_planes4(uint8_t *smem, int off, int plane_
   *reinterpret_cast<uint2 *>(smem + off + 2 * plane_bytes) = s.lo;
 }
 
+// 16 raw bytes of a frame (16-byte unit `unit` of its 28,224 bytes) -> 16 bf16 in the LDS frame: converted here, once
+__device__ __forceinline__ void put_frame_unit(uint8_t *smem, int unit, u32x4 raw) {
+  *reinterpret_cast<bf16x8 *>(smem + oFrame + 32 * unit) = cs_expand8(uint2{raw.x, raw.y});
+  *reinterpret_cast<bf16x8 *>(smem + oFrame + 32 * unit + 16) = cs_expand8(uint2{raw.z, raw.w});
+}
+
 // conv0 for NT_ 32-pixel tiles (tile0, tile0 + TS, ...) of this wave: D[channel][pixel] = sum over the 16 K
-// chunks of W0(planes lo, mid, hi) x pixels; every weight fragment is read from LDS once per chunk for
-// all of the wave's tiles and the next chunk's operands are read before this chunk's MFMAs
+// chunks of W0(planes lo, mid, hi) x pixels; every weight fragment is read from LDS once per chunk for all of the
+// wave's tiles.  One scheduling region per chunk: its 3 NT_ MFMAs with the NEXT chunk's 3 + NT_ fragment reads
+// interleaved, one read behind each of the first MFMAs (no vector-ALU work: the pixels are bf16 in LDS).
 template <int NT_, int TS = 8, int NA = 2>
 __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int lane, f32x16 (&acc)[NA]) {
   static_assert(NT_ <= NA, "accumulator tiles");
@@ -122,34 +134,43 @@ __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int l
   for (int t = 0; t < NT_; ++t) {
     const int p = min(32 * (tile0 + TS * t) + r, kP0 - 1);  // columns past the image compute a copy that is not stored
     const int oy = p / 20, ox = p - 20 * oy;
-    pb[t] = oFrame + (4 * oy * kIn + 4 * ox) * 4 + 8 * kg;
+    pb[t] = oFrame + 2 * ((4 * oy * kIn + 4 * ox) * 4 + 8 * kg);
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   }
   const int wb = oW0 + r * kWRowB + 16 * kg;
-  uint2 px[NT_], pxn[NT_];
-  u32x4 wf[3], wfn[3];
+  bf16x8 px[NT_];
+  u32x4 wf[3];
 #pragma unroll
-  for (int t = 0; t < NT_; ++t) px[t] = *reinterpret_cast<const uint2 *>(smem + pb[t]);
+  for (int t = 0; t < NT_; ++t) px[t] = *reinterpret_cast<const bf16x8 *>(smem + pb[t]);
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int c = 0; c < 16; ++c) {  // chunk c: kernel row c / 2, bytes 16 (c % 2) .. + 15 of its 32
+    bf16x8 pxn[NT_];
+    u32x4 wfn[3];
     if (c + 1 < 16) {
-      const int aoff = ((c + 1) >> 1) * kRowB + 16 * ((c + 1) & 1);
+      const int aoff = 2 * (((c + 1) >> 1) * kRowB + 16 * ((c + 1) & 1));
 #pragma unroll
-      for (int t = 0; t < NT_; ++t) pxn[t] = *reinterpret_cast<const uint2 *>(smem + pb[t] + aoff);
+      for (int t = 0; t < NT_; ++t) pxn[t] = *reinterpret_cast<const bf16x8 *>(smem + pb[t] + aoff);
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) wfn[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB + 32 * (c + 1));
     }
-    __builtin_amdgcn_sched_barrier(0);  // (the reads above stay ahead of this chunk's MFMAs)
-    bf16x8 pf[NT_];
-#pragma unroll
-    for (int t = 0; t < NT_; ++t) pf[t] = cs_expand8(px[t]);
 #pragma unroll
     for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
-      for (int t = 0; t < NT_; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[pl]), pf[t], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT_; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[pl]), px[t], acc[t], 0, 0, 0);
+    if (c + 1 < 16) {
+      constexpr int kReads = 3 + NT_, kMfma = 3 * NT_;
+#pragma unroll
+      for (int i = 0; i < (kReads < kMfma ? kReads : kMfma); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if (kReads > kMfma) __builtin_amdgcn_sched_group_barrier(0x100, kReads - kMfma, 0);
+      if (kMfma > kReads) __builtin_amdgcn_sched_group_barrier(0x008, kMfma - kReads, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < 16) {
 #pragma unroll

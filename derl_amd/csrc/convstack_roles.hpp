@@ -83,77 +83,6 @@ __device__ __forceinline__ void conv_run(const uint8_t *smem, const int (&pb)[NT
       if constexpr (!(V & 1)) R[s][pl] = load_piece(nextb, (s * 3 + pl) * 512, lane_bytes);
 }
 
-// conv0 for NT_ 32-pixel tiles (tile0, tile0 + 4, ...) of an A wave, as convstack_dev.hpp's conv0_mfma but software-
-// pipelined one level deeper: while chunk c's MFMAs issue, the pixels of chunk c + 1 (read from LDS a chunk earlier) are
-// converted byte -> bf16 (12 vector-ALU instructions per tile: the bulk of this loop's instructions) and chunk c + 2's
-// pixels / chunk c + 1's weight fragments are read -- four conversions and at most one read behind every MFMA.  An A
-// wave runs four tiles in ONE in-order stream beside B's conv2 stream; with convert-then-multiply per chunk it took
-// 16,300 cycles for 4,600 of matrix time and B waited 5,800 of them.
-template <int NT_, int NA>
-__device__ __forceinline__ void conv0_mfma_pipelined(const uint8_t *smem, int tile0, int lane, f32x16 (&acc)[NA]) {
-  static_assert(NT_ <= NA, "accumulator tiles");
-  const int r = lane & 31, kg = lane >> 5;
-  int pb[NT_];
-#pragma unroll
-  for (int t = 0; t < NT_; ++t) {
-    const int p = min(32 * (tile0 + 4 * t) + r, kP0 - 1);  // columns past the image compute a copy that is not stored
-    const int oy = p / 20, ox = p - 20 * oy;
-    pb[t] = oFrame + (4 * oy * kIn + 4 * ox) * 4 + 8 * kg;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  }
-  const int wb = oW0 + r * kWRowB + 16 * kg;
-  uint2 px[NT_];      // raw pixels of the chunk after the one being multiplied
-  bf16x8 pf[NT_];     // converted pixels of the chunk being multiplied
-  u32x4 wf[3];
-#pragma unroll
-  for (int t = 0; t < NT_; ++t) px[t] = *reinterpret_cast<const uint2 *>(smem + pb[t]);
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB);
-#pragma unroll
-  for (int t = 0; t < NT_; ++t) pf[t] = cs_expand8(px[t]);
-#pragma unroll
-  for (int t = 0; t < NT_; ++t) px[t] = *reinterpret_cast<const uint2 *>(smem + pb[t] + 16);  // chunk 1
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int c = 0; c < 16; ++c) {  // chunk c: kernel row c / 2, bytes 16 (c % 2) .. + 15 of its 32
-    bf16x8 pfn[NT_];
-    uint2 pxn[NT_];
-    u32x4 wfn[3];
-    if (c + 1 < 16) {
-#pragma unroll
-      for (int t = 0; t < NT_; ++t) pfn[t] = cs_expand8(px[t]);
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) wfn[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB + 32 * (c + 1));
-    }
-    if (c + 2 < 16) {
-      const int aoff = ((c + 2) >> 1) * kRowB + 16 * ((c + 2) & 1);
-#pragma unroll
-      for (int t = 0; t < NT_; ++t) pxn[t] = *reinterpret_cast<const uint2 *>(smem + pb[t] + aoff);
-    }
-#pragma unroll
-    for (int pl = 2; pl >= 0; --pl)
-#pragma unroll
-      for (int t = 0; t < NT_; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[pl]), pf[t], acc[t], 0, 0, 0);
-    if (c + 1 < 16) {
-      constexpr int kMfma = 3 * NT_, kReads = 3 + NT_;
-#pragma unroll
-      for (int i = 0; i < kMfma; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA,
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // four conversions of the next chunk,
-        if (i < kReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + 1 < 16) {
-#pragma unroll
-      for (int t = 0; t < NT_; ++t) { pf[t] = pfn[t]; px[t] = pxn[t]; }
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) wf[pl] = wfn[pl];
-    }
-  }
-}
-
 // bias + ReLU + exact three-way split of four channels (oc0 ..) of conv1's output pixel p: the y1 planes in LDS, and
 // the fp32 values kept for the backward
 __device__ __forceinline__ void finish_conv1(uint8_t *smem, f32x4 sum, f32x4 bias, int p, int oc0, float *gy1) {

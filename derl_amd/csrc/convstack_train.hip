@@ -11,8 +11,8 @@
 //     fragment-ordered copies in L2, each behind one MFMA of step s + 1; no load bursts between the layers).
 //   waves 4-7 ("A"): conv1's pixel tiles 4-5 of image i for the channels of their SIMD's B wave (their own 96-register
 //     fragment buffer), and conv0 of image i + 1: 2-3 of its 13 pixel tiles multiply UNDER B's conv2 loop on the same
-//     matrix pipes (conv0_mfma_pipelined: the byte -> bf16 conversions of chunk c + 1 interleaved with chunk c's
-//     MFMAs), and the epilogue (1 / 255, bias, ReLU, the exact three-way split into the y0 planes: the most vector-ALU
+//     matrix pipes (the frame lies in LDS as bf16, converted once when it is written: no vector-ALU work in the
+//     loop), and the epilogue (1 / 255, bias, ReLU, the exact three-way split into the y0 planes: the most vector-ALU
 //     work of the whole stack) runs beside B's conv2 epilogue.  The next frame travels through registers: fetched from
 //     HBM (a gather by sample_idx) under the conv1 loops -- 4 KB per A wave, 3 KB per B wave -- and written to LDS when
 //     beta frees the slot (fetched by LDS-DMA behind beta it took 4,700 cycles and B waited for it).
@@ -26,9 +26,11 @@
 // multiply in every phase, which is why A takes a third of conv1 and B one conv0 tile; (2) a burst of LDS reads or
 // global loads holds a wave's in-order stream while the LDS / the texture path takes it and no MFMA issues meanwhile
 // (conv1 alone on a SIMD: 13,600 cycles, 9,250 without the fragment re-reads, 6,400 without re-reads and weight loads)
-// -- so every read and load is pinned behind its own MFMA (sched_group_barrier, convstack_roles.hpp); (3) conv0 in
-// ONE wave per SIMD is vector-ALU bound (12 conversion instructions per tile and chunk): 16,300 cycles for four tiles
-// beside B's conv2 until the conversions were pipelined against the MFMAs and B took a tile.
+// -- so every read and load is pinned behind its own MFMA (sched_group_barrier, convstack_roles.hpp); (3) conv0 of a
+// whole image in ONE wave per SIMD beside B's conv2 took 16,300 cycles for 4,600 of matrix time: its tiles are spread
+// 3 / 2 / 2 / 2 over the A waves + one per B wave (13,700), and the byte -> bf16 conversion (12 instructions per tile
+// and chunk) moved out of the loop to where the frame is written (13,000).  The phase stays issue-bound: two streams
+// of MFMAs, LDS reads and loads on one SIMD -- 10,000 cycles of matrix time at the two-wave rate take 13,000-14,000.
 // Result: 33,800 cycles per image, 570-575 us at minibatch 8192 where round 4's kernel takes 621 on the same box.
 //
 // LDS map = convstack_dev.hpp's (149 KB): conv0's weight planes resident; region B holds y0 (image i) -> y1 (image i,
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (tid + 512 * u < kFrameB / 16) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * (tid + 512 * u)) = fr[u];
+      if (tid + 512 * u < kFrameB / 16) put_frame_unit(smem, tid + 512 * u, fr[u]);
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
       const int i = u * 512 + tid;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const int unit = (16 + nt + 4 * u) * 64 + lf;
-          if (unit < kFrameB / 16) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * unit) = fr[u];
+          if (unit < kFrameB / 16) put_frame_unit(smem, unit, fr[u]);
         }
       }
       DX_CS_MARK(3)
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
       f32x4 acc2[4] = {zero4, zero4, zero4, zero4};
       conv_run<V, 2, 4, 9, 8>(smem, pb2, R, acc2, w2h1, w1h0, lane16);  // (then the next image's first taps; behind the last image nobody reads them)
       f32x16 accb[1];
-      if (more && !(V & 4)) conv0_mfma_pipelined<1, 1>(smem, nt, opaque(lane), accb);
+      if (more && !(V & 4)) conv0_mfma<1, 4, 1>(smem, nt, opaque(lane), accb);
       DX_CS_MARK(5)
       lds_barrier();  // delta: every wave has read y1 and the frame -- the y0 planes may overwrite both
       DX_CS_MARK(6)
@@ -270,15 +272,15 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
         // -- the end of region B; the y1 planes B writes meanwhile lie at its start
         const int lf = opaque(lane);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<u32x4 *>(smem + oFrame + 16 * ((aw + 4 * u) * 64 + lf)) = fr[u];
+        for (int u = 0; u < 4; ++u) put_frame_unit(smem, (aw + 4 * u) * 64 + lf, fr[u]);
       }
       DX_CS_MARK(3)
       lds_barrier();  // gamma: the frame is complete
       DX_CS_MARK(4)
       if (more && !(V & 4)) {
         const int l0 = opaque(lane);
-        if (aw == 0) conv0_mfma_pipelined<3, 3>(smem, 4 + aw, l0, acc0);
-        else conv0_mfma_pipelined<2, 3>(smem, 4 + aw, l0, acc0);
+        if (aw == 0) conv0_mfma<3, 4, 3>(smem, 4 + aw, l0, acc0);
+        else conv0_mfma<2, 4, 3>(smem, 4 + aw, l0, acc0);
       }
       if (more) {  // the next image's conv1 taps 0-7: under the epilogue (not carried through the conv0 loop: 96 registers)
 #pragma unroll
