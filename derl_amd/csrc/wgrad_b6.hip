@@ -170,19 +170,50 @@ __global__ __launch_bounds__(512) void conv_wgrad_b6_kernel(const WgradDirectArg
     if (t + 1 < nimg) fetch(blockIdx.x + (t + 1) * gridDim.x);
     __syncthreads();
 
+    // (K step, column tile) units in order; one scheduling region per unit: its 6 OCT MFMAs with the six transposed
+    // reads of the NEXT unit's input fragment interleaved, one read behind each of the first MFMAs (left to the
+    // compiler the reads sat in front of the MFMAs that use them and were waited for at once; as a burst they hold
+    // the wave's in-order stream while the LDS takes them: convstack_train.hip)
+    auto xoff = [&](int unit) {
+      const int ks = unit / G::CT, ct = ct_first + unit % G::CT, tap = ct / CPT, c0 = 16 * (ct % CPT);
+      return int2{xrow[ks][0] + (tap / G::KW) * G::RP + (tap % G::KW) * G::PX + 2 * c0,
+                  xrow[ks][1] + (tap / G::KW) * G::RP + (tap % G::KW) * G::PX + 2 * c0};
+    };
+    bf16x8 xf[3];
+    {
+      const int2 o = xoff(0);
+      b6_read(smem, o.x, o.y, Y::XPLANE, xf);
+    }
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) {
       bf16x8 gf[G::OCT][3];
 #pragma unroll
       for (int i = 0; i < G::OCT; ++i) b6_read(smem, grow[ks][0] + 32 * (oc_first + i), grow[ks][1] + 32 * (oc_first + i), Y::GPLANE, gf[i]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < G::CT; ++j) {
-        const int ct = ct_first + j, tap = ct / CPT, c0 = 16 * (ct % CPT);
-        const int toff = (tap / G::KW) * G::RP + (tap % G::KW) * G::PX + 2 * c0;
-        bf16x8 xf[3];
-        b6_read(smem, xrow[ks][0] + toff, xrow[ks][1] + toff, Y::XPLANE, xf);
+        const int unit = ks * G::CT + j;
+        bf16x8 xfn[3];
+        const bool more = unit + 1 < G::KS * G::CT;  // (compile-time after unrolling)
+        if (more) {
+          const int2 o = xoff(unit + 1);
+          b6_read(smem, o.x, o.y, Y::XPLANE, xfn);
+        }
 #pragma unroll
         for (int i = 0; i < G::OCT; ++i) acc[i][j] = b6_mac(acc[i][j], gf[i], xf);
+        if (more) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 6 * G::OCT - 6, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) xf[pl] = xfn[pl];
+        }
       }
     }
   }
