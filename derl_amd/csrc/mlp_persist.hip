@@ -56,9 +56,10 @@ constexpr int oW0 = 0, oW1 = oW0 + kH * kLd0, oW2 = oW1 + kH * kLd1, oB = oW2 + 
 // outputs (policy: mean d, value: row 0), like the operational layout
 constexpr int aW0 = 0, aB0 = aW0 + kH * kDP, aW1 = aB0 + kH, aB1 = aW1 + kH * kH, aW2 = aB1 + kH,
               aB2 = aW2 + kHeadLd * kH, kNetA = aB2 + kHeadLd;
-constexpr int kLogstdA = 2 * kNetA, kTotalA = kLogstdA + 32, kVecA = kTotalA / 4;
+constexpr int kLogstdA = 2 * kNetA, kTotalA = kLogstdA + 32;
 constexpr int kMaxMb = 64;
 constexpr unsigned kSpinLimit = 1u << 21;
+constexpr int kStampSlots = 16;  // A, barrier, B, barrier, C | A's stages: inputs, h1, h2, outputs, loss, three backward stages, slab
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 
 static_assert(kNetA % 4 == 0 && kTotalA % 4 == 0, "aligned layout in whole vec4");
@@ -82,14 +83,15 @@ struct PersistArgs {
   float *loss_out, *grad_norm_out;
   int grad_norm_stride;
   float *slabs, *gral;    // [G][kTotalA] partial gradients, [kTotalA] reduced gradient
-  float *moments;         // [G][2][kTotalA] every workgroup's own exp_avg / exp_avg_sq (aligned layout)
+  float *moments;         // [G][2][kTotalA] every workgroup's own exp_avg / exp_avg_sq (compact index)
+  unsigned *wtab;         // [G][kTotalA / 4] compact index -> LDS index of its first element | validity bits << 20 (written at epoch start)
   double *lossp, *sumsqp;  // [G][40], [G]
   unsigned *counter, *timeout, *sticky;
   unsigned *exits;         // workgroups that have left the launch: the last one out resets the barrier words
   unsigned *status_host;   // the caller's pinned status word as the device sees it (or NULL: copied behind the launch)
   unsigned spin_limit;
   int G;
-  unsigned long long *stamps;  // optional (DX_MLP_PERSIST_STAMPS=1): [G][5] 100 MHz ticks spent in A, barrier, B, barrier, C
+  unsigned long long *stamps;  // optional (DX_MLP_PERSIST_STAMPS=1): [G][kStampSlots] 100 MHz ticks spent in A, barrier, B, barrier, C and in A's stages
 };
 
 __device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
@@ -204,6 +206,42 @@ __device__ __forceinline__ Where locate(const PersistArgs &a, int v) {
   return w;
 }
 
+// The vec4 of the aligned layout that hold at least one real parameter, numbered 0 .. n - 1 in layout order (the
+// COMPACT index: config 3 has 2,870 of 4,184 -- observation columns 17 .. 31 and output rows 6 .. 31 / 1 .. 31 are
+// padding).  Phase B's slices, the reduced gradient and the moments live in this index space, so the exchange and
+// Adam touch no padding; the slabs keep the aligned layout (phase A's MFMA tiles dictate it).
+struct Compact { int nd4, net0, net1, total, div_mul; };
+__device__ __forceinline__ Compact compact_of(int D, int P) {
+  Compact c;
+  c.nd4 = (D + 3) >> 2;
+  const int common = kH * c.nd4 + kH / 4 + kH * kH / 4 + kH / 4;
+  c.net0 = common + (kH / 4) * P + ((P + 3) >> 2);
+  c.net1 = common + (kH / 4) + 1;
+  c.total = c.net0 + c.net1 + ((P + 3) >> 2);
+  c.div_mul = (65536 + c.nd4 - 1) / c.nd4;  // x / nd4 == (x * div_mul) >> 16 for x < 64 * 8
+  return c;
+}
+__device__ __forceinline__ int aligned_of(const Compact &c, int P, int i) {  // compact index -> aligned vec4 index
+  if (i >= c.net0 + c.net1) return kLogstdA / 4 + (i - c.net0 - c.net1);
+  const int net = i >= c.net0 ? 1 : 0, outs = net ? 1 : P;
+  int r = i - net * c.net0;
+  const int base = net * (kNetA / 4);
+  if (r < kH * c.nd4) {
+    const int j = (r * c.div_mul) >> 16;
+    return base + (aW0 + j * kDP) / 4 + (r - j * c.nd4);
+  }
+  r -= kH * c.nd4;
+  if (r < kH / 4) return base + aB0 / 4 + r;
+  r -= kH / 4;
+  if (r < kH * kH / 4) return base + aW1 / 4 + r;
+  r -= kH * kH / 4;
+  if (r < kH / 4) return base + aB1 / 4 + r;
+  r -= kH / 4;
+  if (r < (kH / 4) * outs) return base + aW2 / 4 + r;
+  r -= (kH / 4) * outs;
+  return base + aB2 / 4 + r;
+}
+
 // 16 k of a 16x16 tile: lane (l % 16, l / 16) holds 4 consecutive k of its A row / B column; MFMA t
 // contracts k = base + 4 * (l / 16) + t over the four lane groups
 __device__ __forceinline__ void mfma16(f32x4 &acc, const f32x4 a4, const f32x4 b4) {
@@ -236,7 +274,8 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
   int *dead = reinterpret_cast<int *>(coef_s + 4);
   float *sched = reinterpret_cast<float *>(dead + 4);        // [2][kMaxMb] step size, sqrt(1 - beta2^t)
   float *sig = sched + 2 * kMaxMb;                           // [3][32] sigma, sigma^2, log sigma of this minibatch
-  double *lred = reinterpret_cast<double *>(sig + 96);       // [8 + 31][R] per-row loss terms, summed by 8 + P lanes
+  float *norm_s = sig + 96;                                  // [2][kMaxMb] mean, sqrt(var) + eps of every minibatch's advantages
+  double *lred = reinterpret_cast<double *>(norm_s + 2 * kMaxMb);  // [8 + 31][R] per-row loss terms
   float *comb = hs;  // phase B staging (activations are dead then)
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -265,10 +304,25 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
       sched[kMaxMb + i] = a.bc2_sqrt[i];
     }
   }
+  if (t < a.nmb) {  // adv_apply_kernel's expression on the precomputed float64 sums, once per epoch
+    float meanf = 0.f, denom = 1.f;
+    if (a.normalize) {
+      const double cnt = a.stats[3 * t + 2], mean = a.stats[3 * t] / cnt;
+      double var = a.stats[3 * t + 1] / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      meanf = static_cast<float>(mean);
+      denom = static_cast<float>(sqrt(var)) + a.norm_eps;
+    }
+    norm_s[t] = meanf;
+    norm_s[kMaxMb + t] = denom;
+  }
   __syncthreads();
   float *mom = a.moments + static_cast<long long>(wg) * 2 * kTotalA;  // this workgroup's exp_avg | exp_avg_sq
+  unsigned *wtab = a.wtab + static_cast<long long>(wg) * (kTotalA / 4);
+  const Compact cx = compact_of(D, P);
 #pragma unroll 1
-  for (int v = t; v < kVecA; v += kT) {
+  for (int ci = t; ci < cx.total; ci += kT) {
+    const int v = aligned_of(cx, P, ci);
     const Where w = locate(a, v);
     f32x4 m4{0.f, 0.f, 0.f, 0.f}, v4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -278,10 +332,22 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
         m4[q] = a.exp_avg[w.canon + q];
         v4[q] = a.exp_avg_sq[w.canon + q];
       }
-    *reinterpret_cast<f32x4 *>(mom + 4 * v) = m4;
-    *reinterpret_cast<f32x4 *>(mom + kTotalA + 4 * v) = v4;
+    *reinterpret_cast<f32x4 *>(mom + 4 * ci) = m4;
+    *reinterpret_cast<f32x4 *>(mom + kTotalA + 4 * ci) = v4;
+    wtab[ci] = static_cast<unsigned>(w.lds) | (w.mask << 20);  // phase C reads it beside the moments instead of recomputing it
   }
   __syncthreads();
+  // phase B's per-thread constants (the slice of the compact index this workgroup sums, its slab groups)
+  const int VB = (cx.total + G - 1) / G;   // vec4 (compact index) per workgroup
+  const int NG = kT / VB;                  // slab groups working side by side
+  const int chunk = (G + NG - 1) / NG;     // slabs per group
+  const int b_vi = t % VB, b_sg = t / VB;
+  const bool b_on = b_sg < NG && wg * VB + b_vi < cx.total;
+  const unsigned b_off = b_on ? 16u * static_cast<unsigned>(aligned_of(cx, P, wg * VB + b_vi)) : 0u;
+  const int b_s0 = b_sg * chunk, b_s1 = b_s0 + chunk < G ? b_s0 + chunk : G;
+  const bool q_on = t < VB && wg * VB + t < cx.total;
+  const int q_c = wg * VB + t, q_v = q_on ? aligned_of(cx, P, q_c) : 0;
+  const unsigned q_mask = q_on ? locate(a, q_v).mask : 0u;
 
   const float *W0 = Wl + net * kNetLds + oW0, *W1 = Wl + net * kNetLds + oW1, *W2 = Wl + net * kNetLds + oW2;
   const float *bs = Wl + net * kNetLds + oB;
@@ -289,26 +355,57 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
   float *dsn = ds + net * kR * kLd0;  // dL/d(this net's outputs)
   const int l16 = lane & 15, kq = 4 * (lane >> 4);  // MFMA lane coordinates: row / column in the tile, k group
   unsigned arrivals = 0;
-  unsigned long long tk[5] = {0, 0, 0, 0, 0}, t_prev = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  unsigned long long tk[kStampSlots] = {}, t_prev = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0, t_sub = t_prev;
 #define DX_STAMP(i)                                                         \
   if (a.stamps) {                                                           \
     const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();       \
     tk[i] += now_ - t_prev;                                                 \
     t_prev = now_;                                                          \
+    t_sub = now_;                                                           \
   }
+#define DX_SUBSTAMP(i)                                                      \
+  if (a.stamps) {                                                           \
+    const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();       \
+    tk[i] += now_ - t_sub;                                                  \
+    t_sub = now_;                                                           \
+  }
+
+  // A tile's inputs wait in registers from one tile (or one minibatch) ahead: 2 + 2 floats per thread, 4 more for the
+  // first kR threads.  Loaded at the top of phase A they were 3.0 us of a 17 us phase (DX_MLP_PERSIST_STAMPS).
+  static_assert(kR * kDP == 2 * kT && kR * 32 == 2 * kT, "two observation / action elements per thread");
+  float pre_x[2], pre_a[2], pre_r[4];
+  int pre_k = -1, pre_tile = -1;
+  auto fetch = [&](int fk, int ftile) {
+    pre_k = fk; pre_tile = ftile;
+    const long long fstart = static_cast<long long>(fk) * a.mbsize;
+    const long long fend = a.samples - fstart < a.mbsize ? a.samples : fstart + a.mbsize;
+    const long long frow0 = fstart + static_cast<long long>(ftile) * kR;
+    const int frows = static_cast<int>(fend - frow0 < kR ? (fend - frow0 > 0 ? fend - frow0 : 0) : kR);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = t + u * kT, r = i / kDP, c = i - r * kDP;  // (kDP == 32: the same (row, column) for both arrays)
+      pre_x[u] = (r < frows && c < D) ? a.obs[(frow0 + r) * D + c] : 0.f;
+      pre_a[u] = (r < frows && c < P) ? a.actions[(frow0 + r) * P + c] : 0.f;
+    }
+    if (t < kR) {
+      const bool ok = t < frows;
+      pre_r[0] = (ok && a.mode == 0) ? a.old_lp[frow0 + t] : 0.f;
+      pre_r[1] = ok ? a.adv[frow0 + t] : 0.f;
+      pre_r[2] = (ok && a.mode == 0) ? a.old_v[frow0 + t] : 0.f;
+      pre_r[3] = ok ? a.vt[frow0 + t] : 0.f;
+    }
+  };
+  fetch(0, wg);
+  // the loss stage's sums over a tile's rows: 8 + P terms, each split over 4 / 2 / 1 lanes of wave 0 (one lane per term
+  // read its 32 rows one after the other: 1.4 us of dependent LDS reads per update)
+  const int lparts = 8 + P <= 16 ? 4 : (8 + P <= 32 ? 2 : 1);
+  const int lterm = lane / lparts, lpart = lane % lparts;
 
   for (int k = 0; k < a.nmb; ++k) {
     const long long start = static_cast<long long>(k) * a.mbsize;
     const int Bk = static_cast<int>(a.samples - start < a.mbsize ? a.samples - start : a.mbsize);
     const float inv_batch = 1.0f / static_cast<float>(Bk);
-    float meanf = 0.f, denom = 1.f;
-    if (a.normalize) {  // adv_apply_kernel's expression on the precomputed float64 sums
-      const double cnt = a.stats[3 * k + 2], mean = a.stats[3 * k] / cnt;
-      double var = a.stats[3 * k + 1] / cnt - mean * mean;
-      if (var < 0.0) var = 0.0;
-      meanf = static_cast<float>(mean);
-      denom = static_cast<float>(sqrt(var)) + a.norm_eps;
-    }
+    const float meanf = norm_s[k], denom = norm_s[kMaxMb + k];
     if (t < P) {  // the Gaussian's per-dimension constants, once per minibatch instead of per row
       const float sigma = expf(logstd_s[t]);
       sig[t] = sigma; sig[32 + t] = sigma * sigma; sig[64 + t] = logf(sigma);
@@ -322,33 +419,38 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
     for (int q = 0; q < 2; ++q) { aw0[q] = zero4; aw2[q] = zero4; }
 #pragma unroll
     for (int q = 0; q < 4; ++q) aw1[q] = zero4;
-    double lacc = 0.0;  // wave 0: lane i < 8 keeps loss sum i, lane 8 + d keeps dL/dlogstd[d]
+    double lacc = 0.0;  // wave 0, lanes with lpart == 0: term i < 8 is loss sum i, term 8 + d is dL/dlogstd[d]
     const int ntiles = (Bk + kR - 1) / kR;
     for (int tile = wg; tile < ntiles; tile += G) {
       const long long row0 = start + static_cast<long long>(tile) * kR;
       const int rows = static_cast<int>(start + Bk - row0 < kR ? start + Bk - row0 : kR);
+      if (!(pre_k == k && pre_tile == tile)) fetch(k, tile);  // (not the tile that was fetched ahead: cannot happen with the order below)
       __syncthreads();  // the previous tile's readers are done
-      for (int i = t; i < kR * kDP; i += kT) {
-        const int r = i / kDP, c = i - r * kDP;
-        xs[r * kLd0 + c] = (r < rows && c < D) ? a.obs[(row0 + r) * D + c] : 0.f;
-      }
-      for (int i = t; i < kR * 32; i += kT) {
-        const int r = i >> 5, c = i & 31;
-        act[i] = (r < rows && c < P) ? a.actions[(row0 + r) * P + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < kR * kDP / kT; ++u) {
+        const int i = t + u * kT, r = i / kDP, c = i - r * kDP;
+        xs[r * kLd0 + c] = pre_x[u];
+        act[i] = pre_a[u];
       }
       if (t < kR) {
         const bool ok = t < rows;
-        float adv = ok ? a.adv[row0 + t] : 0.f;
+        float adv = pre_r[1];
         if (a.normalize && ok) {
           adv = (adv - meanf) / denom;
           a.adv_norm[row0 + t] = adv;
         }
         rowv[kR + t] = adv;
-        rowv[t] = (ok && a.mode == 0) ? a.old_lp[row0 + t] : 0.f;
-        rowv[2 * kR + t] = (ok && a.mode == 0) ? a.old_v[row0 + t] : 0.f;
-        rowv[3 * kR + t] = ok ? a.vt[row0 + t] : 0.f;
+        rowv[t] = pre_r[0];
+        rowv[2 * kR + t] = pre_r[2];
+        rowv[3 * kR + t] = pre_r[3];
+      }
+      {  // the NEXT tile's rows (this minibatch's, or the next minibatch's first) are in flight under this tile's work
+        int nk = k, ntile = tile + G;
+        if (ntile >= ntiles) { nk = k + 1; ntile = wg; }
+        if (nk < a.nmb) fetch(nk, ntile);
       }
       __syncthreads();
+      DX_SUBSTAMP(5)
       // ---- forward, both nets side by side (waves 0-3 / 4-7); wave wn owns output columns 16 wn .. 16 wn + 15 ----
       {  // h1 = tanh(x W0^T + b0): 32 x 64, K = 32
         f32x4 c0 = zero4, c1 = zero4;
@@ -366,6 +468,7 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
         }
       }
       __syncthreads();
+      DX_SUBSTAMP(6)
       {  // h2 = tanh(h1 W1^T + b1): 32 x 64, K = 64
         f32x4 c0 = zero4, c1 = zero4;
 #pragma unroll
@@ -382,6 +485,7 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
         }
       }
       __syncthreads();
+      DX_SUBSTAMP(7)
       {  // outputs = h2 W2^T + b2: 32 x 32 (padded), K = 64; wave wn: rows 16 (wn >> 1) .., columns 16 (wn & 1) ..
         const int mt = wn >> 1, nt = wn & 1;
         f32x4 c0 = zero4;
@@ -396,6 +500,7 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
         }
       }
       __syncthreads();
+      DX_SUBSTAMP(8)
       if (wave == 0) {  // ---- Gaussian PPO / A2C loss, one lane per row (heads.hip: normal_loss_kernel) ----
         const int b = lane;
         const bool row_ok = b < rows;
@@ -463,13 +568,16 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
           for (int i = 0; i < 8; ++i) lred[i * kR + rb] = s[i];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave: the rows' terms are in LDS
-        if (lane < 8 + P) {  // lane i sums term i over the tile's rows, in row order
+        {  // lane (term, part) sums its share of the tile's rows in row order, the parts meet pairwise: a fixed order
           double tot = 0.0;
-          for (int r = 0; r < kR; ++r) tot += lred[lane * kR + r];
+          if (lterm < 8 + P)
+            for (int r = lpart * (kR / lparts); r < (lpart + 1) * (kR / lparts); ++r) tot += lred[lterm * kR + r];
+          for (int o = 1; o < lparts; o <<= 1) tot += __shfl_xor(tot, o);
           lacc += tot;
         }
       }
       __syncthreads();
+      DX_SUBSTAMP(9)
       // ---- backward of both nets; contraction over the tile's 32 rows for the weight gradients ----
       {  // dW2^T: T[j][o] = sum_m h2[m][j] dout[m][o]  (wave: j tile wn, o tiles 0 / 1)
 #pragma unroll
@@ -496,6 +604,7 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
         }
       }
       __syncthreads();
+      DX_SUBSTAMP(10)
       {  // dW1^T: T[j][i] = sum_m h1[m][j] g2[m][i]  (wave: j tile wn, i tiles 0..3)
 #pragma unroll
         for (int m0 = 0; m0 < kR; m0 += 16) {
@@ -521,6 +630,7 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
         }
       }
       __syncthreads();
+      DX_SUBSTAMP(11)
       {  // dW0^T: T[k][j] = sum_m x[m][k] g1[m][j]  (wave: j tile wn, k tiles 0 / 1)
 #pragma unroll
         for (int m0 = 0; m0 < kR; m0 += 16) {
@@ -532,6 +642,7 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
           for (int r = 0; r < kR; ++r) ab0 += g1s[r * kLd1 + tn];
       }
     }
+    DX_SUBSTAMP(12)
     {  // ---- this workgroup's partial gradient -> its slab (write-through, 16 bytes per store) ----
       const unsigned sb = (static_cast<unsigned>(wg) * kTotalA + net * kNetA) * 4u;
 #pragma unroll
@@ -541,8 +652,8 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
       for (int it = 0; it < 4; ++it)  // T[j = 16 wn + kq + r][i = 16 it + l16] = dW1[i][j]
         st16(r_slab, sb + (aW1 + (16 * it + l16) * kH + 16 * wn + kq) * 4u, aw1[it]);
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot)  // T[j = 16 wn + kq + r][o = 16 ot + l16] = dW2[o][j]
-        st16(r_slab, sb + (aW2 + (16 * ot + l16) * kH + 16 * wn + kq) * 4u, aw2[ot]);
+      for (int ot = 0; ot < 2; ++ot)  // T[j = 16 wn + kq + r][o = 16 ot + l16] = dW2[o][j]; only this net's real outputs
+        if (16 * ot + l16 < outs) st16(r_slab, sb + (aW2 + (16 * ot + l16) * kH + 16 * wn + kq) * 4u, aw2[ot]);
       if (tn < kH) {
         st4(r_slab, sb + (aB0 + tn) * 4u, ab0);
         st4(r_slab, sb + (aB1 + tn) * 4u, ab1);
@@ -550,47 +661,41 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
       if (tn < kHeadLd) st4(r_slab, sb + (aB2 + tn) * 4u, ab2);
       if (wave == 0) {
         double *lp_ = a.lossp + static_cast<long long>(wg) * 40;
-        if (lane < 8 + P) st_d(lp_ + lane, lacc);
+        if (lpart == 0 && lterm < 8 + P) st_d(lp_ + lterm, lacc);
       }
     }
+    DX_SUBSTAMP(13)
     DX_STAMP(0)
     grid_barrier(a, (++arrivals) * static_cast<unsigned>(G), dead, 1u + 2u * k);
     DX_STAMP(1)
 
     // ================= phase B: slice `wg` of the gradient, summed over all slabs =================
     {
-      const int VB = (kVecA + G - 1) / G;   // vec4 per workgroup
-      const int NG = kT / VB;               // slab groups working side by side
-      const int chunk = (G + NG - 1) / NG;  // slabs per group
-      const int vi = t % VB, sg = t / VB, v = wg * VB + vi;
       f32x4 acc{0.f, 0.f, 0.f, 0.f};
-      if (sg < NG && v < kVecA) {
-        const int s0 = sg * chunk, s1 = s0 + chunk < G ? s0 + chunk : G;
+      if (b_on) {
 #pragma unroll 1
-        for (int s = s0; s < s1; s += 5) {  // five loads in flight, added in slab order
-          f32x4 x[5];
+        for (int s = b_s0; s < b_s1; s += 6) {  // six loads in flight (config 3: a group's whole share), added in slab order
+          f32x4 x[6];
 #pragma unroll
-          for (int u = 0; u < 5; ++u)
-            x[u] = s + u < s1 ? ld16(r_slab, (static_cast<unsigned>(s + u) * kTotalA + 4u * v) * 4u) : f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int u = 0; u < 6; ++u)
+            x[u] = s + u < b_s1 ? ld16(r_slab, static_cast<unsigned>(s + u) * (kTotalA * 4u) + b_off) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int u = 0; u < 5; ++u) acc += x[u];
+          for (int u = 0; u < 6; ++u) acc += x[u];
         }
-        *reinterpret_cast<f32x4 *>(comb + (sg * VB + vi) * 4) = acc;
+        *reinterpret_cast<f32x4 *>(comb + (b_sg * VB + b_vi) * 4) = acc;
       }
       __syncthreads();
       double sq = 0.0;
-      if (t < VB && wg * VB + t < kVecA) {
-        const int vq = wg * VB + t;
+      if (q_on) {
         f32x4 g{0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < NG; ++s) g += *reinterpret_cast<const f32x4 *>(comb + (s * VB + t) * 4);
-        const Where w = locate(a, vq);
-        if (vq >= kLogstdA / 4) g = f32x4{0.f, 0.f, 0.f, 0.f};  // dL/dlogstd comes from the loss partials below
+        if (q_v >= kLogstdA / 4) g = f32x4{0.f, 0.f, 0.f, 0.f};  // dL/dlogstd comes from the loss partials below
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          if (!((w.mask >> q) & 1u)) g[q] = 0.f;  // padding columns / the other net's head rows
+          if (!((q_mask >> q) & 1u)) g[q] = 0.f;  // padding columns
           sq += static_cast<double>(g[q]) * g[q];
         }
-        if (vq < kLogstdA / 4) st16(r_gral, 16u * vq, g);
+        if (q_v < kLogstdA / 4) st16(r_gral, 16u * q_c, g);
       }
       if (wg == G - 1) {  // the last workgroup (shortest slice): loss terms and dL/dlogstd of the minibatch
         __syncthreads();
@@ -598,7 +703,13 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
         const int j = t % 40, pg = t / 40;  // 12 groups of slabs side by side
         if (pg < 12) {
           const int ch = (G + 11) / 12, s0 = pg * ch, s1 = s0 + ch < G ? s0 + ch : G;
-          for (int s = s0; s < s1; ++s) part += ld_d(a.lossp + static_cast<long long>(s) * 40 + j);
+          for (int s = s0; s < s1; s += 4) {  // four loads in flight, added in slab order
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = s + u < s1 ? ld_d(a.lossp + static_cast<long long>(s + u) * 40 + j) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part += x[u];
+          }
         }
         double *stage = reinterpret_cast<double *>(comb);
         if (pg < 12) stage[pg * 40 + j] = part;
@@ -609,7 +720,7 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
           redd[t] = tot;
           if (t >= 8 && t - 8 < P) {
             const float dl = static_cast<float>(tot);
-            st4(r_gral, (kLogstdA + (t - 8)) * 4u, dl);
+            st4(r_gral, (4 * (cx.net0 + cx.net1) + (t - 8)) * 4u, dl);
             sq += static_cast<double>(dl) * dl;
           }
         }
@@ -676,11 +787,13 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
       const bool write_back = coef_s[1] != 0.f;
       constexpr int kBatch = 3;  // vec4 per lane per round: 9 loads in flight
 #pragma unroll 1
-      for (int v0 = t; v0 < kVecA; v0 += kBatch * kT) {
+      for (int v0 = t; v0 < cx.total; v0 += kBatch * kT) {  // compact indices
         f32x4 g4[kBatch], m4[kBatch], v4[kBatch];
+        unsigned wp[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-          const int v = v0 + u * kT < kVecA ? v0 + u * kT : t;  // (a valid address; the result is not used)
+          const int v = v0 + u * kT < cx.total ? v0 + u * kT : t;  // (a valid address; the result is not used)
+          wp[u] = wtab[v];
           g4[u] = ld16(r_gral, 16u * v);
           m4[u] = *reinterpret_cast<const f32x4 *>(mom + 4 * v);
           v4[u] = *reinterpret_cast<const f32x4 *>(mom + kTotalA + 4 * v);
@@ -688,11 +801,14 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
           const int v = v0 + u * kT;
-          if (v < kVecA) {
-            const Where w = locate(a, v);  // a few dozen integer instructions
+          if (v < cx.total) {
+            const int w_lds = static_cast<int>(wp[u] & 0xfffffu);
+            const unsigned w_mask = wp[u] >> 20;
+            long long w_canon = 0;
+            if (write_back) w_canon = locate(a, aligned_of(cx, P, v)).canon;  // (workgroup 0, the epoch's last update)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if ((w.mask >> q) & 1u) {  // elementwise.hip: adam_one
+              if ((w_mask >> q) & 1u) {  // elementwise.hip: adam_one
                 const float g = g4[u][q] * coef;
                 m4[u][q] = m4[u][q] * a.beta1 + g * a.omb1;
                 v4[u][q] = v4[u][q] * a.beta2 + (g * g) * a.omb2;
@@ -700,13 +816,13 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
                 // 3e-4 -- far below the float32 spacing of the parameter it is added to -- and every workgroup
                 // computes the same bits; the IEEE sequences cost 5 us per update here (33 elements per lane)
                 const float den = __builtin_amdgcn_sqrtf(v4[u][q]) * inv_bc2 + a.eps;
-                const float pnew = Wl[w.lds + q] - step_size * (m4[u][q] * __builtin_amdgcn_rcpf(den));
-                Wl[w.lds + q] = pnew;
+                const float pnew = Wl[w_lds + q] - step_size * (m4[u][q] * __builtin_amdgcn_rcpf(den));
+                Wl[w_lds + q] = pnew;
                 if (write_back) {  // epoch end: one workgroup writes the model, the moments and the clipped gradient back
-                  a.params[w.canon + q] = pnew;
-                  a.exp_avg[w.canon + q] = m4[u][q];
-                  a.exp_avg_sq[w.canon + q] = v4[u][q];
-                  a.grads[w.canon + q] = g;
+                  a.params[w_canon + q] = pnew;
+                  a.exp_avg[w_canon + q] = m4[u][q];
+                  a.exp_avg_sq[w_canon + q] = v4[u][q];
+                  a.grads[w_canon + q] = g;
                 }
               }
             *reinterpret_cast<f32x4 *>(mom + 4 * v) = m4[u];
@@ -719,8 +835,9 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
     DX_STAMP(4)
   }
 #undef DX_STAMP
+#undef DX_SUBSTAMP
   if (a.stamps && t == 0)
-    for (int i = 0; i < 5; ++i) a.stamps[wg * 5 + i] = tk[i];
+    for (int i = 0; i < kStampSlots; ++i) a.stamps[wg * kStampSlots + i] = tk[i];
   if (gave_up(a, dead)) {  // a barrier gave up: NaN losses, and the workspace is poisoned for good
     if (wg == G - 1 && t < 8 * a.nmb) a.loss_out[t] = __builtin_nanf("");
     if (t == 0) {  // (every workgroup that saw the give-up writes the same word: to the workspace and to the host's status word)
@@ -744,15 +861,15 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
 }
 
 size_t persist_lds_bytes() {
-  return sizeof(float) * (2 * kNetLds + 32) + sizeof(float) * (kR * kLd0 + 6 * kR * kLd1 + 3 * kR * kLd0 + kR * 32 + 4 * kR) + 64 * sizeof(double) + 32 + 2 * kMaxMb * sizeof(float) + 96 * sizeof(float) + 39 * kR * sizeof(double);
+  return sizeof(float) * (2 * kNetLds + 32) + sizeof(float) * (kR * kLd0 + 6 * kR * kLd1 + 3 * kR * kLd0 + kR * 32 + 4 * kR) + 64 * sizeof(double) + 32 + 4 * kMaxMb * sizeof(float) + 96 * sizeof(float) + 39 * kR * sizeof(double);
 }
 
 }  // namespace
 
 // workspace: [64 B barrier words][gral kTotalA floats][slabs G x kTotalA floats][moments G x 2 x kTotalA floats]
-// [lossp G x 40 doubles][sumsqp G doubles]
+// [lossp G x 40 doubles][sumsqp G doubles][wtab G x kTotalA / 4 words]
 long long mlp_persist_workspace_bytes(int G) {
-  return 64 + 4LL * kTotalA + 4LL * G * kTotalA + 8LL * G * kTotalA + 8LL * G * 40 + 8LL * G + 64;
+  return 64 + 4LL * kTotalA + 4LL * G * kTotalA + 8LL * G * kTotalA + 8LL * G * 40 + 8LL * G + 64 + 1LL * G * kTotalA;
 }
 
 // number of workgroups for minibatches of `mbsize` rows; 0 = not covered (the caller keeps the
@@ -851,11 +968,12 @@ int launch_mlp_persist_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, int G, 
   a.moments = a.slabs + static_cast<long long>(G) * kTotalA;
   a.lossp = reinterpret_cast<double *>(a.moments + 2LL * G * kTotalA);
   a.sumsqp = a.lossp + static_cast<long long>(G) * 40;
+  a.wtab = reinterpret_cast<unsigned *>(a.sumsqp + G + 8);  // (64 bytes behind the partials)
   a.G = G;
   static const bool want_stamps = getenv("DX_MLP_PERSIST_STAMPS") && atoi(getenv("DX_MLP_PERSIST_STAMPS")) != 0;
   unsigned long long *stamps_dev = nullptr;
   if (want_stamps) {
-    DX_HIP(hipMalloc(&stamps_dev, sizeof(unsigned long long) * 5 * G));
+    DX_HIP(hipMalloc(&stamps_dev, sizeof(unsigned long long) * kStampSlots * G));
     a.stamps = stamps_dev;
   }
   if (e->normalize) {  // every minibatch's {sum, sumsq, n} in one launch (bit-identical to the per-minibatch kernel)
@@ -874,15 +992,24 @@ int launch_mlp_persist_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, int G, 
     DX_HIP(hipMemcpyAsync(e->status_host, a.sticky, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
   if (want_stamps) {  // measurement aid (synchronous): where an epoch's time goes, per update
     DX_HIP(hipStreamSynchronize(stream));
-    std::vector<unsigned long long> h(5 * G);
-    DX_HIP(hipMemcpy(h.data(), stamps_dev, sizeof(unsigned long long) * 5 * G, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h(static_cast<size_t>(kStampSlots) * G);
+    DX_HIP(hipMemcpy(h.data(), stamps_dev, sizeof(unsigned long long) * kStampSlots * G, hipMemcpyDeviceToHost));
     DX_HIP(hipFree(stamps_dev));
-    double mean[5] = {0, 0, 0, 0, 0};
+    double mean[kStampSlots] = {}, hi[kStampSlots] = {};
     for (int w = 0; w < G; ++w)
-      for (int i = 0; i < 5; ++i) mean[i] += h[5 * w + i] * 0.01 / G / a.nmb;
-    fprintf(stderr, "[mlp_persist G=%d nmb=%d] per update, mean over workgroups: A %.2f us, barrier %.2f, B %.2f, barrier %.2f, C %.2f "
-            "(workgroup 0: %.2f %.2f %.2f %.2f %.2f)\n", G, a.nmb, mean[0], mean[1], mean[2], mean[3], mean[4],
-            h[0] * 0.01 / a.nmb, h[1] * 0.01 / a.nmb, h[2] * 0.01 / a.nmb, h[3] * 0.01 / a.nmb, h[4] * 0.01 / a.nmb);
+      for (int i = 0; i < kStampSlots; ++i) {
+        const double us = h[static_cast<size_t>(kStampSlots) * w + i] * 0.01 / a.nmb;
+        mean[i] += us / G;
+        if (us > hi[i]) hi[i] = us;
+      }
+    const unsigned long long *last = &h[static_cast<size_t>(kStampSlots) * (G - 1)];
+    fprintf(stderr, "[mlp_persist G=%d nmb=%d] per update, mean over workgroups (max): A %.2f (%.2f) us, barrier %.2f (%.2f), B %.2f (%.2f), "
+            "barrier %.2f (%.2f), C %.2f (%.2f); last workgroup: %.2f %.2f %.2f %.2f %.2f\n", G, a.nmb, mean[0], hi[0], mean[1], hi[1],
+            mean[2], hi[2], mean[3], hi[3], mean[4], hi[4], last[0] * 0.01 / a.nmb, last[1] * 0.01 / a.nmb, last[2] * 0.01 / a.nmb,
+            last[3] * 0.01 / a.nmb, last[4] * 0.01 / a.nmb);
+    fprintf(stderr, "[mlp_persist] A's stages, mean (max): inputs %.2f (%.2f), h1 %.2f (%.2f), h2 %.2f (%.2f), outputs %.2f (%.2f), loss %.2f (%.2f), "
+            "backward 2 %.2f (%.2f), backward 1 %.2f (%.2f), backward 0 %.2f (%.2f), slab %.2f (%.2f)\n", mean[5], hi[5], mean[6], hi[6],
+            mean[7], hi[7], mean[8], hi[8], mean[9], hi[9], mean[10], hi[10], mean[11], hi[11], mean[12], hi[12], mean[13], hi[13]);
   }
   return DX_OK;
 }
