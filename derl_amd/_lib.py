@@ -218,7 +218,7 @@ class CnnEpoch(ctypes.Structure):
       ("npartials", c_int), ("state0", c_void_p), ("state1", c_void_p),
       ("sumsq_partials", c_void_p), ("loss_partials", c_void_p),
       ("loss_partials_capacity", c_int), ("grad_norm_stride", c_int),
-      ("mirrors_current", c_int), ("reserved0", c_int), ("loss_counter", c_void_p),
+      ("mirrors_current", c_int), ("more_epochs", c_int), ("loss_counter", c_void_p),
       ("max_grad_norm", c_double), ("lr", c_double), ("beta1", c_double), ("beta2", c_double),
       ("opt_eps", c_double), ("first_step", c_longlong), ("grad_norm_out", c_void_p),
       ("loss_out", c_void_p)]

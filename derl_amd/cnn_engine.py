@@ -36,6 +36,7 @@ class CnnEngine:
     self._backward_allocated = False
     ctx.params, ctx.grads, ctx.packed = (t.data_ptr() for t in (self.params, self.grads, self.packed))
     self._packed_version = None
+    self._train_packed_version = None  # see ppo_epoch: only the training kernels' mirrors are current
     self._watched = [self.params]
     self.shapes = self._param_shapes()
 
@@ -106,6 +107,7 @@ class CnnEngine:
 
   def mark_dirty(self):
     self._packed_version = None
+    self._train_packed_version = None
 
   def watch(self, tensors):
     """Registers tensors that alias the flat parameter buffer with their OWN version counter
@@ -307,14 +309,22 @@ class CnnEngine:
     else:
       e.grad_norm_out, e.grad_norm_stride = optimizer.grad_norm.data_ptr(), 0
     e.loss_out = context.losses.data_ptr()
-    e.mirrors_current = int(self._packed_version == self._version())
+    # every mirror current: 1; only the training kernels' (the previous epoch of this rollout ended with the light
+    # pack): 2; neither: the call packs before its first minibatch
+    version = self._version()
+    e.mirrors_current = 1 if self._packed_version == version else (2 if self._train_packed_version == version else 0)
+    e.more_epochs = int(bool(getattr(context, "more_epochs", False)))
     e.loss_counter = self._loss_counter().data_ptr() if self.fused_heads() else None
     keep = (obs, index, actions, old_lp, old_v, adv, vt, stats_ready)  # alive until enqueued
     _lib.call("dx_cnn_ppo_epoch", ctypes.byref(self.ctx), ctypes.byref(e), _lib.stream_ptr(dev))
     del keep
     if record_norms:
       optimizer.grad_norm.copy_(context.grad_norms[-1:])
-    self._packed_version = self._version()  # every update inside the call is followed by dx_cnn_pack
+    # every update inside the call is followed by a pack: of every mirror, or -- when another epoch of the same
+    # rollout follows -- of what the training kernels read only (anything else packs first: _ensure_packed)
+    # (the native steps write through raw pointers: torch's version counters do not move, the marks are set by hand)
+    self._train_packed_version = self._version()
+    self._packed_version = None if e.more_epochs else self._train_packed_version
     return updates
 
   @property

@@ -64,6 +64,8 @@ static int epoch_body(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream, 
   DX_REQUIRE(e->optimizer == 1 || (e->optimizer == 0 && e->state1), "dx_cnn_ppo_epoch: optimizer 0 = Adam (two "
              "state buffers), 1 = RMSprop");
   DX_REQUIRE(e->world >= 1, "dx_cnn_ppo_epoch: world < 1");
+  DX_REQUIRE((e->more_epochs == 0 || e->more_epochs == 1) && e->mirrors_current >= 0 && e->mirrors_current <= 2,
+             "dx_cnn_ppo_epoch: more_epochs must be 0 / 1 and mirrors_current 0 / 1 / 2");
   DX_REQUIRE(!e->allreduce || comm_active(), "dx_cnn_ppo_epoch: allreduce requested without a communicator "
              "(dx_comm_init)");
   DX_REQUIRE(e->loss_partials_capacity >= 8 * ((e->mbsize + 7) / 8), "dx_cnn_ppo_epoch: loss_partials too small");
@@ -184,7 +186,8 @@ static int epoch_body(const dx_cnn_ctx *c, const dx_cnn_epoch *e, void *stream, 
         return rc;
     }
     // the mirrors follow every update (after the last one: everything, the next rollout can act at once)
-    if (int rc = cnn_pack_between_updates(c, !more || !fused_heads, e->obs_is_u8, s)) return rc;
+    // (more_epochs: the next call is another epoch of this rollout -- its kernels read what a minibatch of this one reads)
+    if (int rc = cnn_pack_between_updates(c, (!more && e->more_epochs == 0) || !fused_heads, e->obs_is_u8, s)) return rc;
   }
   return DX_OK;
 }

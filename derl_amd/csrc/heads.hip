@@ -855,6 +855,30 @@ __global__ __launch_bounds__(64 * kTlWaves) void tail_loss_kernel(const TailLoss
   const int A = a.A, NJ = A + 1, lds_rows = NJ < kTailLdsRows ? NJ : kTailLdsRows;
   double *lsum = reinterpret_cast<double *>(tl_smem + (lds_rows < 8 ? 8 : lds_rows) * kTailK);
   const LossParams lparams{a.A, a.mode, a.stats != nullptr, a.cliprange, a.value_loss_coef, a.entropy_coef, a.inv_batch};
+  const int row_begin = blockIdx.x * a.rows_per_wg;
+  const int row_end = min(a.B, row_begin + a.rows_per_wg);
+  constexpr int kAhead = 2;  // rows per wave and pass: every Wc fragment read from LDS serves both
+  // A pass's rows are loaded one pass AHEAD -- the first pass's before Wc is staged, so that the two streams of loads
+  // overlap (at minibatch 1,024 a workgroup has ONE pass: its y2 loads used to start behind the staging barrier)
+  float4 y[kAhead][kTailQ];
+  float yt[kAhead], p_adv[kAhead], p_vt[kAhead], p_olp[kAhead], p_ov[kAhead];
+  int p_act[kAhead];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int row = min(r0 + kTlWaves * u, a.B - 1);
+      const float *base = a.y2 + static_cast<long long>(row) * kTailK;
+#pragma unroll
+      for (int q = 0; q < kTailQ; ++q) y[u][q] = reinterpret_cast<const float4 *>(base)[lane + 64 * q];
+      yt[u] = base[64 * 4 * kTailQ + lane];
+      p_act[u] = static_cast<int>(a.actions[row]);
+      p_adv[u] = a.advantages[row];
+      p_vt[u] = a.value_targets[row];
+      p_olp[u] = a.mode == 0 ? a.old_log_prob[row] : 0.f;
+      p_ov[u] = a.mode == 0 ? a.old_values[row] : 0.f;
+    }
+  };
+  if (row_begin + wave < row_end) fetch(row_begin + wave);
   for (int i = threadIdx.x; i < lds_rows * (kTailK / 4); i += 64 * kTlWaves)
     reinterpret_cast<float4 *>(tl_smem)[i] = reinterpret_cast<const float4 *>(a.Wc)[i];
   const float bias_col = col <= A ? a.beff[col] : 0.f;
@@ -869,47 +893,35 @@ __global__ __launch_bounds__(64 * kTlWaves) void tail_loss_kernel(const TailLoss
   __syncthreads();
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool is_logit = col < A;
-  const int row_begin = blockIdx.x * a.rows_per_wg;
-  const int row_end = min(a.B, row_begin + a.rows_per_wg);
-  constexpr int kAhead = 2;  // rows per wave and pass: every Wc fragment read from LDS serves both
   for (int r0 = row_begin + wave; r0 < row_end; r0 += kTlWaves * kAhead) {
-    float4 y[kAhead][kTailQ];
-    float yt[kAhead], p_adv[kAhead], p_vt[kAhead], p_olp[kAhead], p_ov[kAhead];
-    int p_act[kAhead];
-#pragma unroll
-    for (int u = 0; u < kAhead; ++u) {
-      const int row = min(r0 + kTlWaves * u, a.B - 1);
-      const float *base = a.y2 + static_cast<long long>(row) * kTailK;
-#pragma unroll
-      for (int q = 0; q < kTailQ; ++q) y[u][q] = reinterpret_cast<const float4 *>(base)[lane + 64 * q];
-      yt[u] = base[64 * 4 * kTailQ + lane];
-      p_act[u] = static_cast<int>(a.actions[row]);
-      p_adv[u] = a.advantages[row];
-      p_vt[u] = a.value_targets[row];
-      p_olp[u] = a.mode == 0 ? a.old_log_prob[row] : 0.f;
-      p_ov[u] = a.mode == 0 ? a.old_values[row] : 0.f;
-    }
     float x[kAhead];
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) x[u] = 0.f;
     tail_dots<kAhead>(tl_smem, a.Wc, NJ, y, yt, lane, col, x);
+    CatRow cr[kAhead];
+    float vts[kAhead];
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) {
-      const bool ok = r0 + kTlWaves * u < row_end;  // uniform
       x[u] += bias_col;
       if (col > A) x[u] = 0.f;  // padding columns
       const int act = __builtin_amdgcn_readfirstlane(p_act[u]);
-      const CatRow cr = categorical_loss_row(lparams, x[u], col, is_logit, act, p_adv[u], p_vt[u], p_olp[u], p_ov[u], meanf, denom);
+      cr[u] = categorical_loss_row(lparams, x[u], col, is_logit, act, p_adv[u], p_vt[u], p_olp[u], p_ov[u], meanf, denom);
+      vts[u] = p_vt[u];
+    }
+    if (r0 + kTlWaves * kAhead < row_end) fetch(r0 + kTlWaves * kAhead);  // the next pass's rows, under this pass's stores
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const bool ok = r0 + kTlWaves * u < row_end;  // uniform
       if (!ok) continue;  // rows past the slice: nothing stored, nothing summed
       const int b = r0 + kTlWaves * u;
-      if (a.stats && a.adv_norm_out && lane == 0) a.adv_norm_out[b] = cr.adv;
+      if (a.stats && a.adv_norm_out && lane == 0) a.adv_norm_out[b] = cr[u].adv;
       if (lane < 32) {
         a.head[static_cast<long long>(b) * kHeadLd + col] = x[u];
-        a.dhead[static_cast<long long>(b) * kHeadLd + col] = cr.g;
+        a.dhead[static_cast<long long>(b) * kHeadLd + col] = cr[u].g;
       }
-      const float vt = p_vt[u];
-      s[0] += cr.pl; s[1] += cr.ent; s[2] += cr.vl; s[3] += cr.adv; s[4] += cr.v; s[5] += vt;
-      s[6] += static_cast<double>(cr.v - vt) * (cr.v - vt); s[7] += static_cast<double>(cr.v) * cr.v;
+      const float vt = vts[u];
+      s[0] += cr[u].pl; s[1] += cr[u].ent; s[2] += cr[u].vl; s[3] += cr[u].adv; s[4] += cr[u].v; s[5] += vt;
+      s[6] += static_cast<double>(cr[u].v - vt) * (cr[u].v - vt); s[7] += static_cast<double>(cr[u].v) * cr[u].v;
     }
   }
   if (lane < 8) {

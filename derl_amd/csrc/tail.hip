@@ -16,7 +16,7 @@
 // become two passes over y2 that are bound by HBM.  Rounding differs from the layer-by-layer order at
 // the fp32 level only (both orders against float64 on random data of the layer's shapes: 3-6e-7 of the largest element either way).
 //
-//   tail_pack_*      Wc (NHWC column order of y2) and beff from the canonical parameters, every update
+//   tail_pack_kernel Wc (NHWC column order of y2) and beff from the canonical parameters, every update
 //   tail_loss_kernel (heads.hip) out, loss, dout
 //   tail_bwd_kernel  dy2 = relu'(y2) * (dout Wc), G partials, s partials: one pass over y2
 //   tail_greduce / tail_grads  G -> dWfc, dWh, dbfc, dbh straight into the flat gradient buffer
@@ -46,23 +46,60 @@ __device__ __forceinline__ float head_weight(const TailWeights &w, int j, int n)
   return j < w.A ? w.Wp[j * kNH + n] : (j == w.A ? w.Wv[n] : 0.f);
 }
 
-// partial[chunk][j][kc] = sum over the chunk's 64 hidden units n of Wh[j][n] Wfc[n][kc]; blockIdx.y = group of eight outputs
-// Workgroups beyond the kP x kChunks of the product (first group only) run the direct pack's pieces (pack_direct_dev.hpp)
-// when `direct` has planes to write: between two updates of an epoch the two packs are then one launch.
-__global__ __launch_bounds__(256) void tail_pack_partial_kernel(const TailWeights w, float *partial, int Jp, const PackDirectArgs direct) {
-  if (blockIdx.x >= kP * kChunks) {
-    if (blockIdx.y == 0) pack_direct_piece(direct, (blockIdx.x - kP * kChunks) * 256 + threadIdx.x);
+// Wc = Wh Wfc (A + 1 rows of 3136) and beff = Wh bfc + bh in ONE launch (round 5; two until then: eight chunk partials
+// through global memory and a second launch to add them).  Workgroup = 32 columns of Wfc (its canonical order,
+// kc = c * 49 + p) x 8 output rows (blockIdx.y); thread (col, ng, chunk) forms the product over 16 hidden units of chunk
+// `chunk`, the four ng of a chunk meet pairwise in a fixed order, then the eight chunks in order: the same sums in the
+// same order as the two launches formed (bit-identical Wc).  The result goes out in y2's column order (k = p * 64 + c)
+// and, optionally, in the fragment order of the rollout's conv-stack kernel (convstack.hip:
+// [wave = 4 (p / 32) + c / 16][tile (p % 32) / 16][row j of Jp][lane = 16 ((c % 16) / 4) + p % 16][c % 4]; the rows of
+// pixels 49 .. 63 are never written: `packed` is zero-filled once by its owner).
+// Workgroups beyond the product's: one for beff, then the direct pack's pieces (pack_direct_dev.hpp) when `direct`
+// has planes to write -- between two updates of an epoch every mirror the next minibatch reads comes from this launch.
+constexpr int kPackCols = 32, kPackBlocks = kK / kPackCols, kPackThreads = 1024;
+static_assert(kK % kPackCols == 0 && kPackThreads == kPackCols * 4 * kChunks && kNH == kChunks * 64, "thread = (column, 16 hidden units of a chunk)");
+
+__global__ __launch_bounds__(kPackThreads) void tail_pack_kernel(const TailWeights w, float *Wc, float *beff, float *Wcf, int Jp,
+                                                                const PackDirectArgs direct) {
+  const int t = threadIdx.x;
+  if (blockIdx.x > kPackBlocks) {  // the conv layers' bf16 planes
+    if (blockIdx.y == 0) pack_direct_piece(direct, (blockIdx.x - kPackBlocks - 1) * kPackThreads + t);
     return;
   }
-  __shared__ float sWh[kJ][64];
-  __shared__ float red[4][kJ][64];
-  const int t = threadIdx.x, col = t & 63, ng = t >> 6;
-  const int colblk = blockIdx.x % kP, chunk = blockIdx.x / kP, j0 = 8 * blockIdx.y;
-  for (int i = t; i < kJ * 64; i += 256) sWh[i >> 6][i & 63] = head_weight(w, j0 + (i >> 6), chunk * 64 + (i & 63));
-  const int kc = colblk * 64 + col;
+  const int j0 = 8 * blockIdx.y;
+  if (blockIdx.x == kPackBlocks) {  // beff[j] = Wh[j] . bfc + bh[j]: 256 threads, the two-launch version's order
+    __shared__ float bred[4][kJ];
+    if (t >= 256) return;
+    float part[kJ];
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) part[j] = 0.f;
+    for (int n = t; n < kNH; n += 256) {
+      const float b = w.bfc[n];
+#pragma unroll
+      for (int j = 0; j < kJ; ++j) part[j] = fmaf(head_weight(w, j0 + j, n), b, part[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part[j] += __shfl_xor(part[j], o);
+      if ((t & 63) == 0) bred[t >> 6][j] = part[j];
+    }
+    __syncthreads();  // (every thread below 256 is here: the others left before the first barrier)
+    if (t < kJ) {
+      const int j = j0 + t;
+      const float bh = j < w.A ? w.bp[j] : (j == w.A ? w.bv[0] : 0.f);
+      beff[j] = (((bred[0][t] + bred[1][t]) + bred[2][t]) + bred[3][t]) + bh;
+    }
+    return;
+  }
+  __shared__ float sWh[kJ][kNH];                  // 16 KB
+  __shared__ float red[kChunks][4][kJ][kPackCols];  // 32 KB
+  const int col = t & (kPackCols - 1), ng = (t >> 5) & 3, chunk = t >> 7;
+  const int kc = blockIdx.x * kPackCols + col;
   float v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = w.Wfc[static_cast<long long>(chunk * 64 + ng * 16 + i) * kK + kc];
+  for (int i = t; i < kJ * kNH; i += kPackThreads) sWh[i >> 9][i & (kNH - 1)] = head_weight(w, j0 + (i >> 9), i & (kNH - 1));
   __syncthreads();
   float acc[kJ];
 #pragma unroll
@@ -70,58 +107,22 @@ __global__ __launch_bounds__(256) void tail_pack_partial_kernel(const TailWeight
 #pragma unroll
   for (int i = 0; i < 16; ++i)
 #pragma unroll
-    for (int j = 0; j < kJ; ++j) acc[j] = fmaf(sWh[j][ng * 16 + i], v[i], acc[j]);
+    for (int j = 0; j < kJ; ++j) acc[j] = fmaf(sWh[j][chunk * 64 + ng * 16 + i], v[i], acc[j]);
 #pragma unroll
-  for (int j = 0; j < kJ; ++j) red[ng][j][col] = acc[j];
+  for (int j = 0; j < kJ; ++j) red[chunk][ng][j][col] = acc[j];
   __syncthreads();
-  for (int i = t; i < kJ * 64; i += 256) {
-    const int j = i >> 6, c = i & 63;
-    partial[static_cast<long long>(chunk * Jp + j0 + j) * kK + colblk * 64 + c] = ((red[0][j][c] + red[1][j][c]) + red[2][j][c]) + red[3][j][c];
-  }
-}
-
-// Wc[j][p * 64 + c] = sum of the chunks' partial[.][j][c * 49 + p]; last block: beff[j] = Wh[j] . bfc + bh[j]
-// (Wcf, optional: the same values in the fragment order of the rollout's conv-stack kernel, convstack.hip --
-// [wave = 4 (p / 32) + c / 16][tile (p % 32) / 16][row j of Jp][lane = 16 ((c % 16) / 4) + p % 16][c % 4]; the rows of
-// pixels 49 .. 63 are never written: `packed` is zero-filled once by its owner)
-template <int Jp>  // 8, 16 or 24: compile-time so that the common case (up to 7 actions) keeps eight registers per array
-__global__ __launch_bounds__(256) void tail_pack_finish_kernel(const float *partial, const TailWeights w, float *Wc, float *beff,
-                                                               float *Wcf) {
-  const int t = threadIdx.x;
-  if (blockIdx.x == gridDim.x - 1) {
-    __shared__ float red[4][Jp];
-    float part[Jp];
+  if (t < kJ * kPackCols) {
+    const int j = t >> 5, c32 = t & (kPackCols - 1);
+    float tot = 0.f;
 #pragma unroll
-    for (int j = 0; j < Jp; ++j) part[j] = 0.f;
-    for (int n = t; n < kNH; n += 256) {
-      const float b = w.bfc[n];
-#pragma unroll
-      for (int j = 0; j < Jp; ++j) part[j] = fmaf(head_weight(w, j, n), b, part[j]);
+    for (int ch = 0; ch < kChunks; ++ch)
+      tot += ((red[ch][0][j][c32] + red[ch][1][j][c32]) + red[ch][2][j][c32]) + red[ch][3][j][c32];
+    const int kcc = blockIdx.x * kPackCols + c32, c = kcc / kP, p = kcc - c * kP;
+    Wc[(j0 + j) * kK + p * 64 + c] = tot;
+    if (Wcf) {
+      const int wave = 4 * (p >> 5) + (c >> 4), m = (p >> 4) & 1, lane = 16 * ((c >> 2) & 3) + (p & 15);
+      Wcf[((wave * 2 + m) * Jp + j0 + j) * 256 + lane * 4 + (c & 3)] = tot;
     }
-#pragma unroll
-    for (int j = 0; j < Jp; ++j) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) part[j] += __shfl_xor(part[j], o);
-      if ((t & 63) == 0) red[t >> 6][j] = part[j];
-    }
-    __syncthreads();
-    if (t < Jp) {
-      const float bh = t < w.A ? w.bp[t] : (t == w.A ? w.bv[0] : 0.f);
-      beff[t] = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) + bh;
-    }
-    return;
-  }
-  const int i = blockIdx.x * 256 + t;
-  if (i >= Jp * kK) return;
-  const int j = i / kK, k = i - j * kK, p = k >> 6, c = k & 63;
-  const int kc = c * kP + p;
-  float v = 0.f;
-#pragma unroll
-  for (int chunk = 0; chunk < kChunks; ++chunk) v += partial[static_cast<long long>(chunk * Jp + j) * kK + kc];
-  Wc[i] = v;
-  if (Wcf) {
-    const int wave = 4 * (p >> 5) + (c >> 4), m = (p >> 4) & 1, lane = 16 * ((c >> 2) & 3) + (p & 15);
-    Wcf[((wave * 2 + m) * Jp + j) * 256 + lane * 4 + (c & 3)] = v;
   }
 }
 
@@ -261,15 +262,15 @@ __global__ __launch_bounds__(256) void tail_greduce_kernel(const float *gslab, c
     return;
   }
   float v = 0.f;
-  for (int z0 = sg; z0 < nslab; z0 += 32) {  // eight loads in flight, added in slab order
-    float x[8];
+  for (int z0 = sg; z0 < nslab; z0 += 64) {  // sixteen loads in flight, added in slab order
+    float x[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int z = z0 + 4 * u;
       x[u] = z < nslab ? gslab[(static_cast<long long>(z) * Jp + j) * kK + p * 64 + c] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v += x[u];
+    for (int u = 0; u < 16; ++u) v += x[u];
   }
   red[sg][c] = v;
   if (p == 0) {
@@ -303,11 +304,19 @@ __global__ __launch_bounds__(256) void tail_grads_kernel(const TailGradArgs a) {
   if (blk < kGradBlocksW) {
     const int idx = blk * 256 + t, n = idx / (kK / 4), q = idx - n * (kK / 4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < a.nj; ++j) {  // uniform
-      const float wh = head_weight(a.w, j, n);
-      const float4 g4 = reinterpret_cast<const float4 *>(a.Gc + j * kK)[q];
-      acc.x = fmaf(wh, g4.x, acc.x); acc.y = fmaf(wh, g4.y, acc.y);
-      acc.z = fmaf(wh, g4.z, acc.z); acc.w = fmaf(wh, g4.w, acc.w);
+    // every row's loads in flight at once (a loop over the A + 1 real rows waited for each row's pair of loads in
+    // turn); rows beyond A + 1 are zero in Gc (tail_greduce_kernel) and in Wh: they add +0
+    float wh[Jp];
+    float4 g4[Jp];
+#pragma unroll
+    for (int j = 0; j < Jp; ++j) {
+      wh[j] = head_weight(a.w, j, n);
+      g4[j] = reinterpret_cast<const float4 *>(a.Gc + j * kK)[q];
+    }
+#pragma unroll
+    for (int j = 0; j < Jp; ++j) {
+      acc.x = fmaf(wh[j], g4[j].x, acc.x); acc.y = fmaf(wh[j], g4[j].y, acc.y);
+      acc.z = fmaf(wh[j], g4[j].z, acc.z); acc.w = fmaf(wh[j], g4[j].w, acc.w);
     }
     reinterpret_cast<float4 *>(a.dWfc + static_cast<long long>(n) * kK)[q] = acc;
     return;
@@ -318,10 +327,28 @@ __global__ __launch_bounds__(256) void tail_grads_kernel(const TailGradArgs a) {
     float part[Jp];
 #pragma unroll
     for (int j = 0; j < Jp; ++j) part[j] = 0.f;
-    for (int kc = t; kc < kK; kc += 256) {
-      const float wfc = a.w.Wfc[static_cast<long long>(n) * kK + kc];
+    // the row's 13 column steps with all their loads in flight (one step's loads waited for before the next step's
+    // were issued: 13 dependent round trips, 10 us of a 14.8 us launch at any batch)
+    constexpr int kSteps = (kK + 255) / 256;
+    float wfc[kSteps];
 #pragma unroll
-      for (int j = 0; j < Jp; ++j) part[j] = fmaf(a.Gc[j * kK + kc], wfc, part[j]);  // rows >= A + 1 of Gc are zero
+    for (int i = 0; i < kSteps; ++i) wfc[i] = t + 256 * i < kK ? a.w.Wfc[static_cast<long long>(n) * kK + t + 256 * i] : 0.f;
+#pragma unroll
+    for (int i0 = 0; i0 < kSteps; i0 += 4) {  // four steps' Gc rows at a time: 4 Jp loads in flight
+      float gc[4][Jp];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < Jp; ++j) {
+          const int kc = t + 256 * (i0 + u);
+          gc[u][j] = (i0 + u < kSteps && kc < kK) ? a.Gc[j * kK + kc] : 0.f;  // rows >= A + 1 of Gc are zero
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u < kSteps) {
+#pragma unroll
+          for (int j = 0; j < Jp; ++j) part[j] = fmaf(gc[u][j], wfc[i0 + u], part[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < Jp; ++j) {
@@ -385,14 +412,10 @@ int launch_tail_pack(const float *params, const long long *off_w, const long lon
   if (direct) {  // the conv layers' bf16 planes ride in extra workgroups of the same launch
     DX_REQUIRE(direct->p0 && direct->f1 && direct->f2 && direct->d1 && direct->d2, "tail_pack: direct planes missing");
     d = PackDirectArgs{params + off_w[0], params + off_w[1], params + off_w[2], direct->p0, direct->f1, direct->f2, direct->d1, direct->d2};
-    extra = cdiv(kPackDirectPieces, 256);
+    extra = cdiv(kPackDirectPieces, kPackThreads);
   }
-  hipLaunchKernelGGL(tail_pack_partial_kernel, dim3(kP * kChunks + extra, Jp / 8), dim3(256), 0, stream, w, scratch, Jp, d);
-  DX_LAUNCH_CHECK();
-  const dim3 fgrid(cdiv(Jp * kK, 256) + 1);
-  if (Jp == 8) hipLaunchKernelGGL(tail_pack_finish_kernel<8>, fgrid, dim3(256), 0, stream, scratch, w, Wc, beff, Wcf);
-  else if (Jp == 16) hipLaunchKernelGGL(tail_pack_finish_kernel<16>, fgrid, dim3(256), 0, stream, scratch, w, Wc, beff, Wcf);
-  else hipLaunchKernelGGL(tail_pack_finish_kernel<24>, fgrid, dim3(256), 0, stream, scratch, w, Wc, beff, Wcf);
+  (void)scratch;  // (the two-launch version's chunk partials; kept in the signature for its callers)
+  hipLaunchKernelGGL(tail_pack_kernel, dim3(kPackBlocks + 1 + extra, Jp / 8), dim3(kPackThreads), 0, stream, w, Wc, beff, Wcf, Jp, d);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

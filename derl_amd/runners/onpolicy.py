@@ -46,6 +46,9 @@ class EpochContext:
     self.norm_eps = None
     self.norm_first = None
     self.normalized = None  # every minibatch's normalised advantages, filled by the native epoch
+    # another epoch over the same rollout follows this one (IterateWithMinibatches): a native epoch may then leave
+    # the mirrors only the rollout reads stale at its end (dx_cnn_epoch.more_epochs)
+    self.more_epochs = False
 
 
 class LazyMinibatch(dict):
@@ -379,6 +382,7 @@ class IterateWithMinibatches(RunnerWrapper):
           lazy = {key: val for key, val in interactions.items()
                   if key != "state" and key not in shuffled and isinstance(val, torch.Tensor) and val.is_cuda}
           context = EpochContext(shuffled, sample_size, mbsize, order_dev, lazy)
+          context.more_epochs = epoch + 1 < len(orders)
           if extras is not None:
             context.stats_ready = getattr(extras, "epoch_stats", lambda _: None)(epoch)
         for start in range(0, sample_size, mbsize):

@@ -366,8 +366,16 @@ typedef struct dx_cnn_epoch {
   int loss_partials_capacity;
   int grad_norm_stride;        /* 0: grad_norm_out[0] = the last minibatch's; 1: one each   */
   int mirrors_current;         /* 1: the packed mirrors match ctx->params (no pack before the
-                                  first minibatch; every update is followed by one)          */
-  int reserved0;
+                                  first minibatch; every update is followed by one); 2: the
+                                  previous call had more_epochs = 1 and nothing touched the
+                                  parameters since -- the mirrors the training kernels read are
+                                  current, the rollout's are not                               */
+  int more_epochs;             /* 1: the caller's next use of ctx is another dx_cnn_ppo_epoch (a further
+                                  epoch over the same rollout): the LAST update re-packs only what the
+                                  training kernels read, like the updates before it; the caller
+                                  then passes mirrors_current = 2 to that call, or calls dx_cnn_pack
+                                  before anything else (dx_cnn_act ...) reads the mirrors.  0: the
+                                  last update leaves every mirror current                       */
   unsigned *loss_counter;      /* one zeroed word: heads + loss + heads' backward run as ONE launch
                                   (dx_cnn_heads_loss_f32) where num_actions <= 7; NULL: separate
                                   heads / loss launches                                        */

@@ -9,6 +9,6 @@ python3 - <<PY
 import csv, json
 print(json.load(open("$R/gpurun_out/${TAG}.json"))["ms_per_step"], "ms per iteration under rocprofv3")
 rows=list(csv.DictReader(open("$R/gpurun_out/${TAG}_prof/k_kernel_stats.csv")))
-for r in rows[:30]:
+for r in rows[:45]:
   print(f"{r['Name'][:88]:88s} calls {int(r['Calls']):5d} avg {float(r['AverageNs'])/1e3:8.1f} us")
 PY
