@@ -34,6 +34,10 @@ STAGES = list(STAGE_IDS)
 # (dx_cnn_backward_part 2: one pass over y2, the G reduction, the gradient products)
 FACTORED_STAGES = ["conv0_fwd", "conv1_fwd", "conv2_fwd", "tail_loss", "tail_bwd", "conv2_wgrad",
                    "conv2_dgrad", "conv1_wgrad", "conv1_dgrad", "conv0_wgrad", "finalize"]
+# round 5 (up to 7 actions, dx_cnn_tail_fused): the loss launch also makes the backward pass over y2 -- tail_loss_bwd
+# = out, loss, dL/dout, dy2 and the partial G / s (one read of y2); tail_grads = the G reduction and the gradient
+# products of the linear layer + heads (what is left of dx_cnn_backward_part 2)
+TAIL_FUSED_NAMES = {"tail_loss": "tail_loss_bwd", "tail_bwd": "tail_grads"}
 # algorithmic multiply-accumulates per sample (dgrad = the transposed
 # convolution's MACs = forward MACs, no padding waste counted)
 MACS = dict(conv0=3_276_800, conv1=2_654_208, conv2=1_806_336, fc=1_605_632)
@@ -127,6 +131,8 @@ def stage_launcher(model, obs, idx, batch):
   lib = _lib.load()
   factored = bool(lib.dx_cnn_tail_factored(ctypes.byref(eng.ctx)))
   names = list(FACTORED_STAGES if factored else STAGES)
+  if factored and lib.dx_cnn_tail_fused(ctypes.byref(eng.ctx)):
+    names = [TAIL_FUSED_NAMES.get(n, n) for n in names]
   eng.forward_trunk(obs, idx)
   if factored and lib.dx_cnn_last_route(0).decode() == "convstack_train":  # conv0 / conv1 / conv2 forward are one launch
     names = [CONV_STACK_FWD] + names[3:]
@@ -140,9 +146,9 @@ def stage_launcher(model, obs, idx, batch):
   def launch(name):
     if name == CONV_STACK_FWD:
       _lib.call("dx_cnn_forward_trunk", ctypes.byref(eng.ctx), _lib.ptr(obs), is_u8, _lib.ptr(idx), batch, stream)
-    elif name == "tail_loss":
+    elif name in ("tail_loss", "tail_loss_bwd"):
       eng.heads_loss(batch, actions, zeros, adv, zeros, zeros, 0, 0.1, 0.25, 0.01, batch, partials, terms)
-    elif name == "tail_bwd":
+    elif name in ("tail_bwd", "tail_grads"):
       _lib.call("dx_cnn_backward_part", ctypes.byref(eng.ctx), _lib.ptr(obs), is_u8, _lib.ptr(idx), batch, 2, stream)
     else:
       _lib.call("dx_cnn_stage", ctypes.byref(eng.ctx), STAGE_IDS.index(name), _lib.ptr(obs), is_u8, _lib.ptr(idx),
@@ -488,8 +494,12 @@ def main():
       if fl:  # train_TFLOPs counts algorithmic fp32 flops; executed = what the matrix cores multiply
         row.update(mfma=how, executed_TFLOPs=round(ex / (train[n] * 1e-6) / 1e12, 1), peak_TFLOPs=pk,
                    frac=round(ex / (train[n] * 1e-6) / 1e12 / pk, 4))
-      if n in ("tail_loss", "tail_bwd"):  # HBM passes over y2 (+ dy2 and the partial G slabs for tail_bwd)
-        nbytes = mb * 3136 * 4 * (1 if n == "tail_loss" else 2) + (0 if n == "tail_loss" else 2 * 256 * (A + 1) * 3136 * 4)
+      if n in ("tail_loss", "tail_bwd", "tail_loss_bwd", "tail_grads"):
+        # HBM passes: y2 (tail_loss); y2 + dy2 + the partial G slabs written and read back (tail_bwd incl. its reduction);
+        # fused: y2 + dy2 + the slabs written (tail_loss_bwd) | the slabs read + Wfc read + dWfc written (tail_grads)
+        y2_bytes, slab_bytes, wfc_bytes = mb * 3136 * 4, min(256, -(-mb // 8)) * (A + 1) * 3136 * 4, 512 * 3136 * 4
+        nbytes = {"tail_loss": y2_bytes, "tail_bwd": 2 * y2_bytes + 2 * slab_bytes + 2 * wfc_bytes,
+                  "tail_loss_bwd": 2 * y2_bytes + slab_bytes, "tail_grads": slab_bytes + 2 * wfc_bytes}[n]
         row.update(bound="hbm", algorithmic_bytes=nbytes, GBps=round(nbytes / (train[n] * 1e-6) / 1e9, 1),
                    frac=round(nbytes / (train[n] * 1e-6) / 1e9 / PEAK_HBM_GBPS, 4))
       return row

@@ -75,6 +75,7 @@ SIGNATURES = {
     "dx_cnn_last_route": [c_int],
     "dx_cnn_tail_factored": [P],
     "dx_cnn_fused_heads": [P],
+    "dx_cnn_tail_fused": [P],
     "dx_cnn_act": [P, P, c_int, c_int, P, c_uint64, c_uint64, P, P, P, P],
     "dx_cnn_rollout_synth": [P, P, c_int, c_int, P, P, P, P, P, c_uint64, c_uint64, c_uint64,
                              c_uint64, c_float, c_float, P],

@@ -338,6 +338,10 @@ static bool dgrad_b6_usable(const dx_cnn_ctx *c) {  // (the kernels are built fo
   return dgrad_b6_on() && c->h0 == 20 && c->w0 == 20 && c->h1 == 9 && c->w1 == 9 && c->h2 == 7 && c->w2 == 7;
 }
 static bool fc_factored(const dx_cnn_ctx *c) { return fc_factored_env() && tail_supported(c->flat, c->num_actions); }
+// DX_TAIL_FUSED=0: the factored tail's loss (tail_loss_kernel) and its backward pass over y2 (tail_bwd_kernel) as two
+// launches; default (up to 7 actions): ONE launch from dx_cnn_heads_loss_f32 (heads.hip: tail_loss_bwd_kernel), and the
+// backward that follows it (dx_cnn_backward_part 2 / 3) starts at conv2
+static bool tail_fused(const dx_cnn_ctx *c) { return fc_factored(c) && c->num_actions + 1 <= 8 && DX_ENV("DX_TAIL_FUSED", 1) != 0; }
 
 // `light`: without the mirrors only the layer-by-layer linear layer / heads read (pk_fcf, pk_fcd and their
 // planes): what dx_cnn_ppo_epoch packs between the updates of an epoch when the factored tail is on
@@ -818,6 +822,15 @@ int dx_cnn_heads_loss_f32(const dx_cnn_ctx *c, const int64_t *actions, const flo
   if (int rc = check_ctx(c, "dx_cnn_heads_loss_f32", B, true)) return rc;
   if (fc_factored(c)) {  // out = y2 Wc^T + beff, the loss and dL/dout in one launch (heads.hip: tail_loss_kernel)
     g_route[ST_FC_FWD] = g_route[ST_HEADS_FWD] = g_route[ST_HEADS_WGRAD] = g_route[ST_HEADS_DGRAD] = "tail_factored";
+    if (tail_fused(c)) {  // ... and dy2 + the partial G / s from the same pass over y2: backward_stages skips tail_bwd
+      const Plan plan = make_plan(c, B);
+      const TailBwdPlan tb = tail_bwd_plan(c->slabs + plan.s[L_FC].w_off, B, c->num_actions);
+      return launch_tail_loss_bwd(c->y2, c->packed + c->pk_wc, c->packed + c->pk_beff, actions, old_log_prob, advantages,
+                                  old_values, value_targets, norm_stats, norm_eps, adv_normalized_out, c->head, c->dhead, B,
+                                  c->num_actions, mode, cliprange, value_loss_coef, entropy_coef, global_batch, partials,
+                                  partials_capacity, counter, loss_out, c->dy2, tb.gslab, tb.sslab, tb.Jp, tb.nwg,
+                                  tb.rows_per_wg, as_stream(stream));
+    }
     return launch_tail_loss(c->y2, c->packed + c->pk_wc, c->packed + c->pk_beff, actions, old_log_prob, advantages,
                             old_values, value_targets, norm_stats, norm_eps, adv_normalized_out, c->head, c->dhead, B,
                             c->num_actions, mode, cliprange, value_loss_coef, entropy_coef, global_batch, partials,
@@ -878,6 +891,7 @@ static int backward_stages(const dx_cnn_ctx *c, int first, int last, const void 
       // linear layer's weight- and data-gradient GEMMs
       if (st == ST_FC_WGRAD) {
         g_route[ST_FC_WGRAD] = g_route[ST_FC_DGRAD] = "tail_factored";
+        if (tail_fused(c)) continue;  // dx_cnn_heads_loss_f32 has formed dy2 and the partial G / s already
         rc = launch_tail_bwd(c->y2, c->dhead, c->packed + c->pk_wc, c->dy2, c->slabs + plan.s[L_FC].w_off, B,
                              c->num_actions, s);
       }
@@ -1166,6 +1180,12 @@ int dx_cnn_tail_factored(const dx_cnn_ctx *c) {
 int dx_cnn_fused_heads(const dx_cnn_ctx *c) {
   if (c == nullptr || c->struct_bytes != static_cast<int>(sizeof(dx_cnn_ctx))) return 0;
   return (fc_factored(c) || c->num_actions + 1 <= 8) ? 1 : 0;
+}
+
+// 1: dx_cnn_heads_loss_f32 also runs the factored tail's backward pass over y2 (tail_fused above)
+int dx_cnn_tail_fused(const dx_cnn_ctx *c) {
+  if (c == nullptr || c->struct_bytes != static_cast<int>(sizeof(dx_cnn_ctx))) return 0;
+  return tail_fused(c) ? 1 : 0;
 }
 
 // Kernel family the LAST launch of `stage` took ("ntp", "wgrad_direct", "igemm_pix", ...; "" before any).

@@ -934,6 +934,148 @@ __global__ __launch_bounds__(64 * kTlWaves) void tail_loss_kernel(const TailLoss
   loss_finish<kTlWaves>(lsum, &ticket, a.partials, a.counter, a.loss_out, a.B, a.value_loss_coef, a.entropy_coef);
 }
 
+// tail_loss_kernel AND tail.hip's tail_bwd_kernel in ONE pass over y2 (up to 7 actions), round 5: a row's outputs, its
+// loss and dL/dout, then -- from the same registers -- dy2 = relu'(y2) * (dout Wc) and the workgroup's partial
+// G = dout^T y2, s = sum dout.  (Two launches read y2 twice -- 206 MB at minibatch 8192 -- and at minibatch 1,024 each
+// was a latency chain of its own: 17 + 9 us.)  Threads and registers are tail_bwd_kernel's: 448 threads, thread t owns
+// columns t + 448 i (i < 7) with their Wc and G entries; the outputs of four rows at a time meet through LDS (seven
+// wave sums per output, added in wave order), waves 0-3 take one row each through categorical_loss_row, and every
+// thread reads the four rows' dL/dout back from LDS.
+constexpr int kFbThreads = 448, kFbCols = kTailK / kFbThreads, kFbRows = 4, kFbWaves = kFbThreads / 64;
+static_assert(kFbThreads * kFbCols == kTailK, "seven columns per thread");
+
+struct TailBwdOut {
+  float *dy2;    // [B][3136]
+  float *gslab;  // [gridDim.x][Jp][3136] partial G
+  float *sslab;  // [gridDim.x][Jp] partial s
+  int Jp;
+};
+
+template <int NJ>
+__global__ __launch_bounds__(kFbThreads) void tail_loss_bwd_kernel(const TailLossArgs a, const TailBwdOut o) {
+  __shared__ float red[kFbWaves][kFbRows * 8];
+  __shared__ float dsh[kFbRows][8];
+  __shared__ double lsum[kFbWaves * 8];
+  __shared__ unsigned ticket;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 31;
+  const int A = a.A;
+  const LossParams lparams{a.A, a.mode, a.stats != nullptr, a.cliprange, a.value_loss_coef, a.entropy_coef, a.inv_batch};
+  float wc[NJ][kFbCols], g[NJ][kFbCols], sacc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    sacc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kFbCols; ++i) {
+      wc[j][i] = a.Wc[j * kTailK + t + kFbThreads * i];
+      g[j][i] = 0.f;
+    }
+  }
+  const float bias_col = col <= A ? a.beff[col] : 0.f;
+  float meanf = 0.f, denom = 1.f;
+  if (a.stats) {  // adv_apply_kernel's expression
+    const double cnt = a.stats[2], mean = a.stats[0] / cnt;
+    double var = a.stats[1] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    meanf = static_cast<float>(mean);
+    denom = static_cast<float>(sqrt(var)) + a.norm_eps;
+  }
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool is_logit = col < A;
+  const int r0 = blockIdx.x * a.rows_per_wg, r1 = min(a.B, r0 + a.rows_per_wg);
+  for (int r = r0; r < r1; r += kFbRows) {
+    float y[kFbRows][kFbCols];
+#pragma unroll
+    for (int u = 0; u < kFbRows; ++u) {
+      const long long row = min(r + u, a.B - 1);
+#pragma unroll
+      for (int i = 0; i < kFbCols; ++i) y[u][i] = a.y2[row * kTailK + t + kFbThreads * i];
+    }
+    // this wave's row (waves 0-3): its scalars, in flight with the row loads
+    const int myrow = min(r + (wave < kFbRows ? wave : 0), a.B - 1);
+    const int p_act = static_cast<int>(a.actions[myrow]);
+    const float p_adv = a.advantages[myrow], p_vt = a.value_targets[myrow];
+    const float p_olp = a.mode == 0 ? a.old_log_prob[myrow] : 0.f, p_ov = a.mode == 0 ? a.old_values[myrow] : 0.f;
+    // ---- the four rows' outputs: per-thread partial dots, wave sums, seven waves through LDS ----
+    float mine = 0.f;
+#pragma unroll
+    for (int u = 0; u < kFbRows; ++u)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < kFbCols; ++i) part = fmaf(y[u][i], wc[j][i], part);
+        const float tot = wave_sum_all(part);
+        mine = lane == u * 8 + j ? tot : mine;
+      }
+    if (lane < kFbRows * 8) red[wave][lane] = mine;
+    __syncthreads();
+    if (wave < kFbRows) {  // one row per wave, lane = column (both halves hold the same row)
+      const int u = wave;
+      float x = 0.f;
+      if (col < NJ) {
+#pragma unroll
+        for (int w = 0; w < kFbWaves; ++w) x += red[w][u * 8 + col];
+        x += bias_col;
+      }
+      const int act = __builtin_amdgcn_readfirstlane(p_act);
+      const CatRow cr = categorical_loss_row(lparams, x, col, is_logit, act, p_adv, p_vt, p_olp, p_ov, meanf, denom);
+      const bool ok = r + u < r1;  // uniform
+      if (lane < 8) dsh[u][lane] = ok ? cr.g : 0.f;
+      if (ok) {
+        const int b = r + u;
+        if (a.stats && a.adv_norm_out && lane == 0) a.adv_norm_out[b] = cr.adv;
+        if (lane < 32) {
+          a.head[static_cast<long long>(b) * kHeadLd + col] = x;
+          a.dhead[static_cast<long long>(b) * kHeadLd + col] = cr.g;
+        }
+        s[0] += cr.pl; s[1] += cr.ent; s[2] += cr.vl; s[3] += cr.adv; s[4] += cr.v; s[5] += p_vt;
+        s[6] += static_cast<double>(cr.v - p_vt) * (cr.v - p_vt); s[7] += static_cast<double>(cr.v) * cr.v;
+      }
+    }
+    __syncthreads();
+    // ---- dy2 and the partial G / s from the same rows (tail_bwd_kernel's arithmetic) ----
+#pragma unroll
+    for (int u = 0; u < kFbRows; ++u) {
+      if (r + u >= r1) break;  // uniform
+      float d[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) d[j] = dsh[u][j];
+      float *out = o.dy2 + static_cast<long long>(r + u) * kTailK + t;
+#pragma unroll
+      for (int i = 0; i < kFbCols; ++i) {
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          dsum = fmaf(d[j], wc[j][i], dsum);
+          g[j][i] = fmaf(d[j], y[u][i], g[j][i]);
+        }
+        out[kFbThreads * i] = y[u][i] > 0.f ? dsum : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) sacc[j] += d[j];
+    }
+    // (the next pass's first barrier orders its writes of red / dsh behind these reads: every thread passes it
+    // only after reading dsh here)
+  }
+  float *slab = o.gslab + static_cast<long long>(blockIdx.x) * o.Jp * kTailK;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < kFbCols; ++i) slab[j * kTailK + t + kFbThreads * i] = g[j][i];
+  if (t == 0) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) o.sslab[blockIdx.x * o.Jp + j] = sacc[j];
+  }
+  if (lane < 8) {
+    double mine_d = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine_d = lane == i ? s[i] : mine_d;
+    lsum[wave * 8 + lane] = wave < kFbRows ? mine_d : 0.0;
+  }
+  __syncthreads();
+  loss_finish<kFbWaves>(lsum, &ticket, a.partials, a.counter, a.loss_out, a.B, a.value_loss_coef, a.entropy_coef);
+}
+
 // rollout: out = y2 Wc^T + beff and the categorical sampling of heads_act_fused_block, one wave per row
 struct TailActArgs {
   const float *y2;
@@ -1193,6 +1335,48 @@ int launch_heads_act_synth(const float *hid_slabs, int nslab, long long slab_str
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
+
+// forward + loss of the factored tail AND its backward pass over y2 in one launch (tail_loss_bwd_kernel): up to 7
+// actions; `gslab` / `sslab` / `nwg` / `rows_per_wg` are launch_tail_bwd's (tail.hip owns the slab layout)
+template <int NJ>
+static int launch_tail_loss_bwd_as(const TailLossArgs &a, const TailBwdOut &o, int nwg, hipStream_t stream) {
+  hipLaunchKernelGGL(tail_loss_bwd_kernel<NJ>, dim3(nwg), dim3(kFbThreads), 0, stream, a, o);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+int launch_tail_loss_bwd(const float *y2, const float *Wc, const float *beff, const int64_t *actions,
+                         const float *old_log_prob, const float *advantages, const float *old_values,
+                         const float *value_targets, const double *stats, float norm_eps, float *adv_norm_out, float *head,
+                         float *dhead, int B, int A, int mode, float cliprange, float value_loss_coef, float entropy_coef,
+                         long long global_batch, double *partials, int partials_capacity, unsigned *counter,
+                         float *loss_out, float *dy2, float *gslab, float *sslab, int Jp, int nwg, int rows_per_wg,
+                         hipStream_t stream) {
+  if (A + 1 > 8) return DX_ENOSUP;
+  DX_REQUIRE(B >= 1 && A >= 1, "tail_loss_bwd: bad shape B=%d A=%d", B, A);
+  DX_REQUIRE(mode == 0 || mode == 1, "tail_loss_bwd: mode must be 0 (PPO) or 1 (A2C)");
+  DX_REQUIRE(y2 && Wc && beff && actions && advantages && value_targets && head && dhead && partials && counter && loss_out &&
+                 dy2 && gslab && sslab,
+             "tail_loss_bwd: null pointer");
+  DX_REQUIRE(mode == 1 || (old_log_prob && old_values), "tail_loss_bwd: PPO needs old_log_prob / old_values");
+  DX_REQUIRE(nwg >= 1 && rows_per_wg >= 1 && static_cast<long long>(nwg) * rows_per_wg >= B, "tail_loss_bwd: %d workgroups x %d rows < %d",
+             nwg, rows_per_wg, B);
+  DX_REQUIRE(partials_capacity >= 8 * nwg, "tail_loss_bwd: partials needs %d doubles", 8 * nwg);
+  if (global_batch <= 0) global_batch = B;
+  const TailLossArgs a{y2, Wc, beff, actions, old_log_prob, advantages, old_values, value_targets, stats, norm_eps,
+                       adv_norm_out, head, dhead, partials, counter, loss_out, B, A, rows_per_wg, mode, cliprange,
+                       value_loss_coef, entropy_coef, 1.0f / static_cast<float>(global_batch)};
+  const TailBwdOut o{dy2, gslab, sslab, Jp};
+  switch (A + 1) {
+    case 2: return launch_tail_loss_bwd_as<2>(a, o, nwg, stream);
+    case 3: return launch_tail_loss_bwd_as<3>(a, o, nwg, stream);
+    case 4: return launch_tail_loss_bwd_as<4>(a, o, nwg, stream);
+    case 5: return launch_tail_loss_bwd_as<5>(a, o, nwg, stream);
+    case 6: return launch_tail_loss_bwd_as<6>(a, o, nwg, stream);
+    case 7: return launch_tail_loss_bwd_as<7>(a, o, nwg, stream);
+    default: return launch_tail_loss_bwd_as<8>(a, o, nwg, stream);
+  }
+}
+
 // forward + loss of the factored tail (tail_loss_kernel); DX_ENOSUP for more than 18 actions
 int launch_tail_loss(const float *y2, const float *Wc, const float *beff, const int64_t *actions,
                      const float *old_log_prob, const float *advantages, const float *old_values,

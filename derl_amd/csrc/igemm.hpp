@@ -282,6 +282,17 @@ int launch_tail_loss(const float *y2, const float *Wc, const float *beff, const 
                      float *loss_out, hipStream_t stream);
 int launch_tail_bwd(const float *y2, const float *dhead, const float *Wc, float *dy2, float *scratch, int B, int A,
                     hipStream_t stream);
+// both in one pass over y2 (heads.hip: tail_loss_bwd_kernel; up to 7 actions, DX_ENOSUP beyond): the slab layout inside
+// `scratch` is launch_tail_bwd's -- tail_bwd_plan (tail.hip) names it
+struct TailBwdPlan { float *gslab, *sslab; int Jp, nwg, rows_per_wg; };
+TailBwdPlan tail_bwd_plan(float *scratch, int B, int A);
+int launch_tail_loss_bwd(const float *y2, const float *Wc, const float *beff, const int64_t *actions,
+                         const float *old_log_prob, const float *advantages, const float *old_values,
+                         const float *value_targets, const double *stats, float norm_eps, float *adv_norm_out, float *head,
+                         float *dhead, int B, int A, int mode, float cliprange, float value_loss_coef, float entropy_coef,
+                         long long global_batch, double *partials, int partials_capacity, unsigned *counter,
+                         float *loss_out, float *dy2, float *gslab, float *sslab, int Jp, int nwg, int rows_per_wg,
+                         hipStream_t stream);
 int launch_tail_grads(const float *params, float *grads, const long long *off_w, const long long *off_b, int A,
                       float *scratch, int B, hipStream_t stream);
 int launch_tail_act(const float *y2, const float *Wc, const float *beff, int B, int A, const float *uniforms, uint64_t seed,

@@ -420,6 +420,13 @@ int launch_tail_pack(const float *params, const long long *off_w, const long lon
   return DX_OK;
 }
 
+// where launch_tail_bwd's partial G / s live inside `scratch` and how its rows are split (heads.hip's fused
+// loss + backward launch writes the same slabs)
+TailBwdPlan tail_bwd_plan(float *scratch, int B, int A) {
+  const int nwg = tail_bwd_workgroups(B), Jp = tail_rows(A);
+  return TailBwdPlan{scratch, scratch + static_cast<long long>(nwg) * Jp * kK, Jp, nwg, cdiv(B, nwg)};
+}
+
 // dy2 and the partial G / s of the minibatch (scratch: tail_slab_floats(B) floats); then
 // launch_tail_grads turns them into the linear layer's and the heads' gradients
 int launch_tail_bwd(const float *y2, const float *dhead, const float *Wc, float *dy2, float *scratch, int B, int A,

@@ -409,6 +409,10 @@ int dx_cnn_tail_factored(const dx_cnn_ctx *ctx);
  * derl/env/make_env.py:94-106 builds heads of any width, derl/models.py:186-203) where the tail is factored, up to 7 on
  * the layer-by-layer route; 0: dx_cnn_forward + dx_categorical_loss_f32 + dx_cnn_backward. */
 int dx_cnn_fused_heads(const dx_cnn_ctx *ctx);
+/* 1 when dx_cnn_heads_loss_f32 on this ctx ALSO forms dy2 and the partial gradients of the linear layer + heads (the
+ * factored tail with up to 7 actions: its loss and its backward pass over y2 are one launch, and dx_cnn_backward_part
+ * 2 / 3 then start behind them); 0: that pass is the first launch of dx_cnn_backward_part 2 / 3.  (DX_TAIL_FUSED=0.) */
+int dx_cnn_tail_fused(const dx_cnn_ctx *ctx);
 int dx_cnn_stage(const dx_cnn_ctx *ctx, int stage, const void *obs, int obs_is_u8,
                  const int32_t *sample_idx, int B, void *stream);
 

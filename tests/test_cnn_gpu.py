@@ -680,6 +680,7 @@ def test_side_stream_routes_are_bit_identical_to_the_serial_ones():
 SWITCH_SETTINGS = ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_TN_SWIZZLE=0", "DX_LAT_MAX_TILES=0", "DX_WGRAD_DIRECT=0",
                    "DX_WGRAD_DIRECT_MIN_B=1", "DX_NT_DMA=0", "DX_NTP=0",
                    "DX_FC_FACTORED=0",                           # linear layer + heads layer by layer in updates and rollouts
+                   "DX_TAIL_FUSED=0",                            # the factored tail's loss and its backward pass as two launches
                    "DX_CONVSTACK=0", "DX_CONVSTACK=0 DX_FC_FACTORED=0 DX_FC_ROLLOUT=0",  # the rollout's layer-by-layer kernels
                    "DX_CONVSTACK_TRAIN=0 DX_WGRAD_B6=0 DX_DGRAD_B6=0",  # the update's fp32-MFMA conv stages
                    "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size

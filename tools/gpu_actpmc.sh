@@ -14,7 +14,7 @@ rows = list(csv.DictReader(open(f[0])))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
   name = r["Kernel_Name"]
-  if "convstack_image_kernel<false>" in name or "convstack_image_kernel<(bool)0>" in name or "tail_act" in name:
+  if "convstack_roll_kernel" in name or "tail_act" in name:
     acc[name[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in acc.items():
   print(k, {c: round(sum(x) / len(x)) for c, x in v.items()}, "dispatches", len(next(iter(v.values()))))

@@ -25,21 +25,23 @@ STAGE_OF = [  # substring of the kernel name -> stage
     ("conv0_wgrad_b16", "conv0_wgrad"), ("finalize_fused_kernel", "finalize"), ("permute_reduce_kernel", "finalize"),
     ("fc_row_unpermute_reduce", "finalize_fc"),
     # the factored tail (csrc/tail.hip, heads.hip) and the rollout's one-kernel step (csrc/convstack.hip)
+    ("tail_loss_bwd_kernel", "tail_loss_bwd"),  # round 5: loss + the backward pass over y2 in one launch
     ("tail_loss_kernel", "tail_loss"), ("tail_bwd_kernel", "tail_bwd"), ("tail_greduce_kernel", "tail_greduce"),
-    ("tail_grads_kernel", "tail_grads"),
+    ("tail_grads_kernel", "tail_grads_products"),
     # round 4: the update's conv stages on the bf16 matrix cores (convstack.hip `train`, wgrad_b6.hip, dgrad_b6.hip)
     ("convstack_image_kernel<true>", "conv_stack_fwd"), ("convstack_image_kernel<(bool)1>", "conv_stack_fwd"),
     ("convstack_train_kernel", "conv_stack_fwd"),  # round 5: the role-specialised training forward (convstack_train.hip)
     ("conv_wgrad_b6_kernel<1>", "conv1_wgrad"), ("conv_wgrad_b6_kernel<2>", "conv2_wgrad"),
     ("conv_dgrad_b6_kernel<1>", "conv1_dgrad"), ("conv_dgrad_b6_kernel<2>", "conv2_dgrad"),
 ]
-ROLLOUT_STEP = "rollout_step (convstack_image_kernel<false>, 256 images, one step)"
+ROLLOUT_STEP = "rollout_step (convstack_roll_kernel, 256 images, one step)"
 
 
 def is_rollout_kernel(name):
-  """The ROLLOUT flavour of the conv-stack kernel only (round 4's file took any `convstack_image` symbol, and the
-  training flavour -- launched by the same tool's warm-up -- won)."""
-  return "convstack_image_kernel<false>" in name or "convstack_image_kernel<(bool)0>" in name
+  """The ROLLOUT kernel of the conv stack only: convstack_roll_kernel (round 5; the training forward is its own symbol,
+  convstack_train_kernel, now).  Round 4's tool matched any `convstack_image` symbol and the training flavour --
+  launched by the same tool's warm-up -- won."""
+  return "convstack_roll_kernel" in name or "convstack_image_kernel<false>" in name or "convstack_image_kernel<(bool)0>" in name
 
 
 def mean_per_kernel(root, counter):
