@@ -982,19 +982,30 @@ __global__ __launch_bounds__(kFbThreads) void tail_loss_bwd_kernel(const TailLos
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool is_logit = col < A;
   const int r0 = blockIdx.x * a.rows_per_wg, r1 = min(a.B, r0 + a.rows_per_wg);
-  for (int r = r0; r < r1; r += kFbRows) {
-    float y[kFbRows][kFbCols];
+  // a pass's four rows (and this wave's row scalars, waves 0-3) are loaded one pass AHEAD, behind the previous pass's dots
+  float y[kFbRows][kFbCols], yn[kFbRows][kFbCols];
+  int p_act = 0, n_act = 0;
+  float p_adv = 0.f, p_vt = 0.f, p_olp = 0.f, p_ov = 0.f, n_adv = 0.f, n_vt = 0.f, n_olp = 0.f, n_ov = 0.f;
+  auto fetch = [&](int r) {
 #pragma unroll
     for (int u = 0; u < kFbRows; ++u) {
       const long long row = min(r + u, a.B - 1);
 #pragma unroll
-      for (int i = 0; i < kFbCols; ++i) y[u][i] = a.y2[row * kTailK + t + kFbThreads * i];
+      for (int i = 0; i < kFbCols; ++i) yn[u][i] = a.y2[row * kTailK + t + kFbThreads * i];
     }
-    // this wave's row (waves 0-3): its scalars, in flight with the row loads
     const int myrow = min(r + (wave < kFbRows ? wave : 0), a.B - 1);
-    const int p_act = static_cast<int>(a.actions[myrow]);
-    const float p_adv = a.advantages[myrow], p_vt = a.value_targets[myrow];
-    const float p_olp = a.mode == 0 ? a.old_log_prob[myrow] : 0.f, p_ov = a.mode == 0 ? a.old_values[myrow] : 0.f;
+    n_act = static_cast<int>(a.actions[myrow]);
+    n_adv = a.advantages[myrow]; n_vt = a.value_targets[myrow];
+    n_olp = a.mode == 0 ? a.old_log_prob[myrow] : 0.f; n_ov = a.mode == 0 ? a.old_values[myrow] : 0.f;
+  };
+  if (r0 < r1) fetch(r0);
+  for (int r = r0; r < r1; r += kFbRows) {
+#pragma unroll
+    for (int u = 0; u < kFbRows; ++u)
+#pragma unroll
+      for (int i = 0; i < kFbCols; ++i) y[u][i] = yn[u][i];
+    p_act = n_act; p_adv = n_adv; p_vt = n_vt; p_olp = n_olp; p_ov = n_ov;
+    if (r + kFbRows < r1) fetch(r + kFbRows);
     // ---- the four rows' outputs: per-thread partial dots, wave sums, seven waves through LDS ----
     float mine = 0.f;
 #pragma unroll
