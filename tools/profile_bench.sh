@@ -13,6 +13,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 DX_BWD_OVERLAP=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof_serial -o bench -- python3 $R/bench.py --no-cpu-baseline --no-other-configs > $R/gpurun_out/${TAG}_bench_under_rocprof_serial.json 2> $R/gpurun_out/${TAG}_rocprof_serial.err || exit 1
 timeout -k 10 200 python3 $R/bench.py --nenvs 32 --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs > $R/gpurun_out/${TAG}_shard32.json 2> /dev/null || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_s32prof -o s32 -- python3 $R/bench.py --nenvs 32 --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs > $R/gpurun_out/${TAG}_shard32_under_rocprof.json 2> /dev/null || exit 1
+# the 4- and 2-GPU shards of the same run (64 / 128 envs): the strong-scaling points of DESIGN.md section 5
+timeout -k 10 200 python3 $R/bench.py --nenvs 64 --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs > $R/gpurun_out/${TAG}_shard64.json 2> /dev/null || exit 1
+timeout -k 10 200 python3 $R/bench.py --nenvs 128 --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs > $R/gpurun_out/${TAG}_shard128.json 2> /dev/null || exit 1
 timeout -k 10 200 python3 $R/tools/bench_configs.py c3 10 > $R/gpurun_out/${TAG}_c3.json 2> /dev/null || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_c3prof -o c3 -- python3 $R/tools/bench_configs.py c3 5 > $R/gpurun_out/${TAG}_c3_under_rocprof.json 2> /dev/null || exit 1
 timeout -k 10 200 python3 $R/tools/bench_configs.py c5 100 > $R/gpurun_out/${TAG}_c5.json 2> /dev/null || exit 1

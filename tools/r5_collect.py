@@ -26,7 +26,8 @@ def copy(src, dst):
   return True
 
 
-for name in ("bench", "bench_under_rocprof", "bench_under_rocprof_serial", "shard32", "shard32_under_rocprof", "c3", "c3_under_rocprof", "c5"):
+for name in ("bench", "bench_under_rocprof", "bench_under_rocprof_serial", "shard32", "shard32_under_rocprof", "shard64", "shard128", "c3",
+             "c3_under_rocprof", "c5"):
   copy(f"r05_{name}.json", f"r05_{name}.json")
 copy("r05_prof/**/bench_kernel_stats.csv", "r05_bench_kernel_stats.csv") or copy("r05_prof/bench_kernel_stats.csv", "r05_bench_kernel_stats.csv")
 copy("r05_prof_serial/bench_kernel_stats.csv", "r05_bench_kernel_stats_serial.csv")
