@@ -115,10 +115,19 @@ __device__ __forceinline__ void store_planes4(uint8_t *smem, int off, int plane_
   *reinterpret_cast<uint2 *>(smem + off + 2 * plane_bytes) = s.lo;
 }
 
-// 16 raw bytes of a frame (16-byte unit `unit` of its 28,224 bytes) -> 16 bf16 in the LDS frame: converted here, once
+// The LDS frame: 84 x 84 pixels x 4 channels as bf16, in 16-byte chunks of two pixels.  The chunks of a row go to TWO
+// planes by parity -- chunk 2 j of row y to plane 0, chunk 2 j + 1 to plane 1, both at index 21 y + j -- because conv0's
+// operand read of lane (pixel, k half kg) is chunk 2 ox + 2 (c & 1) + kg of its row: with the chunks in row-major order the
+// 16 lanes of an LDS cycle (one kg, 16 pixels) hit only the even or only the odd 16-byte bank quads, 7.8 cycles per
+// ds_read_b128 for 4 (SQ_LDS_BANK_CONFLICT of the diag variants: 775 conflict cycles per image in these reads, 220 more
+// in the stores below); per plane they are 16 consecutive chunks.
+constexpr int kFramePlaneB = kFrame16B / 2;
+static_assert(kFramePlaneB == 16 * 21 * kIn, "21 chunks of each parity per row");
+// 16 raw bytes of a frame (16-byte unit `unit` of its 28,224 bytes = four pixels = one chunk of each parity) -> 16 bf16
+// in the LDS frame: converted here, once
 __device__ __forceinline__ void put_frame_unit(uint8_t *smem, int unit, u32x4 raw) {
-  *reinterpret_cast<bf16x8 *>(smem + oFrame + 32 * unit) = cs_expand8(uint2{raw.x, raw.y});
-  *reinterpret_cast<bf16x8 *>(smem + oFrame + 32 * unit + 16) = cs_expand8(uint2{raw.z, raw.w});
+  *reinterpret_cast<bf16x8 *>(smem + oFrame + 16 * unit) = cs_expand8(uint2{raw.x, raw.y});
+  *reinterpret_cast<bf16x8 *>(smem + oFrame + kFramePlaneB + 16 * unit) = cs_expand8(uint2{raw.z, raw.w});
 }
 
 // conv0 for NT_ 32-pixel tiles (tile0, tile0 + TS, ...) of this wave: D[channel][pixel] = sum over the 16 K
@@ -134,7 +143,7 @@ __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int l
   for (int t = 0; t < NT_; ++t) {
     const int p = min(32 * (tile0 + TS * t) + r, kP0 - 1);  // columns past the image compute a copy that is not stored
     const int oy = p / 20, ox = p - 20 * oy;
-    pb[t] = oFrame + 2 * ((4 * oy * kIn + 4 * ox) * 4 + 8 * kg);
+    pb[t] = oFrame + kg * kFramePlaneB + 16 * (kIn * oy + ox);  // chunk 21 (4 oy) + ox of plane kg
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   }
@@ -151,7 +160,7 @@ __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int l
     bf16x8 pxn[NT_];
     u32x4 wfn[3];
     if (c + 1 < 16) {
-      const int aoff = 2 * (((c + 1) >> 1) * kRowB + 16 * ((c + 1) & 1));
+      const int aoff = 16 * (((c + 1) >> 1) * 21 + ((c + 1) & 1));  // kernel row (c + 1) / 2, pixels 4 ((c + 1) % 2) + 2 kg ..
 #pragma unroll
       for (int t = 0; t < NT_; ++t) pxn[t] = *reinterpret_cast<const bf16x8 *>(smem + pb[t] + aoff);
 #pragma unroll
