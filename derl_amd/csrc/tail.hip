@@ -298,7 +298,7 @@ struct TailGradArgs {
 constexpr int kGradBlocksW = kNH * (kK / 4) / 256;  // 1568: dWfc, one float4 per thread
 
 // dWfc = Wh^T G | dWh = G Wfc^T + s bfc^T | dbfc = Wh^T s, dbh = s -- three roles in one grid
-template <int Jp>  // 8, 16 or 24 (see tail_pack_finish_kernel)
+template <int Jp>  // 8, 16 or 24 padded output rows: compile-time so that the common case (up to 7 actions) keeps eight registers per array
 __global__ __launch_bounds__(256) void tail_grads_kernel(const TailGradArgs a) {
   const int t = threadIdx.x, blk = blockIdx.x;
   if (blk < kGradBlocksW) {
