@@ -269,6 +269,49 @@ def test_native_epoch_never_silently_differs_from_one_update_per_step(kind):
   assert calls == [] and alg.trainer.optimizer.step_count == 2
 
 
+def test_mirrors_after_an_epoch_that_another_epoch_follows():
+  """dx_cnn_epoch.more_epochs: the last update of an epoch that another epoch of the same rollout follows re-packs only
+  what the training kernels read (the full pack runs once per rollout).  The engine knows: whatever else reads the
+  mirrors between the epochs -- here the rollout's act step and the layer-by-layer forward -- packs first and sees the
+  stepped parameters, and the epoch that follows trains on from the light mirrors (mirrors_current = 2)."""
+  from derl_amd.cnn_engine import CnnEngine
+  alg, calls = make_alg("cnn", True, 8, 16, 2, 4)
+  import derl_amd as derl
+  it = alg.runner.run()
+  for _ in range(4):  # the first of the rollout's two epochs
+    data = next(it)
+    derl.summary.stop_recording()
+    alg.step(data)
+  eng = alg.model.engine
+  assert calls == [4] and eng.open_epoch is None
+  assert eng._packed_version is None and eng._train_packed_version == eng._version()
+  fresh = CnnEngine(eng.num_actions, max_batch=64, device=eng.device)  # the same parameters, every mirror packed
+  fresh.params.copy_(eng.params)
+  fresh.mark_dirty()
+  obs = torch.randint(0, 256, (8, 84, 84, 4), dtype=torch.uint8, device=eng.device, generator=torch.Generator(eng.device).manual_seed(5))
+  uniforms = torch.rand(8, device=eng.device, generator=torch.Generator(eng.device).manual_seed(6))
+  outs = []
+  for e in (eng, fresh):
+    actions = torch.empty(8, dtype=torch.int64, device=eng.device)
+    log_prob, values = torch.empty(8, device=eng.device), torch.empty(8, device=eng.device)
+    e.act(obs, actions, log_prob, values, uniforms=uniforms)
+    outs.append((actions.clone(), log_prob.clone(), values.clone(), e.forward(obs).clone()))
+  for a, b in zip(*outs):
+    assert torch.equal(a, b)
+  assert eng._packed_version == eng._version()  # act packed on demand
+  # the second epoch trains on from the light mirrors: the same parameters as a run whose epochs all end with the full pack
+  other, _ = make_alg("cnn", True, 8, 16, 2, 4)
+  it2 = other.runner.run()
+  for k in range(8):
+    if k >= 4:
+      alg.step(next(it))
+    data2 = next(it2)
+    derl.summary.stop_recording()
+    data2.epoch[0].more_epochs = False  # (read when the epoch's first minibatch is stepped)
+    other.step(data2)
+  assert torch.equal(alg.model.engine.params, other.model.engine.params)
+
+
 def _scalars_of_a_run(native):
   """Every scalar the summaries record over one rollout's updates, as (tag, global_step, value)."""
   import derl_amd as derl
