@@ -182,11 +182,12 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
       }
       f32x4 acc[4] = {zero4, zero4, zero4, zero4};
       conv_run<0, 1, 4, 8, 9>(smem, pb1, R, acc, w1h1, w2h0, lane16);
-      u32x4 fr[3];  // pieces 16 + nt + 4 u of the env's next frame (the A waves make pieces 0 .. 15)
+      u32x4 fr[4];  // pieces 12 + nt + 4 u of the env's next frame (the A waves make pieces 0 .. 11: their conv1 tiles end
+                    // later than these four -- a SIMD serves its older wave first -- so the B waves take the larger share)
       if (env) {
         const int lf = opaque(lane);
 #pragma unroll
-        for (int u = 0; u < 3; ++u) fr[u] = frame_unit(t, (16 + nt + 4 * u) * 64 + lf);
+        for (int u = 0; u < 4; ++u) fr[u] = frame_unit(t, (12 + nt + 4 * u) * 64 + lf);
       }
       DX_CS_MARK(1)
       lds_barrier();  // beta: every wave has read y0 -- the y1 planes may overwrite its start, the next frame its end
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
       if (env) {
         const int lf = opaque(lane);
 #pragma unroll
-        for (int u = 0; u < 3; ++u) put_unit(t, (16 + nt + 4 * u) * 64 + lf, fr[u], next0);
+        for (int u = 0; u < 4; ++u) put_unit(t, (12 + nt + 4 * u) * 64 + lf, fr[u], next0);
       }
       DX_CS_MARK(3)
       lds_barrier();  // gamma: y1 and the next frame are complete
@@ -307,12 +308,12 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
       f32x4 acc[2] = {zero4, zero4};
       conv_run<0, 1, 2, 8, 0, 1>(smem, pb1, R, acc, w1h1, w1h0, lane16);
       // The synthetic env's NEXT frame of this env: this wave's four KB of it, in registers until beta frees the LDS slot
-      u32x4 fr[4];  // pieces aw + 4 u (the B waves make pieces 16 .. 27 behind their four conv1 tiles)
+      u32x4 fr[3];  // pieces aw + 4 u (the B waves make pieces 12 .. 27 behind their four conv1 tiles)
       if (env) {
         const uint64_t key = synth_mix64(a.env_seed * 0x9E3779B97F4A7C15ull + (a.env_counter + t));
         const int lf = opaque(lane);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fr[u] = frame_unit(t, (aw + 4 * u) * 64 + lf);
+        for (int u = 0; u < 3; ++u) fr[u] = frame_unit(t, (aw + 4 * u) * 64 + lf);
         if (tid == 256) {
           const uint64_t r = synth_mix64(~key + static_cast<uint64_t>(a.env0 + e) * 0xD1B54A32D192ED03ull);
           const float u0 = static_cast<float>(r & 0xffffff) * (1.0f / 16777216.0f);
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
       if (env) {
         const int lf = opaque(lane);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) put_unit(t, (aw + 4 * u) * 64 + lf, fr[u], next0);
+        for (int u = 0; u < 3; ++u) put_unit(t, (aw + 4 * u) * 64 + lf, fr[u], next0);
       }
       DX_CS_MARK(3)
       lds_barrier();  // gamma
