@@ -306,8 +306,9 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
         }
       }
       f32x4 acc[2] = {zero4, zero4};
-      conv_run<0, 1, 2, 8, 0, 1>(smem, pb1, R, acc, w1h1, w1h0, lane16);
-      // The synthetic env's NEXT frame of this env: this wave's four KB of it, in registers until beta frees the LDS slot
+      // The synthetic env's NEXT frame of this env: this wave's three KB of it, in registers until beta frees the LDS slot.
+      // Generated BEFORE the conv1 tiles: this SIMD's B wave is served first by the matrix pipe, so these tiles end when B's
+      // four do whenever they start, and the hash's vector-ALU work runs beside B's MFMAs instead of behind both
       u32x4 fr[3];  // pieces aw + 4 u (the B waves make pieces 12 .. 27 behind their four conv1 tiles)
       if (env) {
         const uint64_t key = synth_mix64(a.env_seed * 0x9E3779B97F4A7C15ull + (a.env_counter + t));
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
           if (a.resets) a.resets[row] = u1 < a.p_reset ? 1 : 0;
         }
       }
+      conv_run<0, 1, 2, 8, 0, 1>(smem, pb1, R, acc, w1h1, w1h0, lane16);
       DX_CS_MARK(1)
       lds_barrier();  // beta
       DX_CS_MARK(2)
