@@ -158,13 +158,28 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
     const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
     const int Jp = (a.A + 8) & ~7;
     lds_barrier();  // p1: frame 0 and conv0's planes are in LDS
+    // conv0: the A waves take tiles 0 .. 11 (three each); the half-valid 13th tile (pixels 384 .. 399) is shared by waves 0
+    // and 1, eight K chunks each, wave 1's sums reach wave 0 through LDS behind the phase's last barrier (convstack_train.hip)
+    auto conv0_half = [&](f32x16 (&accb)[1], int l) {
+      if (nt == 0) conv0_mfma<1, 4, 1, 0, 8>(smem, 12, l, accb);
+      else if (nt == 1) {
+        conv0_mfma<1, 4, 1, 8, 16>(smem, 12, l, accb);
+        exch_put(smem, l, accb[0]);
+      }
+    };
+    auto conv0_finish = [&](f32x16 (&accb)[1], int l) {
+      if (nt == 0) {
+        exch_add(smem, l, accb[0]);
+        f32x4 bias0[4];
+        load_bias0(bias0, l);
+        conv0_store<1, 4, 1>(smem, 12, l, accb, bias0, nullptr);
+      }
+    };
     {
       f32x16 accb[1];
-      conv0_mfma<1, 4, 1>(smem, nt, lane, accb);
+      conv0_half(accb, lane);
       lds_barrier();  // p2: every wave has read the frame
-      f32x4 bias0[4];
-      load_bias0(bias0, lane);
-      conv0_store<1, 4, 1>(smem, nt, lane, accb, bias0, nullptr);
+      conv0_finish(accb, lane);
     }
     for (t = 0; t < T; ++t) {
       const bool next0 = env && t + 1 < T;  // (uniform) another step follows: its conv0 runs under this step's conv2
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
       f32x4 acc2[4] = {zero4, zero4, zero4, zero4};
       conv_run<0, 2, 4, 9, 8>(smem, pb2, R, acc2, w2h1, w1h0, lane16);
       f32x16 accb[1];
-      if (next0) conv0_mfma<1, 4, 1>(smem, nt, opaque(lane), accb);
+      if (next0) conv0_half(accb, opaque(lane));
       DX_CS_MARK(5)
       lds_barrier();  // delta: every wave has read y1 and the frame -- the y0 planes may overwrite both
       DX_CS_MARK(6)
@@ -259,11 +274,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
         }
         if (l3 <= a.A) tailred[(t & 1) * (8 * kTailOut) + nt * kTailOut + l3] = mine;  // sampled by wave 7 behind the next alpha
       }
-      if (next0) {
-        f32x4 bias0[4];
-        load_bias0(bias0, l3);
-        conv0_store<1, 4, 1>(smem, nt, l3, accb, bias0, nullptr);
-      }
+      if (next0) conv0_finish(accb, l3);
     }
   } else {
     // ============ A: conv1's tiles 4-5 of step t; the env's next frame; conv0 of step t + 1; the sample of step t - 1 ============
@@ -278,16 +289,31 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) R[8][pl] = R[7][pl];
     const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);
+    // conv0's tiles aw, 4 + aw, 8 + aw: one instantiation per wave (the addresses fold against the constant tile index)
+    auto conv0_tiles = [&](int l, f32x16 (&acc0)[3]) {
+      switch (aw) {
+        case 0: conv0_mfma<3, 4, 3>(smem, 0, l, acc0); break;
+        case 1: conv0_mfma<3, 4, 3>(smem, 1, l, acc0); break;
+        case 2: conv0_mfma<3, 4, 3>(smem, 2, l, acc0); break;
+        default: conv0_mfma<3, 4, 3>(smem, 3, l, acc0); break;
+      }
+    };
+    auto conv0_tiles_store = [&](int l, const f32x16 (&acc0)[3], const f32x4 (&bias0)[4]) {
+      switch (aw) {
+        case 0: conv0_store<3, 4, 3>(smem, 0, l, acc0, bias0, nullptr); break;
+        case 1: conv0_store<3, 4, 3>(smem, 1, l, acc0, bias0, nullptr); break;
+        case 2: conv0_store<3, 4, 3>(smem, 2, l, acc0, bias0, nullptr); break;
+        default: conv0_store<3, 4, 3>(smem, 3, l, acc0, bias0, nullptr); break;
+      }
+    };
     lds_barrier();  // p1
     {
       f32x16 acc0[3];
-      if (aw == 0) conv0_mfma<3, 4, 3>(smem, 4 + aw, lane, acc0);
-      else conv0_mfma<2, 4, 3>(smem, 4 + aw, lane, acc0);
+      conv0_tiles(lane, acc0);
       lds_barrier();  // p2
       f32x4 bias0[4];
       load_bias0(bias0, lane);
-      if (aw == 0) conv0_store<3, 4, 3>(smem, 4 + aw, lane, acc0, bias0, nullptr);
-      else conv0_store<2, 4, 3>(smem, 4 + aw, lane, acc0, bias0, nullptr);
+      conv0_tiles_store(lane, acc0, bias0);
     }
     for (t = 0; t < T; ++t) {
       const bool next0 = env && t + 1 < T;
@@ -340,8 +366,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
       DX_CS_MARK(4)
       if (next0) {
         const int l0 = opaque(lane);
-        if (aw == 0) conv0_mfma<3, 4, 3>(smem, 4 + aw, l0, acc0);
-        else conv0_mfma<2, 4, 3>(smem, 4 + aw, l0, acc0);
+        conv0_tiles(l0, acc0);
 #pragma unroll
         for (int s = 0; s < 8; ++s)  // the next step's conv1 taps 0-7: under the epilogue
 #pragma unroll
@@ -354,8 +379,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
         const int l0 = opaque(lane);
         f32x4 bias0[4];
         load_bias0(bias0, l0);
-        if (aw == 0) conv0_store<3, 4, 3>(smem, 4 + aw, l0, acc0, bias0, nullptr);
-        else conv0_store<2, 4, 3>(smem, 4 + aw, l0, acc0, bias0, nullptr);
+        conv0_tiles_store(l0, acc0, bias0);
       }
     }
   }
@@ -447,7 +471,7 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
   const int B = a.train ? (a.B < cus ? a.B : cus) : a.B;  // workgroups
   if (a.train) return launch_convstack_train(a, B, stream);  // waves specialised by layer, two images in flight
   {
-    DX_LDS_OPT_IN(convstack_roll_kernel, kLdsBytes);
+    DX_LDS_OPT_IN(convstack_roll_kernel, kLdsBytesX);
 #if DX_DIAG
     if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one step (DX_CS_STEP) as seen by wave DX_CS_DIAG, on stderr (synchronous)
       unsigned long long *dev_stamps = nullptr;
@@ -457,7 +481,7 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
       a.env0 |= stamp_wave << 24;  // (timing build only: sampling positions are not what is looked at)
       a.stamp_step = getenv("DX_CS_STEP") ? atoi(getenv("DX_CS_STEP")) : 0;
       if (a.stamp_step >= a.T) a.stamp_step = a.T - 1;
-      hipLaunchKernelGGL(convstack_roll_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
+      hipLaunchKernelGGL(convstack_roll_kernel, dim3(B), dim3(512), kLdsBytesX, stream, a);
       DX_LAUNCH_CHECK();
       DX_HIP(hipStreamSynchronize(stream));
       std::vector<unsigned long long> h(static_cast<size_t>(B) * 16);
@@ -485,7 +509,7 @@ int launch_convstack(const ConvStackArgs &args, hipStream_t stream) {
       return DX_OK;
     }
 #endif
-    hipLaunchKernelGGL(convstack_roll_kernel, dim3(B), dim3(512), kLdsBytes, stream, a);
+    hipLaunchKernelGGL(convstack_roll_kernel, dim3(B), dim3(512), kLdsBytesX, stream, a);
     DX_LAUNCH_CHECK();
     return DX_OK;
   }

@@ -32,7 +32,22 @@ constexpr int kFrame16B = 2 * kFrameB;  // 84 x 84 x 4 bf16
 constexpr int oW0 = 0, oB = oW0 + 3 * kWPlaneB, oY0 = oB, oY1 = oB, oFrame = oB + 3 * kY1Plane;
 constexpr int kRegionB = 3 * kY0Plane > 3 * kY1Plane + kFrame16B ? 3 * kY0Plane : 3 * kY1Plane + kFrame16B;
 constexpr int oTail = oB + kRegionB, kTailOut = 24, kLdsBytes = oTail + 2 * 8 * kTailOut * 4;  // (tail: [step parity][8 waves][up to 24 padded outputs])
-static_assert(oB % 16 == 0 && oFrame % 16 == 0 && oTail % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS layout");
+// conv0's 13th tile (pixels 384 .. 399) is multiplied in two K halves by the first two B waves: the second half's partial
+// sums cross to wave 0 through this area (one f32x16 per lane), behind the barrier that ends the phase
+constexpr int oExch = kLdsBytes, kExchB = 64 * 64, kLdsBytesX = kLdsBytes + kExchB;
+static_assert(oB % 16 == 0 && oFrame % 16 == 0 && oTail % 16 == 0 && oExch % 16 == 0 && kLdsBytesX <= 160 * 1024, "LDS layout");
+__device__ __forceinline__ void exch_put(uint8_t *smem, int lane, const f32x16 &v) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(smem + oExch + q * 1024 + lane * 16) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+__device__ __forceinline__ void exch_add(const uint8_t *smem, int lane, f32x16 &v) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 w = *reinterpret_cast<const f32x4 *>(smem + oExch + q * 1024 + lane * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[4 * q + j] += w[j];
+  }
+}
 
 // two bytes -> two bf16 (exact: the fp32 of an integer < 256 has a zero low half)
 __device__ __forceinline__ uint32_t cs_bytes_to_bf16x2(float f0, float f1) {
@@ -134,9 +149,11 @@ __device__ __forceinline__ void put_frame_unit(uint8_t *smem, int unit, u32x4 ra
 // chunks of W0(planes lo, mid, hi) x pixels; every weight fragment is read from LDS once per chunk for all of the
 // wave's tiles.  One scheduling region per chunk: its 3 NT_ MFMAs with the NEXT chunk's 3 + NT_ fragment reads
 // interleaved, one read behind each of the first MFMAs (no vector-ALU work: the pixels are bf16 in LDS).
-template <int NT_, int TS = 8, int NA = 2>
+// (C0 .. C1 - 1: the K chunks this call multiplies -- all sixteen, or one half of them where two waves share a tile and add
+// their partial sums afterwards)
+template <int NT_, int TS = 8, int NA = 2, int C0 = 0, int C1 = 16>
 __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int lane, f32x16 (&acc)[NA]) {
-  static_assert(NT_ <= NA, "accumulator tiles");
+  static_assert(NT_ <= NA && 0 <= C0 && C0 < C1 && C1 <= 16, "accumulator tiles; chunk range");
   const int r = lane & 31, kg = lane >> 5;
   int pb[NT_];
 #pragma unroll
@@ -150,16 +167,17 @@ __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int l
   const int wb = oW0 + r * kWRowB + 16 * kg;
   bf16x8 px[NT_];
   u32x4 wf[3];
+  constexpr int aoff0 = 16 * ((C0 >> 1) * 21 + (C0 & 1));
 #pragma unroll
-  for (int t = 0; t < NT_; ++t) px[t] = *reinterpret_cast<const bf16x8 *>(smem + pb[t]);
+  for (int t = 0; t < NT_; ++t) px[t] = *reinterpret_cast<const bf16x8 *>(smem + pb[t] + aoff0);
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB);
+  for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const u32x4 *>(smem + wb + pl * kWPlaneB + 32 * C0);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {  // chunk c: kernel row c / 2, bytes 16 (c % 2) .. + 15 of its 32
+  for (int c = C0; c < C1; ++c) {  // chunk c: kernel row c / 2, bytes 16 (c % 2) .. + 15 of its 32
     bf16x8 pxn[NT_];
     u32x4 wfn[3];
-    if (c + 1 < 16) {
+    if (c + 1 < C1) {
       const int aoff = 16 * (((c + 1) >> 1) * 21 + ((c + 1) & 1));  // kernel row (c + 1) / 2, pixels 4 ((c + 1) % 2) + 2 kg ..
 #pragma unroll
       for (int t = 0; t < NT_; ++t) pxn[t] = *reinterpret_cast<const bf16x8 *>(smem + pb[t] + aoff);
@@ -170,7 +188,7 @@ __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int l
     for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
       for (int t = 0; t < NT_; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[pl]), px[t], acc[t], 0, 0, 0);
-    if (c + 1 < 16) {
+    if (c + 1 < C1) {
       constexpr int kReads = 3 + NT_, kMfma = 3 * NT_;
 #pragma unroll
       for (int i = 0; i < (kReads < kMfma ? kReads : kMfma); ++i) {
@@ -181,7 +199,7 @@ __device__ __forceinline__ void conv0_mfma(const uint8_t *smem, int tile0, int l
       if (kMfma > kReads) __builtin_amdgcn_sched_group_barrier(0x008, kMfma - kReads, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (c + 1 < 16) {
+    if (c + 1 < C1) {
 #pragma unroll
       for (int t = 0; t < NT_; ++t) px[t] = pxn[t];
 #pragma unroll

@@ -107,20 +107,36 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
     for (int pl = 0; pl < 3; ++pl) R[8][pl] = R[7][pl];  // (defined; first written for real behind conv1's second half)
     const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);
     const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(a.bias2 + oc0);
-    // conv0's tile nt is this wave's too (the A waves take tiles 4 .. 12): multiplied behind its conv2 loop, where it
-    // otherwise waited 4,300 cycles for the A wave's four tiles, and finished beside its conv2 epilogue
+    // conv0: the A waves take tiles 0 .. 11 (three each); the half-valid 13th tile is the first two B waves', behind their
+    // conv2 loops (round 5, first version: every B wave multiplied a whole tile behind conv2 -- 13,900 cycles where conv2
+    // alone takes 11,200 and the A waves with two tiles idled for 4,400)
     auto load_bias0 = [&](f32x4 (&bias0)[4], int l) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (l >> 5));
     };
     lds_barrier();  // p1: frame 0 and conv0's planes are in LDS
+    // conv0's 13th tile (pixels 384 .. 399) is shared by waves 0 and 1, eight K chunks each (conv0_half); wave 1's sums
+    // reach wave 0 through LDS behind the phase's last barrier (conv0_finish), wave 0 stores the tile
+    auto conv0_half = [&](f32x16 (&accb)[1], int l) {
+      if (nt == 0) conv0_mfma<1, 4, 1, 0, 8>(smem, 12, l, accb);
+      else if (nt == 1) {
+        conv0_mfma<1, 4, 1, 8, 16>(smem, 12, l, accb);
+        exch_put(smem, l, accb[0]);
+      }
+    };
+    auto conv0_finish = [&](f32x16 (&accb)[1], int l, float *gy0) {
+      if (nt == 0) {
+        exch_add(smem, l, accb[0]);
+        f32x4 bias0[4];
+        load_bias0(bias0, l);
+        conv0_store<1, 4, 1>(smem, 12, l, accb, bias0, gy0);
+      }
+    };
     {
       f32x16 accb[1];
-      conv0_mfma<1, 4, 1>(smem, nt, lane, accb);
+      conv0_half(accb, lane);
       lds_barrier();  // p2: every wave has read the frame
-      f32x4 bias0[4];
-      load_bias0(bias0, lane);
-      conv0_store<1, 4, 1>(smem, nt, lane, accb, bias0, a.y0 + static_cast<long long>(e) * (kP0 * 32));
+      conv0_finish(accb, lane, a.y0 + static_cast<long long>(e) * (kP0 * 32));
     }
     for (t = 0; t < steps; ++t, e += grid) {
       DX_CS_MARK(7)
@@ -177,16 +193,11 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
       f32x4 acc2[4] = {zero4, zero4, zero4, zero4};
       conv_run<V, 2, 4, 9, 8>(smem, pb2, R, acc2, w2h1, w1h0, lane16);  // (then the next image's first taps; behind the last image nobody reads them)
       f32x16 accb[1];
-      if (more && !(V & 4)) conv0_mfma<1, 4, 1>(smem, nt, opaque(lane), accb);
+      if (more && !(V & 4)) conv0_half(accb, opaque(lane));
       DX_CS_MARK(5)
       lds_barrier();  // delta: every wave has read y1 and the frame -- the y0 planes may overwrite both
       DX_CS_MARK(6)
-      if (more) {
-        const int l0 = opaque(lane);
-        f32x4 bias0[4];
-        load_bias0(bias0, l0);
-        conv0_store<1, 4, 1>(smem, nt, l0, accb, bias0, a.y0 + static_cast<long long>(e + grid) * (kP0 * 32));
-      }
+      if (more) conv0_finish(accb, opaque(lane), a.y0 + static_cast<long long>(e + grid) * (kP0 * 32));
       float *out = a.y2 + static_cast<long long>(e) * (kP2 * 64);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -223,17 +234,33 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) R[8][pl] = R[7][pl];  // (never used: conv1 has eight steps per half)
     const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.bias1 + oc0);
+    // conv0's tiles aw, 4 + aw, 8 + aw: one instantiation per wave, so that a lane's pixel / store addresses fold against
+    // the constant tile index (with the index in a register the three tiles' address arithmetic spilled 87 registers)
+    auto conv0_tiles = [&](int l, f32x16 (&acc0)[3]) {
+      switch (aw) {
+        case 0: conv0_mfma<3, 4, 3>(smem, 0, l, acc0); break;
+        case 1: conv0_mfma<3, 4, 3>(smem, 1, l, acc0); break;
+        case 2: conv0_mfma<3, 4, 3>(smem, 2, l, acc0); break;
+        default: conv0_mfma<3, 4, 3>(smem, 3, l, acc0); break;
+      }
+    };
+    auto conv0_tiles_store = [&](int l, const f32x16 (&acc0)[3], const f32x4 (&bias0)[4], float *gy0) {
+      switch (aw) {
+        case 0: conv0_store<3, 4, 3>(smem, 0, l, acc0, bias0, gy0); break;
+        case 1: conv0_store<3, 4, 3>(smem, 1, l, acc0, bias0, gy0); break;
+        case 2: conv0_store<3, 4, 3>(smem, 2, l, acc0, bias0, gy0); break;
+        default: conv0_store<3, 4, 3>(smem, 3, l, acc0, bias0, gy0); break;
+      }
+    };
     lds_barrier();  // p1: frame 0 and conv0's planes are in LDS
     {
       f32x16 acc0[3];
-      if (aw == 0) conv0_mfma<3, 4, 3>(smem, 4 + aw, lane, acc0);
-      else conv0_mfma<2, 4, 3>(smem, 4 + aw, lane, acc0);
+      conv0_tiles(lane, acc0);
       lds_barrier();  // p2: every A wave has read the frame
       float *gy0 = a.y0 + static_cast<long long>(e) * (kP0 * 32);
       f32x4 bias0[4];
       load_bias0(bias0, lane);
-      if (aw == 0) conv0_store<3, 4, 3>(smem, 4 + aw, lane, acc0, bias0, gy0);
-      else conv0_store<2, 4, 3>(smem, 4 + aw, lane, acc0, bias0, gy0);
+      conv0_tiles_store(lane, acc0, bias0, gy0);
     }
     for (t = 0; t < steps; ++t, e += grid) {
       const bool more = t + 1 < steps;  // (uniform) an image follows
@@ -279,8 +306,7 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
       DX_CS_MARK(4)
       if (more && !(V & 4)) {
         const int l0 = opaque(lane);
-        if (aw == 0) conv0_mfma<3, 4, 3>(smem, 4 + aw, l0, acc0);
-        else conv0_mfma<2, 4, 3>(smem, 4 + aw, l0, acc0);
+        conv0_tiles(l0, acc0);
       }
       if (more) {  // the next image's conv1 taps 0-7: under the epilogue (not carried through the conv0 loop: 96 registers)
 #pragma unroll
@@ -296,8 +322,7 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
         const int l0 = opaque(lane);
         f32x4 bias0[4];
         load_bias0(bias0, l0);
-        if (aw == 0) conv0_store<3, 4, 3>(smem, 4 + aw, l0, acc0, bias0, gy0);
-        else conv0_store<2, 4, 3>(smem, 4 + aw, l0, acc0, bias0, gy0);
+        conv0_tiles_store(l0, acc0, bias0, gy0);
       }
     }
   }
@@ -316,13 +341,13 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
 // the forward of a training minibatch (ConvStackArgs::train): a.B images over `blocks` workgroups (one per CU)
 int launch_convstack_train(const ConvStackArgs &args, int blocks, hipStream_t stream) {
   ConvStackArgs a = args;
-  DX_LDS_OPT_IN(convstack_train_kernel<0>, kLdsBytes);
+  DX_LDS_OPT_IN(convstack_train_kernel<0>, kLdsBytesX);
 #if DX_DIAG
-  DX_LDS_OPT_IN(convstack_train_kernel<1>, kLdsBytes);
-  DX_LDS_OPT_IN(convstack_train_kernel<2>, kLdsBytes);
-  DX_LDS_OPT_IN(convstack_train_kernel<3>, kLdsBytes);
-  DX_LDS_OPT_IN(convstack_train_kernel<4>, kLdsBytes);
-  DX_LDS_OPT_IN(convstack_train_kernel<7>, kLdsBytes);
+  DX_LDS_OPT_IN(convstack_train_kernel<1>, kLdsBytesX);
+  DX_LDS_OPT_IN(convstack_train_kernel<2>, kLdsBytesX);
+  DX_LDS_OPT_IN(convstack_train_kernel<3>, kLdsBytesX);
+  DX_LDS_OPT_IN(convstack_train_kernel<4>, kLdsBytesX);
+  DX_LDS_OPT_IN(convstack_train_kernel<7>, kLdsBytesX);
 #endif
 #if DX_DIAG
   if (getenv("DX_CS_DIAG")) {  // in-kernel phase cycles of one image (DX_CS_STEP) as seen by wave DX_CS_DIAG, on stderr (synchronous)
@@ -336,12 +361,12 @@ int launch_convstack_train(const ConvStackArgs &args, int blocks, hipStream_t st
     if (a.stamp_step >= steps) a.stamp_step = steps - 1;
     const int variant = getenv("DX_CS_VARIANT") ? atoi(getenv("DX_CS_VARIANT")) : 0;  // (timing variants: WRONG results)
     switch (variant) {
-      case 1: hipLaunchKernelGGL(convstack_train_kernel<1>, dim3(blocks), dim3(512), kLdsBytes, stream, a); break;
-      case 2: hipLaunchKernelGGL(convstack_train_kernel<2>, dim3(blocks), dim3(512), kLdsBytes, stream, a); break;
-      case 3: hipLaunchKernelGGL(convstack_train_kernel<3>, dim3(blocks), dim3(512), kLdsBytes, stream, a); break;
-      case 4: hipLaunchKernelGGL(convstack_train_kernel<4>, dim3(blocks), dim3(512), kLdsBytes, stream, a); break;
-      case 7: hipLaunchKernelGGL(convstack_train_kernel<7>, dim3(blocks), dim3(512), kLdsBytes, stream, a); break;
-      default: hipLaunchKernelGGL(convstack_train_kernel<0>, dim3(blocks), dim3(512), kLdsBytes, stream, a);
+      case 1: hipLaunchKernelGGL(convstack_train_kernel<1>, dim3(blocks), dim3(512), kLdsBytesX, stream, a); break;
+      case 2: hipLaunchKernelGGL(convstack_train_kernel<2>, dim3(blocks), dim3(512), kLdsBytesX, stream, a); break;
+      case 3: hipLaunchKernelGGL(convstack_train_kernel<3>, dim3(blocks), dim3(512), kLdsBytesX, stream, a); break;
+      case 4: hipLaunchKernelGGL(convstack_train_kernel<4>, dim3(blocks), dim3(512), kLdsBytesX, stream, a); break;
+      case 7: hipLaunchKernelGGL(convstack_train_kernel<7>, dim3(blocks), dim3(512), kLdsBytesX, stream, a); break;
+      default: hipLaunchKernelGGL(convstack_train_kernel<0>, dim3(blocks), dim3(512), kLdsBytesX, stream, a);
     }
     DX_LAUNCH_CHECK();
     DX_HIP(hipStreamSynchronize(stream));
@@ -372,7 +397,7 @@ int launch_convstack_train(const ConvStackArgs &args, int blocks, hipStream_t st
 #endif
   a.stamps = nullptr;
   a.stamp_step = 0;
-  hipLaunchKernelGGL(convstack_train_kernel<0>, dim3(blocks), dim3(512), kLdsBytes, stream, a);
+  hipLaunchKernelGGL(convstack_train_kernel<0>, dim3(blocks), dim3(512), kLdsBytesX, stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
