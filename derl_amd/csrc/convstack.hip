@@ -112,6 +112,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (tid + 512 * u < kFrameB / 16) put_frame_unit(smem, tid + 512 * u, fr[u]);
+    bias0_to_lds(smem, a.bias0, tid);
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
       const int i = u * 512 + tid;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(512) void convstack_roll_kernel(const ConvStackArgs
   float *tailred = reinterpret_cast<float *>(smem + oTail);  // [step parity][8 waves][kTailOut outputs] (waves 0-3 write)
   auto load_bias0 = [&](f32x4 (&bias0)[4], int l) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (l >> 5));
+    for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(smem + oBias0 + 4 * (8 * q + 4 * (l >> 5)));
   };
   // 16-byte unit `unit` of the synthetic env's frame after step t (synth_atari_block's hash of (seed, counter, position))
   auto frame_unit = [&](int t_, int unit) {

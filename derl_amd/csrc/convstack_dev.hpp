@@ -34,8 +34,17 @@ constexpr int kRegionB = 3 * kY0Plane > 3 * kY1Plane + kFrame16B ? 3 * kY0Plane 
 constexpr int oTail = oB + kRegionB, kTailOut = 24, kLdsBytes = oTail + 2 * 8 * kTailOut * 4;  // (tail: [step parity][8 waves][up to 24 padded outputs])
 // conv0's 13th tile (pixels 384 .. 399) is multiplied in two K halves by the first two B waves: the second half's partial
 // sums cross to wave 0 through this area (one f32x16 per lane), behind the barrier that ends the phase
-constexpr int oExch = kLdsBytes, kExchB = 64 * 64, kLdsBytesX = kLdsBytes + kExchB;
+constexpr int oExch = kLdsBytes, kExchB = 64 * 64, oBias0 = oExch + kExchB, kLdsBytesX = oBias0 + 32 * 4;  // + conv0's bias (read per image)
 static_assert(oB % 16 == 0 && oFrame % 16 == 0 && oTail % 16 == 0 && oExch % 16 == 0 && kLdsBytesX <= 160 * 1024, "LDS layout");
+// conv0's 32 biases live in LDS for the launch: the epilogue of every image reads this lane's 16 of them (four
+// ds_read_b128 behind the phase's barrier; as global loads they were an exposed L2 round trip per image)
+__device__ __forceinline__ void bias0_to_lds(uint8_t *smem, const float *bias0, int tid) {
+  if (tid < 32) *reinterpret_cast<float *>(smem + oBias0 + 4 * tid) = bias0[tid];
+}
+__device__ __forceinline__ void bias0_from_lds(const uint8_t *smem, int lane, f32x4 (&b)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4 *>(smem + oBias0 + 4 * (8 * q + 4 * (lane >> 5)));
+}
 __device__ __forceinline__ void exch_put(uint8_t *smem, int lane, const f32x16 &v) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(smem + oExch + q * 1024 + lane * 16) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (tid + 512 * u < kFrameB / 16) put_frame_unit(smem, tid + 512 * u, fr[u]);
+    bias0_to_lds(smem, a.bias0, tid);
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
       const int i = u * 512 + tid;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
     // alone takes 11,200 and the A waves with two tiles idled for 4,400)
     auto load_bias0 = [&](f32x4 (&bias0)[4], int l) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (l >> 5));
+      for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(smem + oBias0 + 4 * (8 * q + 4 * (l >> 5)));
     };
     lds_barrier();  // p1: frame 0 and conv0's planes are in LDS
     // conv0's 13th tile (pixels 384 .. 399) is shared by waves 0 and 1, eight K chunks each (conv0_half); wave 1's sums
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
     // kept in 16 registers across the conv1 phase
     auto load_bias0 = [&](f32x4 (&bias0)[4], int l) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(a.bias0 + 8 * q + 4 * (l >> 5));
+      for (int q = 0; q < 4; ++q) bias0[q] = *reinterpret_cast<const f32x4 *>(smem + oBias0 + 4 * (8 * q + 4 * (l >> 5)));
     };
     // conv1's tiles 4 and 5 for the channels of this SIMD's B wave (nt = aw), over the whole contraction: its own
     // fragment buffer cycles taps 0-7 -> taps 8-15 -> the next image's taps 0-7
