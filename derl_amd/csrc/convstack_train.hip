@@ -91,6 +91,10 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
   }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
+  // the gather index of the NEXT image is read one image ahead (a scalar load whose round trip sat in front of the frame
+  // loads at the top of every image's conv1 phase)
+  auto frame_row = [&](int img) { return img < a.B ? (a.sample_idx ? a.sample_idx[img] : img) : 0; };
+  int row_next = frame_row(e + grid);
 
   if (roleB) {
     // =================================== B: conv1 + conv2 of image t ===================================
@@ -159,7 +163,8 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
       u32x4 fr[3];  // pieces 16 + nt + 4 u of the next image's frame (the A waves carry pieces 0 .. 15)
       if (more) {
         const int next = e + grid;
-        const uint8_t *src = a.obs + static_cast<long long>(a.sample_idx ? a.sample_idx[next] : next) * kFrameB;
+        const uint8_t *src = a.obs + static_cast<long long>(row_next) * kFrameB;
+        row_next = frame_row(next + grid);  // (for the image after: landed long before its use)
 #pragma unroll
         for (int u = 0; u < 3; ++u) fr[u] = *reinterpret_cast<const u32x4 *>(src + 16 * min((16 + nt + 4 * u) * 64 + opaque(lane), kFrameB / 16 - 1));
       }
@@ -274,7 +279,8 @@ __global__ __launch_bounds__(512) void convstack_train_kernel(const ConvStackArg
                     // travels under the conv1 loops)
       if (more) {
         const int next = e + grid;
-        const uint8_t *src = a.obs + static_cast<long long>(a.sample_idx ? a.sample_idx[next] : next) * kFrameB;
+        const uint8_t *src = a.obs + static_cast<long long>(row_next) * kFrameB;
+        row_next = frame_row(next + grid);  // (for the image after: landed long before its use)
 #pragma unroll
         for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const u32x4 *>(src + 16 * ((aw + 4 * u) * 64 + opaque(lane)));
       }
