@@ -277,7 +277,7 @@ int dx_cnn_backward(const dx_cnn_ctx *ctx, const void *obs, int obs_is_u8,
  * normalised here with {sum, sumsq, n} (derl/runners/trajectory_transforms.py:89-92), written to
  * adv_normalized_out if given.  `counter`: one word, zero before the first call (the launch leaves
  * it zero).  `partials`: >= 8 * ceil(B / 8) doubles covers every route (the factored tail asks for
- * 8 * min(ceil(B / 16), 256), the layer-by-layer heads for 8 * ceil(B / 64); less is DX_EINVAL).  DX_ENOSUP where
+ * 8 * min(ceil(B / 8), 256) where its loss also runs its backward pass -- dx_cnn_tail_fused -- and 8 * min(ceil(B / 16), 256) otherwise, the layer-by-layer heads for 8 * ceil(B / 64); less is DX_EINVAL).  DX_ENOSUP where
  * dx_cnn_fused_heads(ctx) is 0 (more than 18 actions; more than 7 on the layer-by-layer route).
  *
  * Routes (same outputs and gradients, other association / arithmetic; csrc/cnn.hip):
