@@ -7,6 +7,7 @@
 // the NHWC activations.  NOTE (models.py:112,119-124): the reference flattens NCHW, so the
 // 3136-wide linear layer is permuted while packing; there is no ReLU after it.
 #include "igemm.hpp"
+#include "tail_greduce_dev.hpp"
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -485,7 +486,7 @@ static NTArgs nt_args(const Gather &g, const float *Wp, const float *bias, float
 // slabs -> canonical gradients.  `which`: bit 0 = the three conv layers, bit 1 = linear layer +
 // heads (the contiguous tail of the flat gradient buffer: its all-reduce can start while the conv
 // layers' backward still runs)
-static int finalize_grads(const dx_cnn_ctx *c, const Plan &plan, int which, hipStream_t s) {
+static int finalize_grads(const dx_cnn_ctx *c, const Plan &plan, int which, hipStream_t s, const TailGreduceArgs *greduce = nullptr) {
   const int IC0 = c->in_c, A = c->num_actions, flat = c->flat, P = c->h2 * c->w2;
   PermuteJob j[kMaxJobs];
   int n = 0;
@@ -524,6 +525,7 @@ static int finalize_grads(const dx_cnn_ctx *c, const Plan &plan, int which, hipS
     return launch_finalize_fused(j, n, c->slabs + plan.s[L_FC].w_off, plan.s[L_FC].msplit,
                                  static_cast<long long>(kHid) * flat, g + c->off_w[3], kHid, P, kC2, s);
   }
+  if (greduce != nullptr) return launch_permute_reduce_greduce(j, n, *greduce, s);
   return launch_permute_reduce(j, n, s);
 }
 
@@ -871,9 +873,15 @@ static bool bwd_overlap(int B) {
 // heads) is tail.hip's G reduction instead of a slab reduction
 static int finalize_any(const dx_cnn_ctx *c, const Plan &plan, int which, int B, bool factored, hipStream_t s) {
   if (factored && (which & 2)) {
-    if (int rc = launch_tail_grads(c->params, c->grads, c->off_w, c->off_b, c->num_actions,
-                                   c->slabs + plan.s[L_FC].w_off, B, s))
-      return rc;
+    float *scratch = c->slabs + plan.s[L_FC].w_off;
+    if ((which & ~2) != 0 && DX_ENV("DX_FINALIZE_MERGED", 1) != 0) {
+      // the tail's G / s reduction rides in the conv layers' slab reduction (two independent slab readers, one
+      // launch), the gradient products follow.  DX_FINALIZE_MERGED=0: three launches
+      const TailGreduceArgs g = tail_greduce_args(scratch, B, c->num_actions);
+      if (int rc = finalize_grads(c, plan, which & ~2, s, &g)) return rc;
+      return launch_tail_grads(c->params, c->grads, c->off_w, c->off_b, c->num_actions, scratch, B, s, true);
+    }
+    if (int rc = launch_tail_grads(c->params, c->grads, c->off_w, c->off_b, c->num_actions, scratch, B, s)) return rc;
     which &= ~2;
   }
   return which != 0 ? finalize_grads(c, plan, which, s) : DX_OK;

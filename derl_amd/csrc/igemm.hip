@@ -11,6 +11,7 @@
 //   TN: LDS rows are the reduction index m; a lane reads one float per MFMA, consecutive
 //       lanes -> consecutive banks.
 #include "igemm_dev.hpp"
+#include "tail_greduce_dev.hpp"
 #include <cstdlib>
 
 namespace dx {
@@ -556,6 +557,19 @@ __global__ __launch_bounds__(256) void permute_reduce_kernel(const JobTable t) {
   permute_reduce_block(t, blockIdx.x, red);
 }
 
+// the same grid followed by the (49, Jp) blocks of the factored tail's G / s reduction (tail_greduce_dev.hpp)
+__global__ __launch_bounds__(256) void permute_reduce_greduce_kernel(const JobTable t, const TailGreduceArgs g, int chunks) {
+  __shared__ float red[4][64];
+  __shared__ float sred[256];
+  const int b = blockIdx.x;
+  if (b < chunks) {
+    permute_reduce_block(t, b, red);
+    return;
+  }
+  const int q = b - chunks;
+  tail_greduce_block(g, q % kGreduceP, q / kGreduceP, red, sred);
+}
+
 template <int TAG, int BM, int BN, int WM, int WN, bool AU8, int EPI, int BK = 32>
 int launch_nt_as(const NTArgs &a, hipStream_t stream) {
   DX_REQUIRE(a.g.seglen % BK == 0 && (a.K / a.ksplit) % BK == 0,
@@ -885,6 +899,35 @@ int launch_pack_fused(const PermuteJob *jobs, int njobs, const float *W, float *
   DX_LAUNCH_CHECK();
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(P * C, 64), cdiv(N, 64)), dim3(256), 0, stream, fcf, fcd, N,
                      P * C);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+static int fill_job_table(const PermuteJob *jobs, int njobs, JobTable *t, long long *chunks_out) {
+  long long chunks = 0;
+  for (int i = 0; i < njobs; ++i) {
+    DX_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].nslab >= 1 && jobs[i].D1 > 0 && jobs[i].D2 > 0 &&
+                   jobs[i].D3 > 0 && jobs[i].total > 0,
+               "permute_reduce: bad job %d", i);
+    t->jobs[i] = jobs[i];
+    t->chunk_begin[i] = static_cast<int>(chunks);
+    chunks += (jobs[i].total + 63) / 64;
+    DX_REQUIRE(chunks < (1LL << 30), "permute_reduce: too many elements");
+  }
+  t->chunk_begin[njobs] = static_cast<int>(chunks);
+  t->njobs = njobs;
+  *chunks_out = chunks;
+  return DX_OK;
+}
+
+int launch_permute_reduce_greduce(const PermuteJob *jobs, int njobs, const TailGreduceArgs &g, hipStream_t stream) {
+  DX_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "permute_reduce_greduce: %d jobs (max %d)", njobs, kMaxJobs);
+  DX_REQUIRE(g.gslab && g.sslab && g.Gc && g.s && g.nslab >= 1 && g.Jp % 8 == 0 && g.nj >= 1 && g.nj <= g.Jp, "permute_reduce_greduce: bad tail arguments");
+  JobTable t;
+  long long chunks = 0;
+  if (int rc = fill_job_table(jobs, njobs, &t, &chunks)) return rc;
+  hipLaunchKernelGGL(permute_reduce_greduce_kernel, dim3(static_cast<unsigned>(chunks + kGreduceP * g.Jp)), dim3(256), 0, stream, t, g,
+                     static_cast<int>(chunks));
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -294,7 +294,11 @@ int launch_tail_loss_bwd(const float *y2, const float *Wc, const float *beff, co
                          float *loss_out, float *dy2, float *gslab, float *sslab, int Jp, int nwg, int rows_per_wg,
                          hipStream_t stream);
 int launch_tail_grads(const float *params, float *grads, const long long *off_w, const long long *off_b, int A,
-                      float *scratch, int B, hipStream_t stream);
+                      float *scratch, int B, hipStream_t stream, bool reduced = false);
+// the tail's G / s reduction in the same launch as the conv layers' slab reduction (two independent slab readers)
+struct TailGreduceArgs;
+TailGreduceArgs tail_greduce_args(float *scratch, int B, int A);
+int launch_permute_reduce_greduce(const PermuteJob *jobs, int njobs, const TailGreduceArgs &g, hipStream_t stream);
 int launch_tail_act(const float *y2, const float *Wc, const float *beff, int B, int A, const float *uniforms, uint64_t seed,
                     uint64_t counter, int64_t *actions, float *log_prob, float *values, hipStream_t stream);
 int launch_tail_act_synth(const float *y2, const float *Wc, const float *beff, int B, int A, uint64_t seed, uint64_t counter,

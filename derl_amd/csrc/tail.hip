@@ -21,6 +21,7 @@
 //   tail_bwd_kernel  dy2 = relu'(y2) * (dout Wc), G partials, s partials: one pass over y2
 //   tail_greduce / tail_grads  G -> dWfc, dWh, dbfc, dbh straight into the flat gradient buffer
 #include "pack_direct_dev.hpp"
+#include "tail_greduce_dev.hpp"
 
 namespace dx {
 namespace {
@@ -249,42 +250,10 @@ __global__ __launch_bounds__(448) void tail_bwd_wide_kernel(const TailBwdArgs a)
   }
 }
 
-// G[j][k] = sum over the workgroups' partials (fixed order), in y2's column order and in the canonical
-// order of Wfc's columns (k = p * 64 + c  ->  c * 49 + p); block (0, j) also sums s[j]
-__global__ __launch_bounds__(256) void tail_greduce_kernel(const float *gslab, const float *sslab, int nslab, int nj, int Jp, float *Gc, float *s) {
+__global__ __launch_bounds__(256) void tail_greduce_kernel(const TailGreduceArgs a) {
   __shared__ float red[4][64];
   __shared__ float sred[256];
-  const int t = threadIdx.x, c = t & 63, sg = t >> 6;
-  const int p = blockIdx.x, j = blockIdx.y;
-  if (j >= nj) {  // rows beyond the A + 1 outputs read as zero in the heads' dot products (uniform branch)
-    if (t < 64) Gc[j * kK + c * kP + p] = 0.f;
-    if (p == 0 && t == 0) s[j] = 0.f;
-    return;
-  }
-  float v = 0.f;
-  for (int z0 = sg; z0 < nslab; z0 += 64) {  // sixteen loads in flight, added in slab order
-    float x[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int z = z0 + 4 * u;
-      x[u] = z < nslab ? gslab[(static_cast<long long>(z) * Jp + j) * kK + p * 64 + c] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v += x[u];
-  }
-  red[sg][c] = v;
-  if (p == 0) {
-    float sv = 0.f;
-    for (int z = t; z < nslab; z += 256) sv += sslab[z * Jp + j];
-    sred[t] = sv;
-  }
-  __syncthreads();
-  if (t < 64) Gc[j * kK + c * kP + p] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
-  if (p == 0 && t == 0) {
-    float tot = 0.f;
-    for (int i = 0; i < 256; ++i) tot += sred[i];
-    s[j] = tot;
-  }
+  tail_greduce_block(a, blockIdx.x, blockIdx.y, red, sred);
 }
 
 struct TailGradArgs {
@@ -456,16 +425,25 @@ int launch_tail_bwd(const float *y2, const float *dhead, const float *Wc, float 
   }
 }
 
-int launch_tail_grads(const float *params, float *grads, const long long *off_w, const long long *off_b, int A,
-                      float *scratch, int B, hipStream_t stream) {
-  DX_REQUIRE(params && grads && scratch && B >= 1 && A >= 1 && A + 1 <= kMaxOutputs, "tail_grads: bad arguments");
+// where the reduction reads and writes inside `scratch` (launch_tail_bwd's layout)
+TailGreduceArgs tail_greduce_args(float *scratch, int B, int A) {
   const int nwg = tail_bwd_workgroups(B), Jp = tail_rows(A);
-  const float *gslab = scratch, *sslab = scratch + static_cast<long long>(nwg) * Jp * kK;
   float *Gc = scratch + (static_cast<long long>(nwg) + 1) * Jp * kK;
-  float *s = Gc + Jp * kK;
-  hipLaunchKernelGGL(tail_greduce_kernel, dim3(kP, Jp), dim3(256), 0, stream, gslab, sslab, nwg, A + 1, Jp, Gc, s);
-  DX_LAUNCH_CHECK();
-  const TailGradArgs a{tail_weights(params, off_w, off_b, A), Gc, s, grads + off_w[3], grads + off_b[3], grads + off_w[4],
+  return TailGreduceArgs{scratch, scratch + static_cast<long long>(nwg) * Jp * kK, nwg, A + 1, Jp, Gc, Gc + Jp * kK};
+}
+
+// `reduced`: the G / s reduction has run already (igemm.hip: launch_permute_reduce_greduce, beside the conv layers'
+// slab reduction); otherwise it is this call's first launch
+int launch_tail_grads(const float *params, float *grads, const long long *off_w, const long long *off_b, int A,
+                      float *scratch, int B, hipStream_t stream, bool reduced) {
+  DX_REQUIRE(params && grads && scratch && B >= 1 && A >= 1 && A + 1 <= kMaxOutputs, "tail_grads: bad arguments");
+  const TailGreduceArgs r = tail_greduce_args(scratch, B, A);
+  const int Jp = r.Jp;
+  if (!reduced) {
+    hipLaunchKernelGGL(tail_greduce_kernel, dim3(kP, Jp), dim3(256), 0, stream, r);
+    DX_LAUNCH_CHECK();
+  }
+  const TailGradArgs a{tail_weights(params, off_w, off_b, A), r.Gc, r.s, grads + off_w[3], grads + off_b[3], grads + off_w[4],
                        grads + off_b[4], grads + off_w[5], grads + off_b[5], A + 1};
   const dim3 ggrid(kGradBlocksW + kNH + 1);
   if (Jp == 8) hipLaunchKernelGGL(tail_grads_kernel<8>, ggrid, dim3(256), 0, stream, a);

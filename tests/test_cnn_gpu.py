@@ -681,6 +681,7 @@ SWITCH_SETTINGS = ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_TN_SWIZZLE=0", "DX_LA
                    "DX_WGRAD_DIRECT_MIN_B=1", "DX_NT_DMA=0", "DX_NTP=0",
                    "DX_FC_FACTORED=0",                           # linear layer + heads layer by layer in updates and rollouts
                    "DX_TAIL_FUSED=0",                            # the factored tail's loss and its backward pass as two launches
+                   "DX_FINALIZE_MERGED=0",                       # the tail's G reduction as its own launch, not beside the conv slabs'
                    "DX_CONVSTACK=0", "DX_CONVSTACK=0 DX_FC_FACTORED=0 DX_FC_ROLLOUT=0",  # the rollout's layer-by-layer kernels
                    "DX_CONVSTACK_TRAIN=0 DX_WGRAD_B6=0 DX_DGRAD_B6=0",  # the update's fp32-MFMA conv stages
                    "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
