@@ -1,7 +1,7 @@
 """Headline benchmark: env-steps/sec of PPO on BreakoutNoFrameskip-v4-shaped synthetic frames,
 nenvs=256, nsteps=128 (BASELINE.json configs[1]) on N MI355X GPUs of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W       (N > 1: starts its own ranks, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full PPO iteration: a 128-step rollout of the batched policy over the
@@ -234,6 +234,41 @@ def time_gae(T, N, iters=20):
               unit="GB/s", frac=round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4))
 
 
+def self_launch(args, argv):
+  """`python bench.py --gpus N` started PLAINLY (no RANK / WORLD_SIZE in the environment): this process has not
+  touched the GPU and never will -- it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+  bench.py <same arguments>` as a fresh child (one rank per GPU over RCCL), forwards rank 0's ONE JSON line on
+  stdout (anything else the ranks print goes to stderr) and exits with the child's return code.  With
+  --allow-gloo on a box with fewer GPUs than ranks the ranks share GPU 0 and reduce over gloo (a rehearsal: the
+  line says so)."""
+  import socket
+  import subprocess
+  with socket.socket() as sock:  # a free rendezvous port
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only kind this host driver has
+  env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+  if args.allow_gloo and torch.cuda.device_count() < args.gpus:  # device_count() does not initialise HIP
+    env.setdefault("DERL_AMD_DIST_BACKEND", "gloo")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+  child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+  lines = 0
+  for line in child.stdout:
+    is_result = line.startswith("{") and '"metric"' in line
+    lines += is_result
+    (sys.stdout if is_result else sys.stderr).write(line)
+    (sys.stdout if is_result else sys.stderr).flush()
+  code = child.wait()
+  if code == 0 and lines != 1:
+    print(f"bench.py: the {args.gpus} ranks exited 0 but printed {lines} result lines", file=sys.stderr)
+    code = 1
+  if code:
+    print(f"bench.py: `{' '.join(cmd)}` failed with exit code {code} (the ranks' stderr is above)", file=sys.stderr)
+  raise SystemExit(code)
+
+
 def main():
   parser = argparse.ArgumentParser()
   parser.add_argument("--gpus", type=int, default=1)
@@ -255,6 +290,8 @@ def main():
                       help="rehearsal only: accept a non-RCCL backend for WORLD_SIZE > 1 (the JSON "
                            "line then says so and is not a scaling measurement)")
   args = parser.parse_args()
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+    self_launch(args, sys.argv[1:])  # never returns
 
   import derl_amd as derl
   from derl_amd import distributed
@@ -353,7 +390,10 @@ def main():
                  "ranks_seen": ranks_seen, "backend": backend,
                  "collectives": ("RCCL communicator owned by the native library (dx_comm_init / "
                                  "dx_allreduce_grads inside dx_cnn_ppo_epoch)" if distributed.native_comm()
-                                 else "none" if world == 1 else "torch.distributed (rehearsal)"),
+                                 else "none" if world == 1
+                                 else "torch.distributed's RCCL collectives from Python, update by update (FALLBACK: the "
+                                      "library's own communicator did not come up on every rank)" if backend == "nccl"
+                                 else f"torch.distributed on {backend} (rehearsal, not a scaling measurement)"),
                  "allreduce_bytes_per_update": allreduce_bytes,
                  "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 3),
                  "host_enqueue_ms_unblocked": round(host_unblocked_s * 1e3, 3),

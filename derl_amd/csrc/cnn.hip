@@ -157,6 +157,7 @@ enum Layer { L_C0 = 0, L_C1, L_C2, L_FC, L_HD, L_COUNT };
 struct Plan {
   SlabPlan s[L_COUNT];
   long long total;
+  long long fc_cap_floats;  // floats of the linear layer's weight-slab region (the factored tail's G / Gc / s live there)
 };
 
 }  // namespace
@@ -197,8 +198,22 @@ static bool layer_direct_supported(const dx_cnn_ctx *c, int layer) {
   return false;
 }
 
+// Where the factored tail keeps its partial G / s, Gc and s: the head of the linear layer's slab region.  The launchers
+// trust this pointer for tail_slab_floats(B) floats, so the plan of THIS batch is checked against the reserved region
+// here (nullptr with the error text set otherwise).
+static float *tail_scratch(const dx_cnn_ctx *c, const Plan &plan, int B) {
+  const long long need = tail_slab_floats(B, c->num_actions);
+  if (need > plan.fc_cap_floats) {
+    fail(DX_EINVAL, "factored tail: batch %d with %d actions needs %lld floats of slab scratch, %lld are reserved "
+                    "(max_batch %d)", B, c->num_actions, need, plan.fc_cap_floats, c->max_batch);
+    return nullptr;
+  }
+  return c->slabs + plan.s[L_FC].w_off;
+}
+
 static Plan make_plan(const dx_cnn_ctx *c, long long B) {
   Plan p;
+  p.fc_cap_floats = 0;
   long long off = 0;
   for (int l = 0; l < L_COUNT; ++l) {
     int N, K, bkn;
@@ -211,7 +226,8 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
     p.s[l].bsplit = 0;  // 0 = msplit (set below)
     long long b_cap = 0;  // bias partials beyond the weight slabs' count
     if (l == L_FC && tail_supported(c->flat, c->num_actions)) {  // the factored tail's partial G slabs live here
-      const long long need = (tail_slab_floats(c->max_batch, c->num_actions) + static_cast<long long>(N) * K - 1) / (static_cast<long long>(N) * K);
+      // (tail_bwd_workgroups(B) is NOT monotone in B: the capacity is the bound over every B <= max_batch)
+      const long long need = (tail_slab_capacity_floats(c->max_batch, c->num_actions) + static_cast<long long>(N) * K - 1) / (static_cast<long long>(N) * K);
       if (ms_cap < need) ms_cap = need;
     }
     if (l == L_FC && wgrad_direct_on()) {  // capacity for the dedicated kernel's slices / bias chunks
@@ -242,6 +258,7 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
     }
     if (p.s[l].bsplit == 0) p.s[l].bsplit = p.s[l].msplit;
     p.s[l].w_off = off;
+    if (l == L_FC) p.fc_cap_floats = ms_cap * N * K;
     off += ms_cap * N * K;
     p.s[l].b_off = off;
     off += (b_cap > ms_cap ? b_cap : ms_cap) * N;
@@ -826,7 +843,9 @@ int dx_cnn_heads_loss_f32(const dx_cnn_ctx *c, const int64_t *actions, const flo
     g_route[ST_FC_FWD] = g_route[ST_HEADS_FWD] = g_route[ST_HEADS_WGRAD] = g_route[ST_HEADS_DGRAD] = "tail_factored";
     if (tail_fused(c)) {  // ... and dy2 + the partial G / s from the same pass over y2: backward_stages skips tail_bwd
       const Plan plan = make_plan(c, B);
-      const TailBwdPlan tb = tail_bwd_plan(c->slabs + plan.s[L_FC].w_off, B, c->num_actions);
+      float *scratch = tail_scratch(c, plan, B);
+      if (scratch == nullptr) return DX_EINVAL;
+      const TailBwdPlan tb = tail_bwd_plan(scratch, B, c->num_actions);
       return launch_tail_loss_bwd(c->y2, c->packed + c->pk_wc, c->packed + c->pk_beff, actions, old_log_prob, advantages,
                                   old_values, value_targets, norm_stats, norm_eps, adv_normalized_out, c->head, c->dhead, B,
                                   c->num_actions, mode, cliprange, value_loss_coef, entropy_coef, global_batch, partials,
@@ -873,7 +892,8 @@ static bool bwd_overlap(int B) {
 // heads) is tail.hip's G reduction instead of a slab reduction
 static int finalize_any(const dx_cnn_ctx *c, const Plan &plan, int which, int B, bool factored, hipStream_t s) {
   if (factored && (which & 2)) {
-    float *scratch = c->slabs + plan.s[L_FC].w_off;
+    float *scratch = tail_scratch(c, plan, B);
+    if (scratch == nullptr) return DX_EINVAL;
     if ((which & ~2) != 0 && DX_ENV("DX_FINALIZE_MERGED", 1) != 0) {
       // the tail's G / s reduction rides in the conv layers' slab reduction (two independent slab readers, one
       // launch), the gradient products follow.  DX_FINALIZE_MERGED=0: three launches
@@ -900,8 +920,9 @@ static int backward_stages(const dx_cnn_ctx *c, int first, int last, const void 
       if (st == ST_FC_WGRAD) {
         g_route[ST_FC_WGRAD] = g_route[ST_FC_DGRAD] = "tail_factored";
         if (tail_fused(c)) continue;  // dx_cnn_heads_loss_f32 has formed dy2 and the partial G / s already
-        rc = launch_tail_bwd(c->y2, c->dhead, c->packed + c->pk_wc, c->dy2, c->slabs + plan.s[L_FC].w_off, B,
-                             c->num_actions, s);
+        float *scratch = tail_scratch(c, plan, B);
+        rc = scratch == nullptr ? DX_EINVAL
+                                : launch_tail_bwd(c->y2, c->dhead, c->packed + c->pk_wc, c->dy2, scratch, B, c->num_actions, s);
       }
       continue;
     }

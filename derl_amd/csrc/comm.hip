@@ -197,8 +197,12 @@ int dx_comm_available(void) {
   std::lock_guard<std::mutex> guard(g_lock);
   DX_REQUIRE(g_comm.comm == nullptr, "dx_comm_available: a communicator already exists (dx_comm_destroy first)");
   if (int rc = load_rccl()) return rc;
-  int dev = -1;
+  // the device answers: its context comes up (hipFree(nullptr) creates it) and it reports its compute units
+  int dev = -1, cus = 0;
   DX_HIP(hipGetDevice(&dev));
+  DX_HIP(hipFree(nullptr));
+  DX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  DX_REQUIRE(cus > 0, "dx_comm_available: device %d reports %d compute units", dev, cus);
   return DX_OK;
 }
 

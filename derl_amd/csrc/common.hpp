@@ -1,6 +1,7 @@
 // Shared host-side helpers for the C-ABI translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -62,15 +63,16 @@ struct TraceRange {
 // Environment switches (diagnostic switches): read through ONE cache.  A switch is parsed the first time a
 // call needs it and again after dx_reload_env() (include/derl_amd.h) -- the values are process-wide on purpose (one
 // process per GPU), but nothing else about them is static: a host or a test that changes a switch says so.
-struct EnvSlot { int generation = -1, value = 0; bool set = false; };
+// (two host threads may meet in one slot: the value is published before the generation that vouches for it)
+struct EnvSlot { std::atomic<int> generation{-1}, value{0}; std::atomic<bool> set{false}; };
 int env_generation();
 void env_read(EnvSlot &slot, const char *name, int dflt);  // getenv + atoi
 inline const EnvSlot &env_cached(EnvSlot &slot, const char *name, int dflt) {
-  if (slot.generation != env_generation()) env_read(slot, name, dflt);
+  if (slot.generation.load(std::memory_order_acquire) != env_generation()) env_read(slot, name, dflt);
   return slot;
 }
-#define DX_ENV(name, dflt) ([]() -> int { static ::dx::EnvSlot slot_; return ::dx::env_cached(slot_, name, dflt).value; }())
-#define DX_ENV_SET(name) ([]() -> bool { static ::dx::EnvSlot slot_; return ::dx::env_cached(slot_, name, 0).set; }())
+#define DX_ENV(name, dflt) ([]() -> int { static ::dx::EnvSlot slot_; return ::dx::env_cached(slot_, name, dflt).value.load(std::memory_order_relaxed); }())
+#define DX_ENV_SET(name) ([]() -> bool { static ::dx::EnvSlot slot_; return ::dx::env_cached(slot_, name, 0).set.load(std::memory_order_relaxed); }())
 
 // Per-device one-time set-up of a call site (the dynamic-LDS opt-in belongs to a DEVICE's code object: a process that
 // drives two devices must make it on each), and the CU count of the current device (devices may differ).

@@ -64,10 +64,11 @@ int device_cus(int *cus_out) {
 }
 int env_generation() { return g_env_generation.load(std::memory_order_relaxed); }
 void env_read(EnvSlot &slot, const char *name, int dflt) {
+  const int generation = env_generation();  // (read BEFORE the variable: a reload in between is seen at the next use)
   const char *e = getenv(name);
-  slot.set = e != nullptr;
-  slot.value = e ? atoi(e) : dflt;
-  slot.generation = env_generation();
+  slot.set.store(e != nullptr, std::memory_order_relaxed);
+  slot.value.store(e ? atoi(e) : dflt, std::memory_order_relaxed);
+  slot.generation.store(generation, std::memory_order_release);
 }
 void count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 

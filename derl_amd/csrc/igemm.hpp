@@ -270,6 +270,7 @@ bool tail_supported(int flat, int num_actions);  // 84 x 84 frames' conv output 
 int tail_rows(int num_actions);                   // the A + 1 outputs padded to groups of eight (8, 16 or 24 rows)
 long long tail_pack_scratch_floats(int num_actions);
 long long tail_slab_floats(int B, int num_actions);
+long long tail_slab_capacity_floats(int max_batch, int num_actions);  // >= tail_slab_floats of every B <= max_batch
 // (`direct`, optional: the conv layers' bf16 planes of pack_direct_dev.hpp written by extra workgroups of the same launch)
 struct TailDirectPlanes { uint16_t *p0, *f1, *f2, *d1, *d2; };
 int launch_tail_pack(const float *params, const long long *off_w, const long long *off_b, int A, float *Wc, float *beff,

@@ -970,7 +970,7 @@ int launch_mlp_persist_epoch(const dx_mlp_ctx *c, const dx_mlp_epoch *e, int G, 
   a.sumsqp = a.lossp + static_cast<long long>(G) * 40;
   a.wtab = reinterpret_cast<unsigned *>(a.sumsqp + G + 8);  // (64 bytes behind the partials)
   a.G = G;
-  static const bool want_stamps = getenv("DX_MLP_PERSIST_STAMPS") && atoi(getenv("DX_MLP_PERSIST_STAMPS")) != 0;
+  const bool want_stamps = DX_ENV("DX_MLP_PERSIST_STAMPS", 0) != 0;
   unsigned long long *stamps_dev = nullptr;
   if (want_stamps) {
     DX_HIP(hipMalloc(&stamps_dev, sizeof(unsigned long long) * kStampSlots * G));

@@ -159,7 +159,7 @@ int launch_as(const NtDmaArgs &a, hipStream_t stream) {
   DX_LDS_OPT_IN((nt_dma_kernel<EPI, STAGES>), lds);
   const int grid = (a.M / kBM) * cdiv(a.N, kBN);
 #if DX_DIAG
-  static const int diag = getenv("DX_NT_DIAG") ? atoi(getenv("DX_NT_DIAG")) : 0;
+  const int diag = DX_ENV("DX_NT_DIAG", 0);
 #else
   constexpr int diag = 0;
 #endif

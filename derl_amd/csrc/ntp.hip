@@ -500,9 +500,7 @@ bool ntp_small_on() {  // DX_NTP_SMALL=0: rollout-sized forward stages on the la
 int ntp_workgroups(int per_cu) {  // every CU full (diag build: DX_NTP_NWG forces a count)
   int v = 0;
 #if DX_DIAG
-  static int forced = -1;
-  if (forced < 0) { const char *e = getenv("DX_NTP_NWG"); forced = e ? atoi(e) : 0; }
-  v = forced;
+  v = DX_ENV("DX_NTP_NWG", 0);
 #endif
   const int n = v > 0 ? v : 256 * per_cu;
   return n < 8 ? 8 : n / 8 * 8;
@@ -513,7 +511,7 @@ int launch_as(const NtpArgs &p, hipStream_t stream) {
   DX_LDS_OPT_IN((ntp_kernel<TAG, MODE, EPI, S::BM, S::BN, S::TM, S::TN, S::RING, S::NLOAD, S::WGS>), S::LDS_BYTES);
   const int grid = ntp_workgroups(S::WGS);
 #if DX_DIAG
-  static const int diag = getenv("DX_NTP_DIAG") ? atoi(getenv("DX_NTP_DIAG")) : 0;
+  const int diag = DX_ENV("DX_NTP_DIAG", 0);
 #else
   constexpr int diag = 0;
 #endif

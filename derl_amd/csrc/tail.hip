@@ -70,11 +70,11 @@ __global__ __launch_bounds__(kPackThreads) void tail_pack_kernel(const TailWeigh
   const int j0 = 8 * blockIdx.y;
   if (blockIdx.x == kPackBlocks) {  // beff[j] = Wh[j] . bfc + bh[j]: 256 threads, the two-launch version's order
     __shared__ float bred[4][kJ];
-    if (t >= 256) return;
+    const bool worker = t < 256;  // (all 1,024 threads stay for the barrier; the first 256 do the work)
     float part[kJ];
 #pragma unroll
     for (int j = 0; j < kJ; ++j) part[j] = 0.f;
-    for (int n = t; n < kNH; n += 256) {
+    for (int n = t; worker && n < kNH; n += 256) {
       const float b = w.bfc[n];
 #pragma unroll
       for (int j = 0; j < kJ; ++j) part[j] = fmaf(head_weight(w, j0 + j, n), b, part[j]);
@@ -83,9 +83,9 @@ __global__ __launch_bounds__(kPackThreads) void tail_pack_kernel(const TailWeigh
     for (int j = 0; j < kJ; ++j) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) part[j] += __shfl_xor(part[j], o);
-      if ((t & 63) == 0) bred[t >> 6][j] = part[j];
+      if (worker && (t & 63) == 0) bred[t >> 6][j] = part[j];
     }
-    __syncthreads();  // (every thread below 256 is here: the others left before the first barrier)
+    __syncthreads();
     if (t < kJ) {
       const int j = j0 + t;
       const float bh = j < w.A ? w.bp[j] : (j == w.A ? w.bv[0] : 0.f);
@@ -369,6 +369,12 @@ int tail_bwd_workgroups(int B) {
 long long tail_slab_floats(int B, int num_actions) {
   return (static_cast<long long>(tail_bwd_workgroups(B)) + 2) * tail_rows(num_actions) * kK + 64;
 }
+// >= tail_slab_floats(B) of EVERY B <= max_batch: tail_bwd_workgroups is not monotone (2100 rows -> 234 workgroups of
+// 9, 2048 rows -> 256 of 8), its bound min(ceil(max_batch / 8), 256) is
+long long tail_slab_capacity_floats(int max_batch, int num_actions) {
+  const int nwg = cdiv(max_batch, 8) < 256 ? cdiv(max_batch, 8) : 256;
+  return (static_cast<long long>(nwg) + 2) * tail_rows(num_actions) * kK + 64;
+}
 
 // Wc [Jp][3136] (y2's column order), beff [Jp] from the canonical parameters; scratch: tail_pack_scratch_floats(A)
 int launch_tail_pack(const float *params, const long long *off_w, const long long *off_b, int A, float *Wc, float *beff,
@@ -380,6 +386,8 @@ int launch_tail_pack(const float *params, const long long *off_w, const long lon
   int extra = 0;
   if (direct) {  // the conv layers' bf16 planes ride in extra workgroups of the same launch
     DX_REQUIRE(direct->p0 && direct->f1 && direct->f2 && direct->d1 && direct->d2, "tail_pack: direct planes missing");
+    DX_REQUIRE(aligned(direct->p0, 16) && aligned(direct->f1, 16) && aligned(direct->f2, 16) && aligned(direct->d1, 16) &&
+                   aligned(direct->d2, 16), "tail_pack: a direct plane is not 16-byte aligned (written with 16-byte stores)");
     d = PackDirectArgs{params + off_w[0], params + off_w[1], params + off_w[2], direct->p0, direct->f1, direct->f2, direct->d1, direct->d2};
     extra = cdiv(kPackDirectPieces, kPackThreads);
   }

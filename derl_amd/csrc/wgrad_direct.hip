@@ -279,8 +279,7 @@ bool wgrad_direct_supported(int IH, int IW, int IC, int OH, int OW, int OC, int 
 // CU (four images each at 1,024): the same kernel time and half the slabs for the finalize pass.
 int wgrad_direct_workgroups(int stage, long long batch) {
 #if DX_DIAG
-  static int forced = -1;  // DX_WD_NWG: timing experiments
-  if (forced < 0) { const char *e = getenv("DX_WD_NWG"); forced = e ? atoi(e) : 0; }
+  const int forced = DX_ENV("DX_WD_NWG", 0);  // timing experiments
   if (forced > 0 && stage == ST_CONV2_WGRAD) return forced;
 #endif
   return stage == ST_CONV1_WGRAD || batch < 2048 ? 256 : 512;
@@ -289,9 +288,7 @@ int wgrad_direct_workgroups(int stage, long long batch) {
 int launch_wgrad_direct(const WgradDirectArgs &a_in, int stage, int nwg, hipStream_t stream) {
   WgradDirectArgs a = a_in;
 #if DX_DIAG
-  static int diag = -1;
-  if (diag < 0) { const char *e = getenv("DX_WD_DIAG"); diag = e ? atoi(e) : 0; }
-  a.diag = diag;
+  a.diag = DX_ENV("DX_WD_DIAG", 0);
 #else
   a.diag = 0;
 #endif

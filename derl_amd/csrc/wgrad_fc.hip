@@ -192,9 +192,7 @@ int launch_fc_wgrad(const FcWgradArgs &a_in, hipStream_t stream) {
   DX_REQUIRE(aligned(a.G, 16) && aligned(a.A, 16) && aligned(a.slab, 8), "fc_wgrad: misaligned pointer");
   a.gk = cdiv(a.K, kBK);
 #if DX_DIAG
-  static int diag = -1;
-  if (diag < 0) { const char *e = getenv("DX_FC_DIAG"); diag = e ? atoi(e) : 0; }
-  a.diag = diag;
+  a.diag = DX_ENV("DX_FC_DIAG", 0);
 #else
   a.diag = 0;
 #endif

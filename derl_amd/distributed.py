@@ -111,11 +111,16 @@ def init_native_comm():
   problem = None
   try:
     _lib.call("dx_comm_available")
-  except _lib.NativeError as error:
+  except Exception as error:  # pylint: disable=broad-except
+    # NativeError (the library said no), but also whatever _lib.load() itself can raise on ONE rank -- OSError from
+    # ctypes.CDLL, AttributeError for a stale .so without this symbol: the rank still takes part in the agreement
+    # below (its peers would block in it otherwise) and every rank falls back together
     problem = error
   ready = torch.tensor([0 if problem else 1], dtype=torch.int32, device=device)
   dist.all_reduce(ready, op=dist.ReduceOp.MIN)
   if int(ready.item()) == 0:
+    if problem is not None and not isinstance(problem, _lib.NativeError):
+      raise _lib.NativeError(f"the native library cannot be used on this rank: {type(problem).__name__}: {problem}")
     raise _lib.NativeError(str(problem) if problem is not None else
                            "another rank cannot join an RCCL communicator (dx_comm_available failed there)")
   ident = (ctypes.c_ubyte * 128)()

@@ -44,8 +44,11 @@ extern "C" {
 
 int dx_abi_version(void);
 /* The DX_* environment switches ("Diagnostic switches") are parsed when a call first needs them and cached.
- * dx_reload_env drops the cache: every switch is read again at its next use (a host that changes a switch at run time;
- * the test suite, which walks the switch settings in one process). */
+ * dx_reload_env drops the cache: every integer switch is read again at its next use (a host that changes a switch at
+ * run time; the test suite, which walks the switch settings in one process).  NOT reloadable, read once per process:
+ * DX_ROCTX (whether roctx ranges are emitted), DERL_AMD_RCCL_LIBRARY (which RCCL is dlopen'ed) and the diag flavour's
+ * DX_COMM_TEST_HOOK ("delay_us:factor", a string); DX_CS_DIAG / DX_CS_STEP / DX_CS_VARIANT / DX_C0_DIAG /
+ * DX_MLP_PERSIST_SPIN_LIMIT bypass the cache altogether (plain getenv at every call: always current). */
 int dx_reload_env(void);
 const char *dx_last_error(void);
 /* Kernels this library has launched in this process so far (every entry point counts its own

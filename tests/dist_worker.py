@@ -77,12 +77,14 @@ def bootstrap_agreement():
   real_call = _lib.call
   log = []
 
-  def scripted(fail_id_on=None, fail_init_on=None, unavailable_on=None):
+  def scripted(fail_id_on=None, fail_init_on=None, unavailable_on=None, stale_library_on=None):
     def call(name, *args):
       log.append(name)
       if name == "dx_comm_available":
         if rank == unavailable_on:
           raise _lib.NativeError("scripted: RCCL cannot be loaded")
+        if rank == stale_library_on:  # what _lib.load() raises for a .so from before the symbol existed
+          raise AttributeError("scripted: undefined symbol: dx_comm_available")
         return 0
       if name == "dx_comm_unique_id":
         if rank == fail_id_on:
@@ -139,6 +141,13 @@ def bootstrap_agreement():
     outcome, native, calls = attempt(unavailable_on=who)
     assert outcome.startswith("fallback") and not native, (rank, outcome)
     assert calls == ["dx_comm_available"], calls
+  # the library itself unusable on one rank (a stale .so: AttributeError, not NativeError): that rank still takes
+  # part in the agreement and both fall back
+  for who in (0, 1):
+    outcome, native, calls = attempt(stale_library_on=who)
+    assert outcome.startswith("fallback") and not native, (rank, outcome)
+    assert calls == ["dx_comm_available"], calls
+    assert ("AttributeError" in outcome) == (rank == who), (rank, outcome)
   # nothing fails: both ranks have the communicator
   outcome, native, calls = attempt()
   assert outcome == "native" and native, (rank, outcome)

@@ -10,8 +10,8 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-SUBSET = ("test_forward_matches_reference_golden or test_loss_and_gradients_match_reference_golden or "
-          "(test_backward_ragged_batches_with_gather and (130 or 1024)) or test_fused_rollout_act_matches_unfused_path")
+SUBSET = ("(test_forward_matches_reference_golden or test_loss_and_gradients_match_reference_golden or "
+          "(test_backward_ragged_batches_with_gather and (130 or 1024)) or (test_fused_rollout_act_matches_unfused_path and not width))")
 
 
 def main(settings):

@@ -195,7 +195,10 @@ def test_backward_ragged_batches_with_gather(batch, route):
   check_backward_against_float64(batch, route, 6)
 
 
-@pytest.mark.parametrize("A,batch", [(8, 37), (9, 130), (12, 1024), (18, 300), (18, 2048)])
+# EVERY output width 2 .. 19 the factored tail instantiates a kernel for (tail_bwd_kernel<2..8>, tail_bwd_wide_kernel<9..19>,
+# tail_loss_bwd_kernel<2..8>, tail_grads_kernel<8|16|24>: each its own register allocation and row padding) at one small
+# and one >= 1,024 ragged batch: real Atari ids land on 3 (Freeway, Skiing), 10, 14 and 16 actions too
+@pytest.mark.parametrize("A,batch", [(A, 21) for A in range(1, 19)] + [(A, 1030) for A in range(1, 19)] + [(18, 2048)])
 def test_wide_action_sets_stay_on_the_factored_tail(A, batch):
   """derl builds heads of any width (derl/models.py:186-203) for any Atari id (derl/env/make_env.py:94-106: the full
   action set has 18 actions).  Up to 18 actions the linear layer + heads stay ONE affine map of y2 (csrc/tail.hip: the
@@ -222,7 +225,14 @@ def test_wide_action_sets_stay_on_the_factored_tail(A, batch):
 _FLOAT64_ORACLE = {}  # (batch, actions, digest of the engine's ReLU masks) -> the float64 oracle's verdicts and gradients
 
 
-def check_backward_against_float64(batch, route, A):
+def test_tail_scratch_is_sized_for_every_batch_up_to_max_batch():
+  """The factored tail's workgroup count is not monotone in the batch (2,100 rows -> 234 workgroups of 9 rows, 2,048 rows
+  -> 256 of 8), so an engine reserved for 2,100 samples must hold the LARGER plan of a 2,048-sample update: with 18 actions
+  (24 padded rows) the old max_batch-only sizing ran 150 K floats past the linear layer's slab region."""
+  check_backward_against_float64(2048, "update", 18, max_batch=2100)
+
+
+def check_backward_against_float64(batch, route, A, max_batch=None):
   rs = np.random.RandomState(batch)
   weights = gi.nature_cnn_weights(A, 31)
   pool = gi.frames(batch + 7, 1000 + batch)
@@ -232,7 +242,7 @@ def check_backward_against_float64(batch, route, A):
               advantages=rs.standard_normal(batch).astype(np.float32),
               values=rs.standard_normal((batch, 1)).astype(np.float32) * 0.2,
               value_targets=rs.standard_normal((batch, 1)).astype(np.float32))
-  eng = make_engine(A, weights, max_batch=max(256, batch))
+  eng = make_engine(A, weights, max_batch=max_batch or max(256, batch))
   loss, grads = run_loss_and_backward(eng, data, 0, 0.1, 0.25, 0.01, A,
                                       torch.from_numpy(idx).to(DEV), route=route)
   odata = dict(data, observations=pool[idx])
@@ -281,7 +291,7 @@ def test_backward_with_float_observations(batch, route):
               advantages=rs.standard_normal(batch).astype(np.float32),
               values=rs.standard_normal((batch, 1)).astype(np.float32) * 0.2,
               value_targets=rs.standard_normal((batch, 1)).astype(np.float32))
-  eng = make_engine(A, weights, max_batch=max(256, batch))
+  eng = make_engine(A, weights, max_batch=max_batch or max(256, batch))
   loss, grads = run_loss_and_backward(eng, data, 0, 0.1, 0.25, 0.01, A, torch.from_numpy(idx).to(DEV), route=route)
   lib = _lib.load()
   assert lib.dx_cnn_last_route(1).decode() != "convstack_train"        # conv1 forward: an fp32 stage
@@ -388,7 +398,8 @@ def count_ambiguous_relu_units(weights, obs, rel=3e-6):
   return count
 
 
-@pytest.mark.parametrize("batch,A", [(1, 4), (7, 6), (128, 4), (256, 4), (300, 18), (1500, 6)])
+@pytest.mark.parametrize("batch,A", [(1, 4), (7, 6), (128, 4), (256, 4), (300, 18), (1500, 6)]
+                         + [pytest.param(40 + A, A, id=f"width{A}") for A in range(1, 20) if A not in (4, 6, 18)])  # every sample_step / output-group width; 19: the fallback
 def test_fused_rollout_act_matches_unfused_path(batch, A):
   """dx_cnn_act (split-K linear layer + fused heads/sampling launch) against the plain
   forward + dx_categorical_act_f32 path and the oracle, with supplied uniforms."""

@@ -111,5 +111,44 @@ def test_bench_two_ranks_reports_ranks_seen_and_refuses_non_rccl_backend():
   reduce = cfg["allreduce_bytes_per_update"]
   assert reduce["issued"] and reduce["gradient_total"] == 4 * 1_686_693 == sum(reduce["pieces"])
   mismatch = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
-                            env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+                            env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=ROOT, capture_output=True, text=True,
+                            timeout=600)
   assert mismatch.returncode != 0 and "WORLD_SIZE" in mismatch.stderr
+
+
+def _plain_env():
+  """The driver's environment: nothing of torch.distributed.run's contract set."""
+  env = dict(os.environ, OMP_NUM_THREADS="2")
+  for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DERL_AMD_DIST_BACKEND",
+              "TORCHELASTIC_RUN_ID", "GROUP_RANK", "LOCAL_WORLD_SIZE"):
+    env.pop(key, None)
+  return env
+
+
+@pytest.mark.gpu
+def test_bench_started_plainly_with_gpus_2_spawns_its_own_ranks():
+  """What the driver types: `python bench.py --gpus 2 ...` with no WORLD_SIZE.  bench.py starts its two ranks itself
+  (torch.distributed.run as a fresh child, before anything touches the GPU) and forwards rank 0's one line; on this
+  one-GPU box the ranks share the GPU and reduce over gloo (--allow-gloo), which the line says."""
+  import json
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--allow-gloo", "--steps", "1",
+                        "--warmup", "1", "--nenvs", "16", "--nsteps", "8", "--no-roofline", "--no-cpu-baseline"],
+                       env=_plain_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+  lines = out.stdout.splitlines()
+  assert len(lines) == 1, out.stdout[-2000:]  # ONE JSON line on stdout, everything else on stderr
+  d = json.loads(lines[0])
+  assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["backend"] == "gloo"
+  assert "rehearsal" in d["config"]["collectives"]
+
+
+def test_bench_started_plainly_forwards_its_ranks_failure():
+  """The same plain command where the ranks cannot run (no GPU in the CPU suite's container; on a GPU box an
+  impossible shard: 3 envs over 2 ranks): the launcher exits non-zero with the ranks' own error on stderr and
+  prints no result line."""
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--allow-gloo", "--steps", "1",
+                        "--warmup", "0", "--nenvs", "3", "--nsteps", "8", "--no-roofline", "--no-cpu-baseline"],
+                       env=_plain_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert out.returncode != 0
+  assert out.stdout.strip() == "", out.stdout[-2000:]
+  assert "torch.distributed.run" in out.stderr and "failed with exit code" in out.stderr

@@ -312,6 +312,66 @@ def test_mirrors_after_an_epoch_that_another_epoch_follows():
   assert torch.equal(alg.model.engine.params, other.model.engine.params)
 
 
+@pytest.mark.parametrize("switches", ["", "DX_FC_FACTORED=0", "DX_PACK_DIRECT=0"])
+def test_back_to_back_epochs_train_on_from_the_light_mirrors(switches):
+  """Two native epochs of one rollout with NOTHING in between (no act, no state_dict: the training loop's own shape):
+  the second call must reach dx_cnn_ppo_epoch with mirrors_current = 2 -- the C side trusts the flag, a wrong 2 would
+  train on stale mirrors without an error -- and end at the same parameters, bit for bit, as a run whose epochs all end
+  with the full pack (more_epochs off: mirrors_current 1 on the second call).  128 samples in minibatches of 42: a ragged
+  fourth minibatch of 2.  Also with the linear layer + heads layer by layer and with the general packs."""
+  import os
+  import ctypes
+  import derl_amd as derl
+  from derl_amd import _lib
+  lib = _lib.load()
+  names = [item.split("=")[0] for item in switches.split()]
+  saved = {n: os.environ.get(n) for n in names}
+  real_call = _lib.call
+  try:
+    for item in switches.split():
+      os.environ[item.split("=")[0]] = item.split("=")[1]
+    assert lib.dx_reload_env() == 0
+
+    def two_epochs(light):
+      alg, calls = make_alg("cnn", True, 8, 16, 2, 3)
+      seen = []
+
+      def spying_call(name, *args):
+        if name == "dx_cnn_ppo_epoch":
+          epoch = args[1]._obj
+          seen.append((epoch.mirrors_current, epoch.more_epochs, epoch.mbsize, epoch.samples))
+        return real_call(name, *args)
+
+      _lib.call = spying_call
+      try:
+        it = alg.runner.run()
+        for k in range(8):  # 2 epochs x (3 minibatches of 42 + one of 2)
+          data = next(it)
+          derl.summary.stop_recording()
+          if not light:
+            data.epoch[0].more_epochs = False  # (read when the epoch's first minibatch is stepped)
+          alg.step(data)
+      finally:
+        _lib.call = real_call
+      assert calls == [4, 4] and alg.model.engine.open_epoch is None
+      return alg.model.engine.params.clone(), seen
+
+    light_params, light_seen = two_epochs(True)
+    full_params, full_seen = two_epochs(False)
+    assert [s[:2] for s in light_seen] == [(1, 1), (2, 0)], light_seen  # the rollout's act packed everything; then the light pack
+    assert [s[:2] for s in full_seen] == [(1, 0), (1, 0)], full_seen
+    assert all(s[2:] == (42, 128) for s in light_seen + full_seen)
+    assert torch.equal(light_params, full_params)
+  finally:
+    _lib.call = real_call
+    for n, v in saved.items():
+      if v is None:
+        os.environ.pop(n, None)
+      else:
+        os.environ[n] = v
+    lib.dx_reload_env()
+
+
 def _scalars_of_a_run(native):
   """Every scalar the summaries record over one rollout's updates, as (tag, global_step, value)."""
   import derl_amd as derl

@@ -32,6 +32,37 @@ def test_gae_matches_reference(case):
     assert adv.dtype == np.float32 and vt.dtype == np.float32
 
 
+@pytest.mark.parametrize("case", list(gi.GAE_CASES))
+def test_plain_c_gae_checker_is_pinned_to_the_reference_bit_for_bit(case):
+  """oracle/gae.c (the checker of tests/test_gae_gpu.py's full-size cases) against the same reference-generated
+  vectors as the NumPy restatement: bit-equal advantages and value targets on all seven cases.  (The reference feeds
+  float64 rewards where the golden case has them; the C checker takes the engine's float32 rewards, so a case whose
+  rewards are not exactly representable in float32 would differ -- none is.)"""
+  import ctypes
+  import __graft_entry__
+  path = os.path.join(os.path.dirname(G), os.pardir, "oracle", "liboracle_gae.so")
+  if not os.path.exists(path):
+    __graft_entry__.build_oracle()
+  lib = ctypes.CDLL(os.path.abspath(path))
+  lib.oracle_gae_f32.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                         ctypes.c_void_p, ctypes.c_void_p]
+  d = gi.gae_inputs(case)
+  r, z, v = d["rewards"], d["resets"], d["values"][..., 0]
+  if r.ndim == 1:
+    r, z, v = r[:, None], z[:, None], v[:, None]
+  r32 = np.ascontiguousarray(r, np.float32)
+  assert np.array_equal(r32.astype(r.dtype), r)  # the float32 hand-over loses nothing
+  z8, v32 = np.ascontiguousarray(z, np.uint8), np.ascontiguousarray(v, np.float32)
+  lv = np.ascontiguousarray(d["last_values"].reshape(-1), np.float32)
+  T, N = r32.shape
+  adv, vt = np.empty((T, N), np.float32), np.empty((T, N), np.float32)
+  assert lib.oracle_gae_f32(r32.ctypes.data, z8.ctypes.data, v32.ctypes.data, lv.ctypes.data, T, N,
+                            float(d["gamma"]), float(d["lambda_"]), adv.ctypes.data, vt.ctypes.data) == 0
+  with load("gae.npz") as g:
+    nt.assert_array_equal(adv.reshape(-1), g[f"{case}.advantages"].reshape(-1))
+    nt.assert_array_equal(vt.reshape(-1), g[f"{case}.value_targets"].reshape(-1))
+
+
 def test_gae_whole_batch_normalisation():
   d = gi.gae_inputs("ragged")
   adv, _ = oracle.gae_advantages(d["rewards"], d["resets"], d["values"],
