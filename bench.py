@@ -47,7 +47,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak
 # products they EXECUTE per algorithmic fp32 product: the first conv layer's uint8 pixels are exact in bf16
 # and the fp32 side splits exactly into three bf16 terms (3); conv1 / conv2 split BOTH fp32 operands and
 # multiply the six products above 2^-23 of x w (6).
-BF16_TERMS = {"conv0_b16": 3.0, "wgrad_b6": 6.0, "dgrad_b6": 6.0}
+BF16_TERMS = {"conv0_b16": 3.0, "conv0_ks": 3.0, "wgrad_b6": 6.0, "dgrad_b6": 6.0}
 CONV_STACK_FWD = "conv_stack_fwd"  # the training forward's three conv layers as ONE launch (route convstack_train)
 PEAK_HBM_GBPS = 8000.0
 

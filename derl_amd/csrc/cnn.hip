@@ -211,6 +211,12 @@ static float *tail_scratch(const dx_cnn_ctx *c, const Plan &plan, int B) {
   return c->slabs + plan.s[L_FC].w_off;
 }
 
+// the first layer's weight gradient on conv0_wgrad_ks.hip (84 x 84 x 4 frames; uint8 observations take it, float ones
+// keep the general GEMM with the same slab count)
+static bool conv0_ks_usable(const dx_cnn_ctx *c) {
+  return conv0_wgrad_ks_on() && !conv0_f32() && conv0_wgrad_ks_supported(c->in_h, c->in_w, c->in_c, c->h0, c->w0);
+}
+
 static Plan make_plan(const dx_cnn_ctx *c, long long B) {
   Plan p;
   p.fc_cap_floats = 0;
@@ -251,9 +257,10 @@ static Plan make_plan(const dx_cnn_ctx *c, long long B) {
         p.s[l].msplit = static_cast<int>(B < nwg ? B : nwg);
       }
     }
-    if (l == L_C0) {  // one slab per persistent workgroup of the direct conv0 wgrad (<= 512)
+    if (l == L_C0) {  // one slab per persistent workgroup of the direct conv0 wgrad (<= 512; the K-split kernel: <= 256)
       const long long tiles = (layer_rows(c, l, B) + 255) / 256;
       p.s[l].msplit = static_cast<int>(tiles < 512 ? tiles : 512);
+      if (conv0_ks_usable(c)) p.s[l].msplit = conv0_wgrad_ks_workgroups(B);  // (never more than the tile kernel's count)
       p.s[l].mper = roundup((layer_rows(c, l, B) + p.s[l].msplit - 1) / p.s[l].msplit, 32);
     }
     if (p.s[l].bsplit == 0) p.s[l].bsplit = p.s[l].msplit;
@@ -716,6 +723,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
         d.in_h = c->in_h; d.in_w = c->in_w; d.h0 = c->h0; d.w0 = c->w0;
         d.M = static_cast<int>(M0); d.ntiles = static_cast<int>((M0 + 255) / 256);
         d.G = c->dy0; d.slab = c->slabs + plan.s[L_C0].w_off; d.bias_slab = c->slabs + plan.s[L_C0].b_off;
+        if (conv0_ks_usable(c)) return took("conv0_ks", launch_conv0_wgrad_ks(d, plan.s[L_C0].msplit, s));
         return conv0_f32() ? took("conv0_f32", launch_conv0_wgrad(d, plan.s[L_C0].msplit, s))
                            : took("conv0_b16", launch_conv0_wgrad_b16(d, plan.s[L_C0].msplit, s));
       }

@@ -1,0 +1,261 @@
+// Weight gradient of the first convolution (8x8 stride 4 on uint8 84 x 84 x 4 frames; the autograd backward of
+// derl/models.py:103,117-124 triggered by derl/alg/common.py:70), round 6: the contraction over output pixels SPLIT
+// ACROSS THE WAVES, a wave holding all 32 channels x half the taps of the result.
+//
+//   dW[oc][kh][kw][ci] = 1/255 * sum over (img, oy, ox) of dY0[img][oy][ox][oc] * frame[img][4 oy + kh][4 ox + kw][ci]
+//
+// A GEMM with M = 32 output channels, N = 256 taps and K = 400 pixels per image.  With M that small, any split of N (or
+// M) over the waves of a workgroup makes every wave read the whole gradient operand again: conv0_b16.hip's tile kernel
+// (two k halves x two pixel halves, 32x32x16, bytes gathered with ds_read_u8-style reads and converted PER USE: 48
+// conversions per 12 MFMAs) runs with the matrix pipe 0.42 busy and 24 % of its LDS cycles in bank conflicts; round 4's
+// transposed-read kernel with four accumulator tiles per wave read a K step's operands 3x over and was slower still.
+// Here a wave owns 2 x 8 accumulator tiles (all 32 channels x HALF the taps: 64 registers; the whole 32 x 256 result in
+// 128 registers was built first and spilled) and takes whole K STEPS of 32 pixels: per step 12 transposed reads of the
+// gradient fragments (2 channel tiles x 3 planes) and 16 of the frame's (8 tap tiles) feed 48 v_mfma_f32_16x16x32_bf16
+// -- the frame leaves LDS ONCE per image, the gradient planes twice, 0.58 reads per MFMA.
+//   * the frame is converted to bf16 ONCE per image, when it is copied into LDS (a byte is exact in bf16): LDS image
+//     [84 rows][84 pixels][4 channels] bf16 in the frame's own order, so the 16 taps (kw, ci) of half a kernel row are 32
+//     contiguous bytes at pixel (4 oy + kh, 4 ox) and ds_read_b64_tr_b16 -- every lane supplies the address of ITS pixel
+//     -- hands each lane 4 consecutive K slots of its tap: no im2col, no gather table.  The natural 672-byte row pitch is
+//     conflict-free for the 8 consecutive pixels a 32-lane half reads (32-byte pixel stride; an 8-pixel group that
+//     crosses an output row lands 4 x 672 = 128 (mod 256) bytes on).
+//   * dY0 (fp32) is split EXACTLY into three bf16 planes [pixel][32 channels] (64-byte rows, the two 32-byte channel
+//     halves swapped on rows with bit 2 set: conflict-free transposed reads without padding); byte x bf16 products are
+//     exact in fp32, the planes are accumulated smallest first, fp32 accumulation as in every fp32 chain.
+//   * 400 pixels = 12.5 K steps.  Wave w = (tap half w >> 2, K group w & 3) takes the steps 3 (w & 3) .. + 2 and a QUARTER
+//     of the half-valid step 12 (two of its eight tap tiles, the step's upper K half known to be zero): every wave
+//     multiplies 3.25 half-steps per image, 13 steps per image where 12.5 are useful (executed / useful 1.04).
+//   * accumulators stay in registers over all images of the workgroup (one workgroup per CU, images blockIdx.x, + grid,
+//     ...); the next image's rows travel in registers while this one multiplies; at the end the four K groups' partial
+//     results meet in LDS in a fixed order (deterministic), are scaled by 1/255 and leave as ONE slab per workgroup
+//     (<= 256 slabs where the tile kernel wrote 512).
+// LDS: 56,448 (frame) + 3 x 25,664 (gradient planes incl. one zero row) = 133,440 bytes.
+#include "bf16_split.hpp"
+#include "igemm_dev.hpp"
+
+namespace dx {
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using lds_s16x4 = __attribute__((address_space(3))) s16x4;
+
+constexpr int kFrameB = 84 * 84 * 4;           // bytes of a uint8 frame
+constexpr int kXRow = 84 * 4 * 2;              // bytes of a bf16 LDS row
+constexpr int kXB = 84 * kXRow;
+constexpr int kPix = 400, kOW = 20, kGRow = 64;
+constexpr int kGPlane = (kPix + 1) * kGRow;    // row 400: zeros (K slots past the image)
+constexpr int oX = 0, oG = kXB, kEnd = oG + 3 * kGPlane;
+constexpr int kNG4 = kPix * 32 / 4, kGR = (kNG4 + 511) / 512;      // float4 pieces of an image's gradient rows; per lane
+constexpr int kNX16 = kFrameB / 16, kXR = (kNX16 + 511) / 512;     // 16-byte pieces of a frame; per lane
+static_assert(kFrameB % 16 == 0 && oG % 64 == 0 && kGPlane % 16 == 0 && kEnd <= 160 * 1024, "LDS layout");
+static_assert(4 * 32 * 256 * 4 <= kEnd, "the final reduction (four partial results) reuses the image's LDS");
+
+__device__ __forceinline__ s16x4 ks_tr(const uint8_t *smem, int off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(smem + off));  // (flat -> LDS address space)
+}
+__device__ __forceinline__ bf16x8 ks_frag(s16x4 lo, s16x4 hi) {
+  const __attribute__((ext_vector_type(8))) short v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// two bytes -> two bf16 (exact: the fp32 of an integer < 256 has a zero low half)
+__device__ __forceinline__ uint32_t ks_bytes2(uint32_t w, int lo) {
+  const float f0 = static_cast<float>((w >> (8 * lo)) & 0xff), f1 = static_cast<float>((w >> (8 * lo + 8)) & 0xff);
+  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, f1), __builtin_bit_cast(uint32_t, f0), 0x07060302u);
+}
+__device__ __forceinline__ float ks_div255(float x) {  // x / 255 to within the last bit (conv0_b16.hip)
+  const float r = 1.0f / 255.0f;
+  const float q = x * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
+}
+
+struct KsRows { int g0, g1, x0, x1; };  // this lane's row addresses of one K step: gradient / frame, K slots 4 r + q
+
+// Tap tiles J0 .. J0 + NJ - 1 (of this wave's eight; row.x0 / x1 point at its tap half) of one K step: the six gradient
+// fragments once, then per tap tile 6 MFMAs with the next tile's two transposed reads behind the first two.  HALF: the
+// step's K slots 16 .. 31 lie past the image (zeros).
+template <int J0, int NJ, bool HALF>
+__device__ __forceinline__ void ks_step(const uint8_t *smem, const KsRows &row, f32x4 (&acc)[2][8]) {
+  const s16x4 zero = {0, 0, 0, 0};
+  bf16x8 gf[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      gf[i][pl] = ks_frag(ks_tr(smem, (row.g0 ^ (32 * i)) + pl * kGPlane), HALF ? zero : ks_tr(smem, (row.g1 ^ (32 * i)) + pl * kGPlane));
+  auto xfrag = [&](int j) {
+    const int o = (j >> 1) * kXRow + (j & 1) * 32;
+    return ks_frag(ks_tr(smem, row.x0 + o), HALF ? zero : ks_tr(smem, row.x1 + o));
+  };
+  bf16x8 xf = xfrag(J0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int j = J0 + jj;
+    bf16x8 xn;
+    const bool more = jj + 1 < NJ;  // (compile-time after unrolling)
+    if (more) xn = xfrag(j + 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // planes smallest first
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i][2], xf, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i][1], xf, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i][0], xf, acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < (HALF ? 1 : 2); ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, HALF ? 5 : 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) xf = xn;
+  }
+}
+
+__global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, int B) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grid = static_cast<int>(gridDim.x), first = static_cast<int>(blockIdx.x);
+  const int nimg = (B - first + grid - 1) / grid;
+  typedef const __attribute__((address_space(4))) int32_t *ConstTable;  // the gather table: scalar loads, never written here
+  auto raw_of = [&](int img) { return a.idx ? static_cast<int>(((ConstTable)a.idx)[img]) : img; };
+
+  if (tid < 12)  // the zero row of each plane (never overwritten)
+    *reinterpret_cast<u32x4 *>(smem + oG + (tid >> 2) * kGPlane + kPix * kGRow + 16 * (tid & 3)) = u32x4{0u, 0u, 0u, 0u};
+
+  // ---- staging: piece tid + 512 u of the gradient rows (pixel (tid >> 3) + 64 u, channels 4 (tid & 7) ..) and of the frame
+  const int gdst = oG + (tid >> 3) * kGRow + 32 * (((tid >> 2) & 1) ^ ((tid >> 5) & 1)) + 8 * (tid & 3);
+  const int xdst = oX + 32 * tid;
+  f32x4 gr[kGR];
+  u32x4 xr[kXR];
+  auto fetch = [&](int img, int raw) {
+    const f32x4 *gs = reinterpret_cast<const f32x4 *>(a.G) + static_cast<long long>(img) * kNG4;
+    const u32x4 *xs = reinterpret_cast<const u32x4 *>(a.obs + static_cast<long long>(raw) * kFrameB);
+#pragma unroll
+    for (int u = 0; u < kGR; ++u) gr[u] = gs[min(tid + 512 * u, kNG4 - 1)];
+#pragma unroll
+    for (int u = 0; u < kXR; ++u) xr[u] = xs[min(tid + 512 * u, kNX16 - 1)];
+  };
+
+  // ---- this wave's K steps and this lane's rows in them: K slot 8 g + 4 r + q holds pixel 32 s + 16 r + 4 g + q ----
+  const int g4 = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+  const int kg = wave & 3, nh = wave >> 2;  // K group, tap half (kernel rows 4 nh .. 4 nh + 3)
+  auto rows_of = [&](int s) {
+    KsRows r;
+    int g[2], x[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p = 32 * s + 16 * h + 4 * g4 + q;
+      g[h] = oG + (p < kPix ? p * kGRow + 32 * (g4 & 1) : kPix * kGRow) + 8 * p4;
+      const int pc = min(p, kPix - 1), oy = pc / kOW, ox = pc - oy * kOW;  // (past the image: any valid pixel, times 0)
+      x[h] = oX + (4 * oy + 4 * nh) * kXRow + 32 * ox + 8 * p4;
+    }
+    r.g0 = g[0]; r.g1 = g[1]; r.x0 = x[0]; r.x1 = x[1];
+    return r;
+  };
+  const KsRows row0 = rows_of(3 * kg), row1 = rows_of(3 * kg + 1), row2 = rows_of(3 * kg + 2), row3 = rows_of(12);
+
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // column sums of the gradient rows this lane copies (channels 4 (tid & 7) ..)
+
+  int raw_next = nimg > 1 ? raw_of(first + grid) : 0;
+  fetch(first, raw_of(first));
+  for (int t = 0; t < nimg; ++t) {
+    if (t > 0) __syncthreads();  // every wave is done with the previous image
+#pragma unroll
+    for (int u = 0; u < kGR; ++u)
+      if (tid + 512 * u < kNG4) {
+        const Split4 s = split4(gr[u]);
+        *reinterpret_cast<uint2 *>(smem + gdst + 64 * kGRow * u) = s.hi;
+        *reinterpret_cast<uint2 *>(smem + gdst + 64 * kGRow * u + kGPlane) = s.mid;
+        *reinterpret_cast<uint2 *>(smem + gdst + 64 * kGRow * u + 2 * kGPlane) = s.lo;
+        bsum += gr[u];
+      }
+#pragma unroll
+    for (int u = 0; u < kXR; ++u)
+      if (tid + 512 * u < kNX16) {
+        const u32x4 w = xr[u];
+        *reinterpret_cast<u32x4 *>(smem + xdst + 32 * 512 * u) =
+            u32x4{ks_bytes2(w.x, 0), ks_bytes2(w.x, 2), ks_bytes2(w.y, 0), ks_bytes2(w.y, 2)};
+        *reinterpret_cast<u32x4 *>(smem + xdst + 32 * 512 * u + 16) =
+            u32x4{ks_bytes2(w.z, 0), ks_bytes2(w.z, 2), ks_bytes2(w.w, 0), ks_bytes2(w.w, 2)};
+      }
+    if (t + 1 < nimg) {
+      fetch(first + (t + 1) * grid, raw_next);
+      if (t + 2 < nimg) raw_next = raw_of(first + (t + 2) * grid);  // (a scalar load: in flight for a whole image)
+    }
+    __syncthreads();
+
+    ks_step<0, 8, false>(smem, row0, acc);
+    ks_step<0, 8, false>(smem, row1, acc);
+    ks_step<0, 8, false>(smem, row2, acc);
+    switch (kg) {  // (wave-uniform; the accumulator tiles need compile-time indices)
+      case 0: ks_step<0, 2, true>(smem, row3, acc); break;
+      case 1: ks_step<2, 2, true>(smem, row3, acc); break;
+      case 2: ks_step<4, 2, true>(smem, row3, acc); break;
+      default: ks_step<6, 2, true>(smem, row3, acc); break;
+    }
+  }
+
+  // ---- the four K groups' partial results meet in LDS, added in order ----
+  float *part = reinterpret_cast<float *>(smem);  // [kg][nh][i][j][r][lane]
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[((((kg * 2 + nh) * 2 + i) * 8 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+  __syncthreads();
+  // slab[oc][k], k = 32 kh + 4 kw + ci: element (oc, k) sits in tap half k / 128, tile (i = oc / 16, j = (k % 128) / 16),
+  // register r = oc % 4 of lane 16 ((oc % 16) / 4) + k % 16 (the MFMA's output map: D[4 (lane >> 4) + r][lane & 15])
+  float *slab = a.slab + static_cast<long long>(first) * 32 * 256;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = tid + 512 * u, oc = e >> 8, k = e & 255;
+    const int at = (((((k >> 7) * 2 + (oc >> 4)) * 8 + ((k >> 4) & 7)) * 4 + (oc & 3)) * 64) + 16 * ((oc & 15) >> 2) + (k & 15);
+    slab[e] = ks_div255(((part[at] + part[at + 8192]) + part[at + 2 * 8192]) + part[at + 3 * 8192]);
+  }
+  // ---- bias gradient: the 64 lanes with the same tid & 7 hold partial sums of the same four channels ----
+  if (a.bias_slab) {
+    __syncthreads();
+    reinterpret_cast<f32x4 *>(smem)[tid] = bsum;
+    __syncthreads();
+    if (tid < 32) {
+      float s = 0.f;
+      for (int m = 0; m < 64; ++m) s += reinterpret_cast<const float *>(smem)[(8 * m + (tid >> 2)) * 4 + (tid & 3)];
+      a.bias_slab[static_cast<long long>(first) * 32 + tid] = s;
+    }
+  }
+}
+
+}  // namespace
+
+// DX_CONV0_KS=0: conv0_b16.hip's tile kernel (two k halves x two pixel halves per 256-pixel tile)
+bool conv0_wgrad_ks_on() { return DX_ENV("DX_CONV0_KS", 1) != 0; }
+bool conv0_wgrad_ks_supported(int in_h, int in_w, int in_c, int h0, int w0) {
+  return in_h == 84 && in_w == 84 && in_c == 4 && h0 == 20 && w0 == 20;
+}
+// slabs (= workgroups) a minibatch of B frames is reduced over: one workgroup per CU, at most one per frame
+int conv0_wgrad_ks_workgroups(long long B) { return static_cast<int>(B < 256 ? B : 256); }
+
+int launch_conv0_wgrad_ks(const Conv0Args &a, int nblocks, hipStream_t stream) {
+  DX_REQUIRE(a.obs && a.G && a.slab && a.M > 0 && a.M % kPix == 0, "conv0_wgrad_ks: bad arguments");
+  DX_REQUIRE(conv0_wgrad_ks_supported(a.in_h, a.in_w, 4, a.h0, a.w0), "conv0_wgrad_ks: 84 x 84 x 4 frames only (%d x %d -> %d x %d)",
+             a.in_h, a.in_w, a.h0, a.w0);
+  const int B = a.M / kPix;
+  DX_REQUIRE(nblocks >= 1 && nblocks <= B && nblocks <= 256, "conv0_wgrad_ks: %d workgroups for %d frames", nblocks, B);
+  DX_REQUIRE(aligned(a.obs, 16) && aligned(a.G, 16), "conv0_wgrad_ks: frames and gradient rows must be 16-byte aligned");
+  DX_LDS_OPT_IN(conv0_wgrad_ks_kernel, kEnd);
+  hipLaunchKernelGGL(conv0_wgrad_ks_kernel, dim3(nblocks), dim3(512), kEnd, stream, a, B);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+}  // namespace dx

@@ -212,6 +212,12 @@ int launch_conv0_wgrad(const Conv0Args &a, int nblocks, hipStream_t stream);
 // (conv0_b16.hip); the default.  DX_CONV0_F32=1 selects the fp32-MFMA kernels above.
 int launch_conv0_fwd_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t stream);
 int launch_conv0_wgrad_b16(const Conv0Args &a, int nblocks, hipStream_t stream);
+// round 6 (conv0_wgrad_ks.hip): 84 x 84 x 4 uint8 frames, the pixel contraction split over the waves, ONE slab per
+// workgroup (conv0_wgrad_ks_workgroups(B) <= 256 of them); DX_CONV0_KS=0 keeps the tile kernel above
+bool conv0_wgrad_ks_on();
+bool conv0_wgrad_ks_supported(int in_h, int in_w, int in_c, int h0, int w0);
+int conv0_wgrad_ks_workgroups(long long B);
+int launch_conv0_wgrad_ks(const Conv0Args &a, int nblocks, hipStream_t stream);
 // rollout-sized batches: 32x32 tile per workgroup, pre-split weight planes Wb [3][32][256] bf16
 int launch_conv0_lat_b16(const Conv0Args &a, const uint16_t *Wb, hipStream_t stream);
 // the rollout's whole conv stack -- optionally the whole act step, or T steps against the synthetic device

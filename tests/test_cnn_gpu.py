@@ -291,7 +291,7 @@ def test_backward_with_float_observations(batch, route):
               advantages=rs.standard_normal(batch).astype(np.float32),
               values=rs.standard_normal((batch, 1)).astype(np.float32) * 0.2,
               value_targets=rs.standard_normal((batch, 1)).astype(np.float32))
-  eng = make_engine(A, weights, max_batch=max_batch or max(256, batch))
+  eng = make_engine(A, weights, max_batch=max(256, batch))
   loss, grads = run_loss_and_backward(eng, data, 0, 0.1, 0.25, 0.01, A, torch.from_numpy(idx).to(DEV), route=route)
   lib = _lib.load()
   assert lib.dx_cnn_last_route(1).decode() != "convstack_train"        # conv1 forward: an fp32 stage
@@ -571,6 +571,36 @@ def test_bf16_split_gradients_are_as_accurate_as_the_fp32_kernels():
     assert err_b6 <= max(2.0 * err_fp32, 2e-6 * scale), (name, err_b6, err_fp32, scale)
 
 
+@pytest.mark.parametrize("batch,gather", [(1, False), (5, True), (37, True), (300, False), (1030, True)])
+def test_first_layer_weight_gradient_against_float64_sums_over_its_own_operands(batch, gather):
+  """conv0_wgrad_ks.hip (the pixel contraction split over the waves; the frame converted to bf16 once per image, dY0 split
+  exactly into three bf16 planes, transposed LDS reads) against float64 sums over the very buffers the kernel reads --
+  the uint8 frames (through the minibatch's gather table) and the dY0 the backward left: exact products, so only the
+  fp32 accumulation's own roundings remain (<= 2e-6 of the gradient's scale).  1, 5, 37, 300 frames: one workgroup per
+  frame; 1,030: 256 workgroups of 4 - 5 frames, accumulators kept across them."""
+  import ctypes
+  from derl_amd import _lib
+  eng = make_engine(4, gi.nature_cnn_weights(4, 3), max_batch=max(batch, 64))
+  pool = torch.from_numpy(gi.frames(batch + 3, 40 + batch)).to(DEV)
+  idx = torch.from_numpy(np.random.RandomState(batch).permutation(batch + 3)[:batch].astype(np.int32)).to(DEV) if gather else None
+  obs = pool if gather else pool[:batch].contiguous()
+  eng.forward(obs, idx)
+  eng._ensure_backward()
+  eng.dhead[:batch * 32].normal_(generator=torch.Generator(DEV).manual_seed(batch))
+  grads = eng.backward(obs, idx).double()
+  torch.cuda.synchronize()
+  assert _lib.load().dx_cnn_last_route(13).decode() == "conv0_ks"
+  frames = (pool[idx.long()] if gather else obs).permute(0, 3, 1, 2).double() / 255
+  dy0 = eng.dy0[:batch * 12800].view(batch, 20, 20, 32).permute(0, 3, 1, 2).double()
+  ref = torch.nn.grad.conv2d_weight(frames, (32, 4, 8, 8), dy0, stride=4)
+  ctx = eng.ctx
+  got = grads[ctx.off_w[0]:ctx.off_w[0] + ref.numel()].view_as(ref)
+  scale = float(ref.abs().max())
+  assert float((got - ref).abs().max()) <= 2e-6 * scale, (float((got - ref).abs().max()), scale)
+  bias = dy0.sum((0, 2, 3))
+  assert float((grads[ctx.off_b[0]:ctx.off_b[0] + 32] - bias).abs().max()) <= 2e-6 * float(bias.abs().max())
+
+
 def test_exact_split_keeps_extreme_magnitudes_and_never_hides_a_non_finite_value():
   """The conv layers split every fp32 operand EXACTLY into three bf16 terms (csrc/bf16_split.hpp).  bf16 has fp32's
   exponent range, so (i) activations of extreme but finite magnitude (1e-30 .. 1e30 here, by scaling the first layer's
@@ -696,7 +726,8 @@ SWITCH_SETTINGS = ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_TN_SWIZZLE=0", "DX_LA
                    "DX_CONVSTACK=0", "DX_CONVSTACK=0 DX_FC_FACTORED=0 DX_FC_ROLLOUT=0",  # the rollout's layer-by-layer kernels
                    "DX_CONVSTACK_TRAIN=0 DX_WGRAD_B6=0 DX_DGRAD_B6=0",  # the update's fp32-MFMA conv stages
                    "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
-                   "DX_BWD_OVERLAP=0 DX_C0_WAVES=4 DX_C0_GROUP4=0"]  # and their serial / round-2 twins
+                   "DX_BWD_OVERLAP=0 DX_C0_WAVES=4 DX_C0_GROUP4=0 DX_CONV0_KS=0",  # and their serial / round-2 twins
+                   "DX_CONV0_KS=0"]                              # the first layer's weight gradient on the 256-pixel-tile kernel
 
 
 def test_diagnostic_switches_keep_parity():
@@ -777,7 +808,7 @@ def test_baseline_minibatches_take_the_fast_kernel_families():
     assert got["conv2_wgrad"] == got["conv1_wgrad"] == "wgrad_b6", (batch, got)
     assert got["conv2_dgrad"] == got["conv1_dgrad"] == "dgrad_b6", (batch, got)
     assert got["fc_wgrad"] == "wgrad_fc", (batch, got)
-    assert got["conv0_fwd"] == got["conv0_wgrad"] == "conv0_b16", (batch, got)
+    assert got["conv0_fwd"] == "conv0_b16" and got["conv0_wgrad"] == "conv0_ks", (batch, got)
   assert routes(8192)["fc_fwd"] == "ntp"
   ragged = routes(8192 - 64)  # 63.5 groups of 128 images: the ring's dgrad tiles (one pixel x 128 images) do not exist
   assert ragged["fc_dgrad"] != "ntp", ragged
