@@ -32,6 +32,9 @@
 // LDS: 56,448 (frame) + 3 x 25,664 (gradient planes incl. one zero row) = 133,440 bytes.
 #include "bf16_split.hpp"
 #include "igemm_dev.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace dx {
 namespace {
@@ -47,7 +50,7 @@ constexpr int kPix = 400, kOW = 20, kGRow = 64;
 constexpr int kGPlane = (kPix + 1) * kGRow;    // row 400: zeros (K slots past the image)
 constexpr int oX = 0, oG = kXB, kEnd = oG + 3 * kGPlane;
 constexpr int kNG4 = kPix * 32 / 4, kGR = (kNG4 + 511) / 512;      // float4 pieces of an image's gradient rows; per lane
-constexpr int kNX16 = kFrameB / 16, kXR = (kNX16 + 511) / 512;     // 16-byte pieces of a frame; per lane
+constexpr int kNX8 = kFrameB / 8, kXR = (kNX8 + 511) / 512;        // 8-byte pieces of a frame; per lane
 static_assert(kFrameB % 16 == 0 && oG % 64 == 0 && kGPlane % 16 == 0 && kEnd <= 160 * 1024, "LDS layout");
 static_assert(4 * 32 * 256 * 4 <= kEnd, "the final reduction (four partial results) reuses the image's LDS");
 
@@ -114,29 +117,38 @@ __device__ __forceinline__ void ks_step(const uint8_t *smem, const KsRows &row, 
   }
 }
 
-__global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, int B) {
+__global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, int B, unsigned long long *stamps) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grid = static_cast<int>(gridDim.x), first = static_cast<int>(blockIdx.x);
   const int nimg = (B - first + grid - 1) / grid;
   typedef const __attribute__((address_space(4))) int32_t *ConstTable;  // the gather table: scalar loads, never written here
   auto raw_of = [&](int img) { return a.idx ? static_cast<int>(((ConstTable)a.idx)[img]) : img; };
+  // DX_DIAG only: shader cycles per phase, summed over this workgroup's images (wave 0)
+  unsigned long long ph[4] = {0, 0, 0, 0}, tprev = 0;
+#define DX_KS_MARK(i) if (kDiag && stamps) { const unsigned long long now = __builtin_amdgcn_s_memtime(); ph[i] += now - tprev; tprev = now; }
 
   if (tid < 12)  // the zero row of each plane (never overwritten)
     *reinterpret_cast<u32x4 *>(smem + oG + (tid >> 2) * kGPlane + kPix * kGRow + 16 * (tid & 3)) = u32x4{0u, 0u, 0u, 0u};
 
-  // ---- staging: piece tid + 512 u of the gradient rows (pixel (tid >> 3) + 64 u, channels 4 (tid & 7) ..) and of the frame
+  // ---- staging: piece tid + 512 u of the gradient rows (float4: pixel (tid >> 3) + 64 u, channels 4 (tid & 7) ..) and of
+  // the frame (8 bytes = 2 pixels -> 16 bytes of bf16: consecutive lanes write consecutive 16 bytes) ----
   const int gdst = oG + (tid >> 3) * kGRow + 32 * (((tid >> 2) & 1) ^ ((tid >> 5) & 1)) + 8 * (tid & 3);
-  const int xdst = oX + 32 * tid;
-  f32x4 gr[kGR];
-  u32x4 xr[kXR];
-  auto fetch = [&](int img, int raw) {
+  const int xdst = oX + 16 * tid;
+  // The gradient rows (2/3 of an image's bytes) travel TWO images ahead, the frame one: with everything one image ahead
+  // the loads were only in flight while an image multiplied (2.5 us) and an image took the memory latency under load plus
+  // its staging -- 5.4 us, 3.7 TB/s (first version of this kernel: 173 us at minibatch 8192)
+  f32x4 ga[kGR], gb[kGR];
+  uint2 xr[kXR];
+  auto fetch_g = [&](f32x4 (&gr)[kGR], int img) {
     const f32x4 *gs = reinterpret_cast<const f32x4 *>(a.G) + static_cast<long long>(img) * kNG4;
-    const u32x4 *xs = reinterpret_cast<const u32x4 *>(a.obs + static_cast<long long>(raw) * kFrameB);
 #pragma unroll
     for (int u = 0; u < kGR; ++u) gr[u] = gs[min(tid + 512 * u, kNG4 - 1)];
+  };
+  auto fetch_x = [&](int raw) {
+    const uint2 *xs = reinterpret_cast<const uint2 *>(a.obs + static_cast<long long>(raw) * kFrameB);
 #pragma unroll
-    for (int u = 0; u < kXR; ++u) xr[u] = xs[min(tid + 512 * u, kNX16 - 1)];
+    for (int u = 0; u < kXR; ++u) xr[u] = xs[min(tid + 512 * u, kNX8 - 1)];
   };
 
   // ---- this wave's K steps and this lane's rows in them: K slot 8 g + 4 r + q holds pixel 32 s + 16 r + 4 g + q ----
@@ -164,10 +176,23 @@ __global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, 
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // column sums of the gradient rows this lane copies (channels 4 (tid & 7) ..)
 
+  // one image: its rows -> LDS, the registers refilled (gradient rows of image t + 2, frame of image t + 1), multiply
   int raw_next = nimg > 1 ? raw_of(first + grid) : 0;
-  fetch(first, raw_of(first));
-  for (int t = 0; t < nimg; ++t) {
+  auto image = [&](int t, f32x4 (&gr)[kGR]) {
+    if (kDiag && stamps) tprev = __builtin_amdgcn_s_memtime();
     if (t > 0) __syncthreads();  // every wave is done with the previous image
+    DX_KS_MARK(0)
+#pragma unroll
+    for (int u = 0; u < kXR; ++u)
+      if (tid + 512 * u < kNX8) {
+        const uint2 w = xr[u];
+        *reinterpret_cast<u32x4 *>(smem + xdst + 16 * 512 * u) =
+            u32x4{ks_bytes2(w.x, 0), ks_bytes2(w.x, 2), ks_bytes2(w.y, 0), ks_bytes2(w.y, 2)};
+      }
+    if (t + 1 < nimg) {
+      fetch_x(raw_next);
+      if (t + 2 < nimg) raw_next = raw_of(first + (t + 2) * grid);  // (a scalar load: in flight for a whole image)
+    }
 #pragma unroll
     for (int u = 0; u < kGR; ++u)
       if (tid + 512 * u < kNG4) {
@@ -177,21 +202,10 @@ __global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, 
         *reinterpret_cast<uint2 *>(smem + gdst + 64 * kGRow * u + 2 * kGPlane) = s.lo;
         bsum += gr[u];
       }
-#pragma unroll
-    for (int u = 0; u < kXR; ++u)
-      if (tid + 512 * u < kNX16) {
-        const u32x4 w = xr[u];
-        *reinterpret_cast<u32x4 *>(smem + xdst + 32 * 512 * u) =
-            u32x4{ks_bytes2(w.x, 0), ks_bytes2(w.x, 2), ks_bytes2(w.y, 0), ks_bytes2(w.y, 2)};
-        *reinterpret_cast<u32x4 *>(smem + xdst + 32 * 512 * u + 16) =
-            u32x4{ks_bytes2(w.z, 0), ks_bytes2(w.z, 2), ks_bytes2(w.w, 0), ks_bytes2(w.w, 2)};
-      }
-    if (t + 1 < nimg) {
-      fetch(first + (t + 1) * grid, raw_next);
-      if (t + 2 < nimg) raw_next = raw_of(first + (t + 2) * grid);  // (a scalar load: in flight for a whole image)
-    }
+    if (t + 2 < nimg) fetch_g(gr, first + (t + 2) * grid);
+    DX_KS_MARK(1)
     __syncthreads();
-
+    DX_KS_MARK(2)
     ks_step<0, 8, false>(smem, row0, acc);
     ks_step<0, 8, false>(smem, row1, acc);
     ks_step<0, 8, false>(smem, row2, acc);
@@ -201,7 +215,20 @@ __global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, 
       case 2: ks_step<4, 2, true>(smem, row3, acc); break;
       default: ks_step<6, 2, true>(smem, row3, acc); break;
     }
+    DX_KS_MARK(3)
+  };
+  fetch_x(raw_of(first));
+  fetch_g(ga, first);
+  if (nimg > 1) fetch_g(gb, first + grid);
+  for (int t = 0; t < nimg; t += 2) {
+    image(t, ga);
+    if (t + 1 < nimg) image(t + 1, gb);
   }
+  if (kDiag && stamps && tid == 0) {
+    unsigned long long *o = stamps + static_cast<long long>(blockIdx.x) * 4;
+    for (int i = 0; i < 4; ++i) o[i] = ph[i];
+  }
+#undef DX_KS_MARK
 
   // ---- the four K groups' partial results meet in LDS, added in order ----
   float *part = reinterpret_cast<float *>(smem);  // [kg][nh][i][j][r][lane]
@@ -253,7 +280,25 @@ int launch_conv0_wgrad_ks(const Conv0Args &a, int nblocks, hipStream_t stream) {
   DX_REQUIRE(nblocks >= 1 && nblocks <= B && nblocks <= 256, "conv0_wgrad_ks: %d workgroups for %d frames", nblocks, B);
   DX_REQUIRE(aligned(a.obs, 16) && aligned(a.G, 16), "conv0_wgrad_ks: frames and gradient rows must be 16-byte aligned");
   DX_LDS_OPT_IN(conv0_wgrad_ks_kernel, kEnd);
-  hipLaunchKernelGGL(conv0_wgrad_ks_kernel, dim3(nblocks), dim3(512), kEnd, stream, a, B);
+#if DX_DIAG
+  if (getenv("DX_C0_DIAG")) {  // in-kernel phase cycles, summarised on stderr (synchronous)
+    unsigned long long *dev = nullptr;
+    DX_HIP(hipMalloc(&dev, static_cast<size_t>(nblocks) * 32));
+    hipLaunchKernelGGL(conv0_wgrad_ks_kernel, dim3(nblocks), dim3(512), kEnd, stream, a, B, dev);
+    DX_LAUNCH_CHECK();
+    DX_HIP(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> h(static_cast<size_t>(nblocks) * 4);
+    DX_HIP(hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost));
+    DX_HIP(hipFree(dev));
+    double sum[4] = {0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b)
+      for (int i = 0; i < 4; ++i) sum[i] += static_cast<double>(h[static_cast<size_t>(b) * 4 + i]);
+    fprintf(stderr, "[conv0_wgrad_ks B=%d grid=%d] cycles per image (wave 0): barrier-in %.0f, staging (waits for its loads) "
+            "%.0f, barrier %.0f, multiply %.0f\n", B, nblocks, sum[0] / B, sum[1] / B, sum[2] / B, sum[3] / B);
+    return DX_OK;
+  }
+#endif
+  hipLaunchKernelGGL(conv0_wgrad_ks_kernel, dim3(nblocks), dim3(512), kEnd, stream, a, B, static_cast<unsigned long long *>(nullptr));
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
