@@ -672,14 +672,14 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     case ST_CONV2_WGRAD:
       if (plan.s[L_C2].direct) {
         const WgradDirectArgs d{c->y1, c->dy2, c->slabs + plan.s[L_C2].w_off, c->slabs + plan.s[L_C2].b_off,
-                                B, c->h1, c->w1, c->h2, c->w2, 0};
+                                B, c->h1, c->w1, c->h2, c->w2, 0, bwd_descending(ST_CONV2_WGRAD) ? 1 : 0};
         if (wgrad_b6_on()) return took("wgrad_b6", launch_wgrad_b6(d, stage, plan.s[L_C2].msplit, s));
         return took("wgrad_direct", launch_wgrad_direct(d, stage, plan.s[L_C2].msplit, s));
       }
       return took("igemm_tn", tn(L_C2, conv_gather(c->y1, nullptr, c->h1, c->w1, kC1, c->h2, c->w2, 1, 3, 3), c->dy2, kC2, M2,
                                   kC2, 9 * kC1, false));
     case ST_CONV2_DGRAD:
-      if (dgrad_b6_usable(c)) return took("dgrad_b6", launch_dgrad_b6(2, c->dy2, planes(c, c->ps_c2d), c->y1, c->dy1, B, s));
+      if (dgrad_b6_usable(c)) return took("dgrad_b6", launch_dgrad_b6(2, c->dy2, planes(c, c->ps_c2d), c->y1, c->dy1, B, s, bwd_descending(ST_CONV2_DGRAD)));
       a = nt_args(dgrad_gather(c->dy2, c->h2, c->w2, kC2, c->h1, c->w1, 3, 3), pk + c->pk_c2d, nullptr,
                   c->dy1, kC1, M1, kC1, 9 * kC2);
       a.Wb = planes(c, c->pb_c2d); a.wb_plane = kC2 * 9LL * kC1;
@@ -690,7 +690,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
     case ST_CONV1_WGRAD:
       if (plan.s[L_C1].direct) {
         const WgradDirectArgs d{c->y0, c->dy1, c->slabs + plan.s[L_C1].w_off, c->slabs + plan.s[L_C1].b_off,
-                                B, c->h0, c->w0, c->h1, c->w1, 0};
+                                B, c->h0, c->w0, c->h1, c->w1, 0, bwd_descending(ST_CONV1_WGRAD) ? 1 : 0};
         if (wgrad_b6_on()) return took("wgrad_b6", launch_wgrad_b6(d, stage, plan.s[L_C1].msplit, s));
         return took("wgrad_direct", launch_wgrad_direct(d, stage, plan.s[L_C1].msplit, s));
       }
@@ -702,7 +702,7 @@ static int run_stage(const dx_cnn_ctx *c, int stage, const void *obs, int obs_is
       // share one gathered A matrix: one GEMM with N = 4 x 32 columns [(py,px)][ic], scattered
       // to the 2x2 pixel block by the output map.
       const int OHp = (c->h0 + 1) / 2, OWp = (c->w0 + 1) / 2;
-      if (dgrad_b6_usable(c)) return took("dgrad_b6", launch_dgrad_b6(1, c->dy1, planes(c, c->ps_c1d), c->y0, c->dy0, B, s));
+      if (dgrad_b6_usable(c)) return took("dgrad_b6", launch_dgrad_b6(1, c->dy1, planes(c, c->ps_c1d), c->y0, c->dy0, B, s, bwd_descending(ST_CONV1_DGRAD)));
       a = nt_args(dgrad_gather(c->dy1, c->h1, c->w1, kC1, OHp, OWp, 2, 2), pk + c->pk_c1d[0], nullptr,
                   c->dy0, kC0, static_cast<long long>(B) * OHp * OWp, 4 * kC0, 4 * kC1);
       a.Wb = planes(c, c->pb_c1d); a.wb_plane = kC1 * 16LL * kC0;

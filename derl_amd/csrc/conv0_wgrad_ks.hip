@@ -144,18 +144,18 @@ __device__ __forceinline__ void ks_multiply(const uint8_t *smem, const KsRows &r
 
 // `variant` (DX_DIAG only, DX_KS_VARIANT; WRONG results, timing experiments): 1 = no multiplication, 2 = no loads after
 // the first image's, 4 = no copy into LDS (bits may be combined)
-__global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, int B, unsigned long long *stamps, int variant) {
+__global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, int B, unsigned long long *stamps, int variant, int descending) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grid = static_cast<int>(gridDim.x), first = static_cast<int>(blockIdx.x);
   const int nimg = (B - first + grid - 1) / grid;
   // The gather table entries of this workgroup's frames, read ONCE into LDS: a scalar load per image, even issued an image
   // ahead, is waited for by the next barrier's lgkmcnt(0) -- a memory round trip per image (1,260 cycles per image in the
-  // stamps of this kernel's second version).  Images are walked from the LAST one down: the first layer's gradient rows
-  // were written by the launch before this one in ascending order, so the tail of them is what the 256 MB last-level
-  // cache still holds.
+  // stamps of this kernel's second version).  `descending`: images are walked from the LAST one down -- the first layer's
+  // gradient rows were written by the launch before this one in ascending order, so the tail of them is what the 256 MB
+  // last-level cache still holds (180-181 us against 185-188 ascending, same box).
   int *raws = reinterpret_cast<int *>(smem + kEnd);
-  auto img_of = [&](int t) { return (kDiag && (variant & 32)) ? first + t * grid : B - 1 - (first + t * grid); };  // (32: ascending, a timing experiment)
+  auto img_of = [&](int t) { return descending ? B - 1 - (first + t * grid) : first + t * grid; };
   for (int i = tid; i < nimg; i += 512) raws[i] = a.idx ? a.idx[img_of(i)] : img_of(i);
   __syncthreads();
   auto raw_of = [&](int t) { return __builtin_amdgcn_readfirstlane(raws[t]); };
@@ -300,6 +300,18 @@ __global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, 
 
 }  // namespace
 
+bool bwd_descending(int stage) {  // (igemm.hpp: which way a backward stage walks the minibatch)
+  const int mask = DX_ENV("DX_BWD_ORDER", 21);
+  switch (stage) {
+    case ST_CONV2_WGRAD: return (mask & 1) != 0;
+    case ST_CONV2_DGRAD: return (mask & 2) != 0;
+    case ST_CONV1_WGRAD: return (mask & 4) != 0;
+    case ST_CONV1_DGRAD: return (mask & 8) != 0;
+    case ST_CONV0_WGRAD: return (mask & 16) != 0;
+    default: return false;
+  }
+}
+
 // DX_CONV0_KS=0: conv0_b16.hip's tile kernel (two k halves x two pixel halves per 256-pixel tile)
 bool conv0_wgrad_ks_on() { return DX_ENV("DX_CONV0_KS", 1) != 0; }
 bool conv0_wgrad_ks_supported(int in_h, int in_w, int in_c, int h0, int w0) {
@@ -318,13 +330,14 @@ int launch_conv0_wgrad_ks(const Conv0Args &a, int nblocks, hipStream_t stream) {
   const int per_wg = cdiv(B, nblocks), lds = kEnd + 4 * per_wg;
   DX_REQUIRE(per_wg <= kMaxImages, "conv0_wgrad_ks: %d frames per workgroup (max %d)", per_wg, kMaxImages);
   DX_LDS_OPT_IN(conv0_wgrad_ks_kernel, kEnd + 4 * kMaxImages);
+  const int descending = bwd_descending(ST_CONV0_WGRAD) ? 1 : 0;
   int variant = 0;
 #if DX_DIAG
   variant = DX_ENV("DX_KS_VARIANT", 0);
   if (getenv("DX_C0_DIAG")) {  // in-kernel phase cycles, summarised on stderr (synchronous)
     unsigned long long *dev = nullptr;
     DX_HIP(hipMalloc(&dev, static_cast<size_t>(nblocks) * 64));
-    hipLaunchKernelGGL(conv0_wgrad_ks_kernel, dim3(nblocks), dim3(512), lds, stream, a, B, dev, variant);
+    hipLaunchKernelGGL(conv0_wgrad_ks_kernel, dim3(nblocks), dim3(512), lds, stream, a, B, dev, variant, descending);
     DX_LAUNCH_CHECK();
     DX_HIP(hipStreamSynchronize(stream));
     std::vector<unsigned long long> h(static_cast<size_t>(nblocks) * 4);
@@ -338,7 +351,7 @@ int launch_conv0_wgrad_ks(const Conv0Args &a, int nblocks, hipStream_t stream) {
     return DX_OK;
   }
 #endif
-  hipLaunchKernelGGL(conv0_wgrad_ks_kernel, dim3(nblocks), dim3(512), lds, stream, a, B, static_cast<unsigned long long *>(nullptr), variant);
+  hipLaunchKernelGGL(conv0_wgrad_ks_kernel, dim3(nblocks), dim3(512), lds, stream, a, B, static_cast<unsigned long long *>(nullptr), variant, descending);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -166,6 +166,7 @@ struct DgradB6Args {
   const float *mask_src; // the layer's INPUT activation (post-ReLU): its sign is the mask
   float *out;            // the input gradient, same shape as mask_src
   int B;
+  int descending;        // walk the minibatch from its last image down (igemm.hpp: bwd_descending)
 };
 
 template <int L>
@@ -196,8 +197,9 @@ __global__ __launch_bounds__(512) void conv_dgrad_b6_kernel(const DgradB6Args a)
     gdst[u] = (pix / G::GW + G::BORDER) * G::RP + (pix % G::GW + G::BORDER) * kPX + 8 * (v % 16);
   }
   f32x4 gr[Y::GR];
-  auto fetch = [&](int img) {
-    const f32x4 *gs = reinterpret_cast<const f32x4 *>(a.g) + static_cast<long long>(img) * Y::NG4;
+  auto image_of = [&](int slot) { return a.descending ? a.B - 1 - slot : slot; };
+  auto fetch = [&](int slot) {
+    const f32x4 *gs = reinterpret_cast<const f32x4 *>(a.g) + static_cast<long long>(image_of(slot)) * Y::NG4;
 #pragma unroll
     for (int u = 0; u < Y::GR; ++u) gr[u] = gs[min(tid + 512 * u, Y::NG4 - 1)];
   };
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(512) void conv_dgrad_b6_kernel(const DgradB6Args a)
   stage(0);
   if (nimg > 1) fetch(blockIdx.x + gridDim.x);
   for (int t = 0; t < nimg; ++t) {
-    const int img = blockIdx.x + t * gridDim.x;
+    const int img = image_of(blockIdx.x + t * gridDim.x);
     dg_lds_barrier();  // image t is in LDS (and every wave is done with image t - 1: its buffer may be overwritten)
     if (t + 1 < nimg) {
       stage((t + 1) & 1);
@@ -350,12 +352,13 @@ int launch_dgrad_b6_pack(const float *const c1d[4], const float *c2d, uint16_t *
 }
 
 // layer 1: dY0 (B, 20, 20, 32) from dY1 (B, 9, 9, 64), masked by Y0; layer 2: dY1 from dY2 (B, 7, 7, 64), masked by Y1
-int launch_dgrad_b6(int layer, const float *g, const uint16_t *Wf, const float *mask_src, float *out, int B, hipStream_t stream) {
+int launch_dgrad_b6(int layer, const float *g, const uint16_t *Wf, const float *mask_src, float *out, int B, hipStream_t stream,
+                    bool descending) {
   DX_REQUIRE((layer == 1 || layer == 2) && g && Wf && mask_src && out && B > 0, "dgrad_b6: bad arguments");
   DX_REQUIRE(aligned(g, 16) && aligned(Wf, 16) && aligned(mask_src, 16) && aligned(out, 16), "dgrad_b6: operands must be 16-byte aligned");
   int cus = 0;
   if (int rc = device_cus(&cus)) return rc;
-  const DgradB6Args a{g, Wf, mask_src, out, B};
+  const DgradB6Args a{g, Wf, mask_src, out, B, descending ? 1 : 0};
   const int nwg = B < cus ? B : cus;
   return layer == 1 ? launch_dg<1>(a, nwg, stream) : launch_dg<2>(a, nwg, stream);
 }

@@ -165,7 +165,14 @@ struct WgradDirectArgs {
   float *bias_slab;  // [workgroups][OC]
   int B, IH, IW, OH, OW;
   int diag;  // timing experiments only (DX_WD_DIAG): bit 0 copy only the first image, bit 1 skip the slab store
+  int descending;  // wgrad_b6.hip: walk the minibatch from its LAST image down (bwd_descending)
 };
+// Which way a backward stage walks the minibatch.  A stage's operands were written (or last read) by the stage before
+// it, ascending; what the 256 MB last-level cache still holds of them is their TAIL.  So the weight gradients walk
+// descending (conv1: the tail of dY1 that conv2's data gradient just wrote; conv0: the tail of dY0) and the data
+// gradient that follows walks ascending again -- into the low images the weight gradient read last.  DX_BWD_ORDER:
+// bit 0 conv2 wgrad, 1 conv2 dgrad, 2 conv1 wgrad, 3 conv1 dgrad, 4 conv0 wgrad descending (default 21 = 1 + 4 + 16).
+bool bwd_descending(int stage);
 bool wgrad_direct_supported(int IH, int IW, int IC, int OH, int OW, int OC, int KH, int KW, int S);
 int launch_wgrad_direct(const WgradDirectArgs &a, int stage, int nwg, hipStream_t stream);
 int wgrad_direct_workgroups(int stage, long long batch);  // persistent workgroups that fill the chip for this layer
@@ -174,7 +181,8 @@ int wgrad_direct_workgroups(int stage, long long batch);  // persistent workgrou
 bool dgrad_b6_on();
 long long dgrad_b6_pack_elems(int layer);
 int launch_dgrad_b6_pack(const float *const c1d[4], const float *c2d, uint16_t *Wf1, uint16_t *Wf2, hipStream_t stream);
-int launch_dgrad_b6(int layer, const float *g, const uint16_t *Wf, const float *mask_src, float *out, int B, hipStream_t stream);
+int launch_dgrad_b6(int layer, const float *g, const uint16_t *Wf, const float *mask_src, float *out, int B, hipStream_t stream,
+                    bool descending = false);
 bool wgrad_b6_on();
 int launch_wgrad_b6(const WgradDirectArgs &a, int stage, int nwg, hipStream_t stream);
 

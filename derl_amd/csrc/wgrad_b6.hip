@@ -113,7 +113,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_b6_kernel(const WgradDirectArg
     gdst[u] = Y::oG + (v / 16) * kPG + 8 * (v % 16);
   }
   f32x4 xr[Y::XR], gr[Y::GR];
-  auto fetch = [&](int img) {
+  auto fetch = [&](int slot) {  // slot = blockIdx.x + t gridDim.x; the image: from the last one down when `descending`
+    const int img = a.descending ? a.B - 1 - slot : slot;
     const f32x4 *xs = reinterpret_cast<const f32x4 *>(a.x) + static_cast<long long>(img) * Y::NX4;
     const f32x4 *gs = reinterpret_cast<const f32x4 *>(a.g) + static_cast<long long>(img) * Y::NG4;
 #pragma unroll
