@@ -11,6 +11,7 @@
 //             in SURVEY.md Appendix A.1-A.5)
 // Diagonal-Gaussian head for the MLP policy: thread per row (derl/policies.py:40-42,66).
 #include "heads_dev.hpp"
+#include <type_traits>
 #include "synth_dev.hpp"
 
 namespace {
@@ -951,6 +952,27 @@ struct TailBwdOut {
   int Jp;
 };
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+// a (kept by the wave's lanes 0 .. 31) and b (kept by lanes 32 .. 63), each summed over the lane pairs (l, l + 32).
+// Inline asm on purpose: with a wave-uniform operand hipcc 7.2 folds __builtin_amdgcn_permlane32_swap's two results into
+// one register (v_permlane32_swap v3, v1; v_add v1, v3, v3 -- measured wrong sums, gpurun_out/tmp/meet_probe.hip).
+__device__ __forceinline__ float swap_sum32(float a, float b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));  // a = [a.lo | b.lo], b = [a.hi | b.hi]
+  return a + b;
+}
+// a (kept by the even 16-lane rows) and b (kept by the odd rows), each summed over the row pairs (0, 1) and (2, 3)
+__device__ __forceinline__ float swap_sum16(float a, float b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));  // a = rows [a0 b0 a2 b2], b = rows [a1 b1 a3 b3]
+  return a + b;
+}
+// the sum over each 16-lane row, in every lane of the row
+__device__ __forceinline__ float row_sum_all(float v) {
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  return dpp_add<0x140, 0xf>(v);  // row_mirror
+}
+
 template <int NJ>
 __global__ __launch_bounds__(kFbThreads) void tail_loss_bwd_kernel(const TailLossArgs a, const TailBwdOut o) {
   __shared__ float red[kFbWaves][kFbRows * 8];
@@ -960,16 +982,34 @@ __global__ __launch_bounds__(kFbThreads) void tail_loss_bwd_kernel(const TailLos
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 31;
   const int A = a.A;
   const LossParams lparams{a.A, a.mode, a.stats != nullptr, a.cliprange, a.value_loss_coef, a.entropy_coef, a.inv_batch};
-  float wc[NJ][kFbCols], g[NJ][kFbCols], sacc[NJ];
+  // Up to six outputs: in PAIRS (2 jp, 2 jp + 1) -- one v_pk_fma_f32 multiplies a y2 element by both rows' weights (and, in
+  // the backward half, adds both rows' dL/dout x y2 to G): the fp32 vector peak needs the packed form; every element's own
+  // fma chain is the one the unpacked code forms.  An odd NJ carries a zero row.  Seven and eight outputs stay unpacked
+  // (the aligned register pairs spill there).
+  constexpr bool PACK = NJ <= 6;
+  constexpr int NP = (NJ + 1) / 2, NR = PACK ? NP : NJ;  // register rows of wc / g
+  using Row = std::conditional_t<PACK, f32x2, float>;
+  Row wc[NR][kFbCols], g[NR][kFbCols];
+  float sacc[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    sacc[j] = 0.f;
+  for (int j = 0; j < NJ; ++j) sacc[j] = 0.f;
+#pragma unroll
+  for (int jr = 0; jr < NR; ++jr)
 #pragma unroll
     for (int i = 0; i < kFbCols; ++i) {
-      wc[j][i] = a.Wc[j * kTailK + t + kFbThreads * i];
-      g[j][i] = 0.f;
+      if constexpr (PACK) {
+        wc[jr][i].x = a.Wc[(2 * jr) * kTailK + t + kFbThreads * i];
+        wc[jr][i].y = 2 * jr + 1 < NJ ? a.Wc[(2 * jr + 1) * kTailK + t + kFbThreads * i] : 0.f;
+        g[jr][i] = f32x2{0.f, 0.f};
+      } else {
+        wc[jr][i] = a.Wc[jr * kTailK + t + kFbThreads * i];
+        g[jr][i] = 0.f;
+      }
     }
-  }
+  auto w_of = [&](int j, int i) -> float {
+    if constexpr (PACK) return j & 1 ? wc[j >> 1][i].y : wc[j >> 1][i].x;
+    else return wc[j][i];
+  };
   const float bias_col = col <= A ? a.beff[col] : 0.f;
   float meanf = 0.f, denom = 1.f;
   if (a.stats) {  // adv_apply_kernel's expression
@@ -1007,18 +1047,43 @@ __global__ __launch_bounds__(kFbThreads) void tail_loss_bwd_kernel(const TailLos
     p_act = n_act; p_adv = n_adv; p_vt = n_vt; p_olp = n_olp; p_ov = n_ov;
     if (r + kFbRows < r1) fetch(r + kFbRows);
     // ---- the four rows' outputs: per-thread partial dots, wave sums, seven waves through LDS ----
+    // The 4 x NJ partial dots of a lane, summed over the wave TRANSPOSED: rows (u, u + 2) meet across the wave's halves
+    // (v_permlane32_swap: one swap + one add per pair), rows (0, 1) / (2, 3) across the 16-lane rows (v_permlane16_swap), then
+    // four DPP steps inside a row -- row u of the wave ends with output j's total in every lane: 10 NJ instructions where 4 NJ
+    // whole-wave sums took 28 NJ.
     float mine = 0.f;
+    auto meet = [&](int j, float p0, float p1, float p2, float p3) {  // output j's four row sums -> row u of the wave
+      const float tot = row_sum_all(swap_sum16(swap_sum32(p0, p2), swap_sum32(p1, p3)));
+      mine = (lane & 15) == j ? tot : mine;
+    };
+    if constexpr (PACK) {
 #pragma unroll
-    for (int u = 0; u < kFbRows; ++u)
+      for (int jp = 0; jp < NP; ++jp) {
+        f32x2 part[kFbRows];
+#pragma unroll
+        for (int u = 0; u < kFbRows; ++u) {
+          f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < kFbCols; ++i) acc2 = __builtin_elementwise_fma(f32x2{y[u][i], y[u][i]}, wc[jp][i], acc2);
+          part[u] = acc2;
+        }
+        meet(2 * jp, part[0].x, part[1].x, part[2].x, part[3].x);
+        if (2 * jp + 1 < NJ) meet(2 * jp + 1, part[0].y, part[1].y, part[2].y, part[3].y);
+      }
+    } else {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        float part = 0.f;
+        float part[kFbRows];
 #pragma unroll
-        for (int i = 0; i < kFbCols; ++i) part = fmaf(y[u][i], wc[j][i], part);
-        const float tot = wave_sum_all(part);
-        mine = lane == u * 8 + j ? tot : mine;
+        for (int u = 0; u < kFbRows; ++u) {
+          part[u] = 0.f;
+#pragma unroll
+          for (int i = 0; i < kFbCols; ++i) part[u] = fmaf(y[u][i], wc[j][i], part[u]);
+        }
+        meet(j, part[0], part[1], part[2], part[3]);
       }
-    if (lane < kFbRows * 8) red[wave][lane] = mine;
+    }
+    if ((lane & 15) < 8) red[wave][(lane >> 4) * 8 + (lane & 15)] = mine;
     __syncthreads();
     if (wave < kFbRows) {  // one row per wave, lane = column (both halves hold the same row)
       const int u = wave;
@@ -1056,9 +1121,14 @@ __global__ __launch_bounds__(kFbThreads) void tail_loss_bwd_kernel(const TailLos
       for (int i = 0; i < kFbCols; ++i) {
         float dsum = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          dsum = fmaf(d[j], wc[j][i], dsum);
-          g[j][i] = fmaf(d[j], y[u][i], g[j][i]);
+        for (int j = 0; j < NJ; ++j) dsum = fmaf(d[j], w_of(j, i), dsum);
+        if constexpr (PACK) {
+#pragma unroll
+          for (int jp = 0; jp < NP; ++jp)
+            g[jp][i] = __builtin_elementwise_fma(f32x2{d[2 * jp], 2 * jp + 1 < NJ ? d[2 * jp + 1] : 0.f}, f32x2{y[u][i], y[u][i]}, g[jp][i]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) g[j][i] = fmaf(d[j], y[u][i], g[j][i]);
         }
         out[kFbThreads * i] = y[u][i] > 0.f ? dsum : 0.f;
       }
@@ -1072,7 +1142,10 @@ __global__ __launch_bounds__(kFbThreads) void tail_loss_bwd_kernel(const TailLos
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int i = 0; i < kFbCols; ++i) slab[j * kTailK + t + kFbThreads * i] = g[j][i];
+    for (int i = 0; i < kFbCols; ++i) {
+        if constexpr (PACK) slab[j * kTailK + t + kFbThreads * i] = j & 1 ? g[j >> 1][i].y : g[j >> 1][i].x;
+        else slab[j * kTailK + t + kFbThreads * i] = g[j][i];
+      }
   if (t == 0) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) o.sslab[blockIdx.x * o.Jp + j] = sacc[j];
