@@ -64,9 +64,16 @@ def executed_flops(name, route, batch, num_actions):
   return fl, PEAK_F32_MFMA_TFLOPS, "fp32 MFMA" if fl else ""
 
 
-PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
-POWER_FILE = os.path.join("profiles", "r05_power.json")        # tools/power_probe.py over every stage + the rollout launch
-MFMA_POWER_FILE = os.path.join("profiles", "r05_mfma_power.txt")  # tools/ubench/mfma_power: bare matrix-instruction loops
+def _latest(name):
+  """profiles/<round>_<name> of the latest round that has one (the counters cannot be read from inside this process)."""
+  import glob
+  found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + name)))
+  return os.path.relpath(found[-1], ROOT) if found else os.path.join("profiles", "r06_" + name)
+
+
+PMC_FILE = _latest("pmc_traffic.json")
+POWER_FILE = _latest("power.json")        # tools/power_probe.py over every stage + the rollout launch
+MFMA_POWER_FILE = _latest("mfma_power.txt")  # tools/ubench/mfma_power: bare matrix-instruction loops
 
 
 def power_evidence(stage):

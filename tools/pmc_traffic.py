@@ -22,7 +22,8 @@ STAGE_OF = [  # substring of the kernel name -> stage
     ("conv_wgrad_direct_kernel<9,", "conv2_wgrad"), ("igemm_tn_kernel<9,", "conv2_wgrad"),
     ("igemm_nt_pix_kernel<10,", "conv2_dgrad"), ("conv_wgrad_direct_kernel<11,", "conv1_wgrad"),
     ("igemm_tn_kernel<11,", "conv1_wgrad"), ("igemm_nt_pix_kernel<12,", "conv1_dgrad"),
-    ("conv0_wgrad_b16", "conv0_wgrad"), ("finalize_fused_kernel", "finalize"), ("permute_reduce_kernel", "finalize"),
+    ("conv0_wgrad_b16", "conv0_wgrad"), ("conv0_wgrad_ks", "conv0_wgrad"),  # round 6: the K-split kernel (conv0_wgrad_ks.hip)
+    ("finalize_fused_kernel", "finalize"), ("permute_reduce_kernel", "finalize"),
     ("permute_reduce_greduce_kernel", "finalize_with_tail_greduce"),  # round 5: the training loop's merged slab reduction
     ("fc_row_unpermute_reduce", "finalize_fc"),
     # the factored tail (csrc/tail.hip, heads.hip) and the rollout's one-kernel step (csrc/convstack.hip)

@@ -62,13 +62,14 @@ def sample():
       low = key.lower()
       if "power" in low and "(w)" in low:
         row["power_w"] = float(val)
-      elif low.startswith("sclk"):
+      elif low.startswith("sclk"):  # "sclk clock speed:": "(1915Mhz)"; "sclk clock level:": "1" (no MHz: must not overwrite)
         m = re.search(r"(\d+)\s*mhz", str(val).lower())
-        row["sclk_mhz"] = int(m.group(1)) if m else val
+        if m:
+          row["sclk_mhz"] = int(m.group(1))
       elif "junction" in low or "hotspot" in low:
         row["temp_c"] = float(val)
     samples.append(row)
-    time.sleep(0.25)
+    time.sleep(0.05)
 
 
 def mean(key, rows):
