@@ -96,4 +96,4 @@ if os.path.exists(rows_path):
                                     "kernel (tools/sustained_clock.py, diag flavour)", "rows": clocks}
   with open(os.path.join(P, TAG + "_power.json"), "w") as f:
     json.dump(doc, f, indent=1)
-  print("wrote profiles/r05_power.json")
+  print("wrote profiles/" + TAG + "_power.json")
