@@ -101,10 +101,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_b6_kernel(const WgradDirectArg
   }
 
   // ---- this lane's share of an image's rows: float4 pieces tid + 512 u; LDS byte offsets in plane 0 ----
+  // conv1's 32-channel image: a pixel is 8 lanes x 8 bytes and the 80-byte pixel pitch (conflict-free for the transposed
+  // reads at stride 2) puts two CONSECUTIVE pixels of a 16-lane write group 16 bytes into each other mod 128 (16 % of the
+  // kernel's LDS cycles were bank conflicts, round-6 counters).  Pixels 4 apart sit 320 = 64 (mod 128) bytes apart: lane
+  // groups take the pieces with pixel bits 0 and 2 exchanged (the same 64-piece block of the image: the loads stay coalesced).
+  const bool exchange = L == 1 && !(kDiag && (a.diag & 4));  // (diag flavour, DX_WB6_DIAG=4: the plain order, an A/B switch)
+  auto piece_of = [&](int v) { return exchange ? ((v & ~0x28) | ((v & 0x08) << 2) | ((v & 0x20) >> 2)) : v; };
+  static_assert(L != 1 || Y::NX4 % 64 == 0, "the exchange stays inside whole 64-piece blocks");
   int xdst[Y::XR], gdst[Y::GR];
 #pragma unroll
   for (int u = 0; u < Y::XR; ++u) {
-    const int v = min(tid + 512 * u, Y::NX4 - 1), pix = v / (G::IC / 4), c4 = v % (G::IC / 4);
+    const int v = piece_of(min(tid + 512 * u, Y::NX4 - 1)), pix = v / (G::IC / 4), c4 = v % (G::IC / 4);
     xdst[u] = Y::oX + (pix / G::IW) * G::RP + (pix % G::IW) * G::PX + 8 * c4;
   }
 #pragma unroll
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_b6_kernel(const WgradDirectArg
 #pragma unroll
     for (int u = 0; u < Y::GR; ++u) gr[u] = gs[min(tid + 512 * u, Y::NG4 - 1)];
 #pragma unroll
-    for (int u = 0; u < Y::XR; ++u) xr[u] = xs[min(tid + 512 * u, Y::NX4 - 1)];
+    for (int u = 0; u < Y::XR; ++u) xr[u] = xs[piece_of(min(tid + 512 * u, Y::NX4 - 1))];
   };
 
   // ---- operand addresses (bytes): lane (g, q, p4) reads row 4 r + q of its group's block, columns 4 p4 .. ----
@@ -259,7 +266,11 @@ bool wgrad_b6_on() {
 }
 
 // conv1 (stage ST_CONV1_WGRAD) / conv2 weight gradient of an 84 x 84 observation's conv stack; nwg <= one per CU
-int launch_wgrad_b6(const WgradDirectArgs &a, int stage, int nwg, hipStream_t stream) {
+int launch_wgrad_b6(const WgradDirectArgs &a_in, int stage, int nwg, hipStream_t stream) {
+  WgradDirectArgs a = a_in;
+#if DX_DIAG
+  a.diag = DX_ENV("DX_WB6_DIAG", 0);
+#endif
   DX_REQUIRE(a.x && a.g && a.slab && a.bias_slab && a.B > 0 && nwg > 0 && nwg <= a.B, "wgrad_b6: bad arguments (B=%d, workgroups=%d)",
              a.B, nwg);
   DX_REQUIRE(aligned(a.x, 16) && aligned(a.g, 16), "wgrad_b6: activations must be 16-byte aligned");
