@@ -61,6 +61,12 @@ constexpr int kMaxMb = 64;
 constexpr unsigned kSpinLimit = 1u << 21;
 constexpr int kStampSlots = 16;  // A, barrier, B, barrier, C | A's stages: inputs, h1, h2, outputs, loss, three backward stages, slab
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+// v of lane l + v of lane l ^ 32, in both lanes (inline asm: hipcc 7.2 miscompiles the builtin with a uniform operand, heads.hip)
+__device__ __forceinline__ float both_halves_sum(float v) {
+  float w = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(w));  // v = [lo | lo], w = [hi | hi]
+  return v + w;
+}
 
 static_assert(kNetA % 4 == 0 && kTotalA % 4 == 0, "aligned layout in whole vec4");
 
@@ -502,15 +508,20 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
       __syncthreads();
       DX_SUBSTAMP(8)
       if (wave == 0) {  // ---- Gaussian PPO / A2C loss, one lane per row (heads.hip: normal_loss_kernel) ----
-        const int b = lane;
-        const bool row_ok = b < rows;
-        const int rb = b & (kR - 1);
+        // Both halves of the wave work on the tile's 32 rows: lanes 32 .. 63 take the odd action dimensions of row lane - 32
+        // (one lane per row walked all P dimensions twice -- 3.0 us of dependent LDS reads and divisions per update, round-5
+        // stamps); the two halves' partial log-probabilities / entropies meet through one v_permlane32_swap.
+        const int rb = lane & (kR - 1), dhalf = lane >> 5;
+        const bool row_ok = rb < rows;
+        const int b = dhalf == 0 ? rb : kR;  // (b < kR: the lane that writes its row's terms; rows past the tile get zeros)
         float lp = 0.f, ent = 0.f;
-        for (int d = 0; d < P; ++d) {
+        for (int d = dhalf; d < P; d += 2) {
           const float diff = act[rb * 32 + d] - heads[rb * kLd0 + d];
           lp += -(diff * diff) / (2.f * sig[32 + d]) - sig[64 + d] - kHalfLog2Pi;
           ent += 0.5f + kHalfLog2Pi + sig[64 + d];
         }
+        lp = both_halves_sum(lp);
+        ent = both_halves_sum(ent);
         const float v = heads[rb * kLd0 + P];
         const float adv = row_ok ? rowv[kR + rb] : 0.f;
         const float vt = row_ok ? rowv[3 * kR + rb] : 0.f;
@@ -548,16 +559,14 @@ __global__ __launch_bounds__(kT, 2) void mlp_persist_kernel(const PersistArgs a)
           vl = dd * dd;
           dv = a.vcoef * 2.f * dd * inv_batch;
         }
-        for (int d = 0; d < P; ++d) {  // dL/dmean_d = dlp (a - mu) / sigma^2 ; dL/dlogstd_d = sum_b dlp ((a - mu)^2 / sigma^2 - 1) - c_H
+        for (int d = dhalf; d < P; d += 2) {  // dL/dmean_d = dlp (a - mu) / sigma^2 ; dL/dlogstd_d = sum_b dlp ((a - mu)^2 / sigma^2 - 1) - c_H
           const float diff = act[rb * 32 + d] - heads[rb * kLd0 + d];
           const float var = sig[32 + d];
           const float g = dlp * diff / var;
           double dls = 0.0;
           if (row_ok) dls = static_cast<double>(dlp) * (diff * diff / var - 1.f) - a.ecoef * inv_batch;
-          if (b < kR) {
-            ds[rb * kLd0 + d] = row_ok ? g : 0.f;
-            lred[(8 + d) * kR + rb] = dls;
-          }
+          ds[rb * kLd0 + d] = row_ok ? g : 0.f;  // (each (row, dimension) has exactly one lane)
+          lred[(8 + d) * kR + rb] = dls;
         }
         if (b < kR) ds[kR * kLd0 + rb * kLd0] = row_ok ? dv : 0.f;  // the value net's single output
         double s[8] = {row_ok ? pl : 0.0, row_ok ? ent : 0.0, row_ok ? vl : 0.0, row_ok ? adv : 0.0,
