@@ -396,7 +396,9 @@ int dx_cnn_ppo_epoch(const dx_cnn_ctx *ctx, const dx_cnn_epoch *epoch, void *str
  * forward = 0..4, backward = 5..14. */
 /* Which kernel family the most recent launch of `stage` took in this process ("ntp" = the persistent
  * LDS-DMA ring, "wgrad_direct" / "wgrad_fc" = the image-resident / linear-layer weight gradients,
- * "conv0_b16", "igemm_lat", "igemm_pix", "igemm_nt", "igemm_tn", "nt_dma", ...; "" before any launch).
+ * "conv0_b16" / "conv0_ks" = the first layer's tile kernels / its K-split weight gradient, "wgrad_b6" / "dgrad_b6" /
+ * "convstack_train" = the bf16 x6 conv stages, "tail_factored", "igemm_lat", "igemm_pix", "igemm_nt", "igemm_tn",
+ * "nt_dma", ...; "" before any launch).
  * The routes depend on tile counts and divisibility by 128 images: tests pin BASELINE's minibatches
  * to the fast families, bench.py prints the route of every stage. */
 const char *dx_cnn_last_route(int stage);
