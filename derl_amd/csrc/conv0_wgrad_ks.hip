@@ -56,7 +56,7 @@ constexpr int kGPlane = (kPix + 1) * kGRow;    // row 400: zeros (K slots past t
 constexpr int oX = 0, oG = kXB, kEnd = oG + 3 * kGPlane;
 constexpr int kMaxImages = 4096;               // frames per workgroup: their gather entries sit in LDS behind the image
 constexpr int kNG4 = kPix * 32 / 4, kGR = (kNG4 + 511) / 512;      // float4 pieces of an image's gradient rows; per lane
-constexpr int kNX8 = kFrameB / 8, kXR = (kNX8 + 511) / 512;        // 8-byte pieces of a frame; per lane
+constexpr int kNX16 = kFrameB / 16, kXR = (kNX16 + 511) / 512;     // 16-byte pieces of a frame; per lane
 static_assert(kFrameB % 16 == 0 && oG % 64 == 0 && kGPlane % 64 == 0 && kEnd + 4 * kMaxImages <= 160 * 1024, "LDS layout");
 static_assert(4 * 32 * 256 * 4 <= kEnd, "the final reduction (four partial results) reuses the image's LDS");
 
@@ -164,13 +164,14 @@ __global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, 
 #define DX_KS_MARK(i) if (kDiag && stamps) { const unsigned long long now = __builtin_amdgcn_s_memtime(); ph[i] += now - tprev; tprev = now; }
 
   // ---- staging: piece tid + 512 u of the gradient rows (float4: pixel (tid >> 3) + 64 u, channels 4 (tid & 7) ..) and of
-  // the frame (8 bytes = 2 pixels -> 16 bytes of bf16: consecutive lanes write consecutive 16 bytes) ----
+  // the frame (16 bytes = 4 pixels -> two 16-byte stores of bf16.  8-byte pieces -- consecutive lanes then write
+  // consecutive 16 bytes, no 2-way conflict on the stores -- were measured 6 % SLOWER: 7 loads per lane instead of 4) ----
   const int gdst = oG + (tid >> 3) * kGRow + 32 * (((tid >> 2) & 1) ^ ((tid >> 5) & 1)) + 8 * (tid & 3);
-  const int xdst = oX + 16 * tid;
+  const int xdst = oX + 32 * tid;
   // an image's rows travel in registers while the previous image multiplies (the gradient rows TWO images ahead were
   // measured: no faster, 28 registers more)
   f32x4 ga[kGR];
-  uint2 xr[kXR];
+  u32x4 xr[kXR];
   auto fetch_g = [&](f32x4 (&gr)[kGR], int t) {
     if (kDiag && (variant & 2) && t != 0) return;
     const int img = img_of(t);
@@ -181,9 +182,9 @@ __global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, 
   auto fetch_x = [&](int t) {
     if (kDiag && (variant & 2) && t != 0) return;
     const int raw = raw_of(t);
-    const uint2 *xs = reinterpret_cast<const uint2 *>(a.obs + static_cast<long long>(raw) * kFrameB);
+    const u32x4 *xs = reinterpret_cast<const u32x4 *>(a.obs + static_cast<long long>(raw) * kFrameB);
 #pragma unroll
-    for (int u = 0; u < kXR; ++u) xr[u] = xs[min(tid + 512 * u, kNX8 - 1)];
+    for (int u = 0; u < kXR; ++u) xr[u] = xs[min(tid + 512 * u, kNX16 - 1)];
   };
 
   // ---- this wave's K steps and this lane's rows in them: K slot 8 g + 4 r + q holds pixel 32 s + 16 r + 4 g + q ----
@@ -217,10 +218,12 @@ __global__ __launch_bounds__(512) void conv0_wgrad_ks_kernel(const Conv0Args a, 
     if (!copies) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the loads are still waited for)
 #pragma unroll
     for (int u = 0; u < kXR; ++u)
-      if (copies && tid + 512 * u < kNX8) {
-        const uint2 w = xr[u];
-        *reinterpret_cast<u32x4 *>(smem + xdst + 16 * 512 * u) =
+      if (copies && tid + 512 * u < kNX16) {
+        const u32x4 w = xr[u];
+        *reinterpret_cast<u32x4 *>(smem + xdst + 32 * 512 * u) =
             u32x4{ks_bytes2(w.x, 0), ks_bytes2(w.x, 2), ks_bytes2(w.y, 0), ks_bytes2(w.y, 2)};
+        *reinterpret_cast<u32x4 *>(smem + xdst + 32 * 512 * u + 16) =
+            u32x4{ks_bytes2(w.z, 0), ks_bytes2(w.z, 2), ks_bytes2(w.w, 0), ks_bytes2(w.w, 2)};
       }
     if (t + 1 < nimg) fetch_x(t + 1);
 #pragma unroll
