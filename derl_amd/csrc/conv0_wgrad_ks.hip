@@ -112,7 +112,8 @@ __device__ __forceinline__ void ks_multiply(const uint8_t *smem, const KsRows &r
     return ks_frag(ks_tr(smem, rows.x0[s] + o), k < 24 ? ks_tr(smem, rows.x1[s] + o) : zero);
   };
   bf16x8 gf[2][3];
-  bf16x8 xf = xfrag(0);
+  bf16x8 xf[2];  // this tile's and the next tile's frame fragment, alternately
+  xf[0] = xfrag(0);
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const int s = k < 24 ? k / 8 : 3, jj = k < 24 ? k % 8 : k - 24, j = k < 24 ? jj : J0 + jj;  // (compile-time after unrolling)
@@ -123,13 +124,12 @@ __device__ __forceinline__ void ks_multiply(const uint8_t *smem, const KsRows &r
         for (int pl = 0; pl < 3; ++pl) gf[i][pl] = gfrag(s, i, pl);
       __builtin_amdgcn_sched_barrier(0);
     }
-    bf16x8 xn = xf;
-    if (k + 1 < NT) xn = xfrag(k + 1);
+    if (k + 1 < NT) xf[(k + 1) & 1] = xfrag(k + 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {  // planes smallest first
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i][2], xf, acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i][1], xf, acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i][0], xf, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i][2], xf[k & 1], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i][1], xf[k & 1], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i][0], xf[k & 1], acc[i][j], 0, 0, 0);
     }
     const int xreads = k + 1 < NT ? (k + 1 >= 24 ? 1 : 2) : 0;
     switch (xreads) {  // (compile-time)
@@ -138,7 +138,6 @@ __device__ __forceinline__ void ks_multiply(const uint8_t *smem, const KsRows &r
       default: ks_pin<2>(); break;
     }
     __builtin_amdgcn_sched_barrier(0);
-    xf = xn;
   }
 }
 
