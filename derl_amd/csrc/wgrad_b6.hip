@@ -248,6 +248,185 @@ __global__ __launch_bounds__(512) void conv_wgrad_b6_kernel(const WgradDirectArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv2's weight gradient with the contraction STREAMED over the workgroup's images (round 6).  An image has 49 output
+// pixels: as two K steps of 32 per image (above) 15 of the 64 slots multiply zeros -- executed / useful 1.31, at a stage
+// that runs at the package power limit.  Every lane supplies the address of ITS pixel to the transposed reads, so a K step
+// need not stop at an image: here the workgroup's images form ONE run of pixels f = 49 n + p (n = the workgroup's n-th
+// image), K step k covers f = 32 k .. 32 k + 31 whatever images those fall into, and LDS holds TWO images (slots n & 1:
+// 68 KB each; conv1's 143 KB image does not allow that).  A step runs as soon as its last pixel's image is in LDS
+// (1 or 2 steps per image: 49 / 32 = 1.53 on average instead of 2), the run's last step is padded with a zero gradient
+// row.  Same tiles per wave, same fragments, same six products; the lane's row addresses are formed per step (two
+// divisions by constants) instead of once per launch.
+// ---------------------------------------------------------------------------------------------------------------------
+struct B6Stream {
+  using G = B6Geom<2>;
+  static constexpr int OHW = 49, KK = 9 * 64;
+  // The workgroup's n-th image sits (n & 7) x 160 bytes into its slot's planes: a pixel is 160 bytes, the pitches make the
+  // bank phase advance by 5 x 32 bytes per pixel ALONG an image (tools/ubench/tr_pitch_search.py), and 49 pixels = 1 (mod 8)
+  // -- with that rotation the 8 consecutive pixels of the run a 32-lane half reads stay conflict-free across an image's
+  // end (without it 14 % of the reads were 2-way conflicted: the next image starts where pixel 48 sits, mod 256 bytes).
+  static constexpr int ROT = 7 * kPG, ZROW = OHW + 7;                      // rotation room; the zero gradient row
+  static constexpr int XPLANE = G::IH * G::RP + ROT, GPLANE = (ZROW + 1) * kPG;
+  static constexpr int oX = 0, oG = 3 * XPLANE, SLOT = (oG + 3 * GPLANE + 255) / 256 * 256, END = 2 * SLOT;
+  static constexpr int NX4 = G::IH * G::IW * G::IC / 4, NG4 = OHW * kOC / 4;
+  static constexpr int XR = (NX4 + 511) / 512, GR = (NG4 + 511) / 512;
+  static_assert(XPLANE % 16 == 0 && GPLANE % 16 == 0 && END <= 160 * 1024 && 512 * 16 <= END, "LDS layout");
+};
+
+__global__ __launch_bounds__(512) void conv2_wgrad_stream_kernel(const WgradDirectArgs a) {
+  using G = B6Geom<2>;
+  using Y = B6Stream;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nimg = (a.B - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+
+  if (tid < 60) {  // the zero gradient row of each slot's planes: 2 slots x 3 planes x 160 bytes
+    const int sl = tid / 30, rem = tid % 30;
+    *reinterpret_cast<u32x4 *>(smem + sl * Y::SLOT + Y::oG + (rem / 10) * Y::GPLANE + Y::ZROW * kPG + 16 * (rem % 10)) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  // ---- this lane's share of an image's rows: float4 pieces tid + 512 u; byte offsets in plane 0 of a slot ----
+  int xdst[Y::XR], gdst[Y::GR];
+#pragma unroll
+  for (int u = 0; u < Y::XR; ++u) {
+    const int v = min(tid + 512 * u, Y::NX4 - 1), pix = v / (G::IC / 4), c4 = v % (G::IC / 4);
+    xdst[u] = Y::oX + (pix / G::IW) * G::RP + (pix % G::IW) * G::PX + 8 * c4;
+  }
+#pragma unroll
+  for (int u = 0; u < Y::GR; ++u) {
+    const int v = min(tid + 512 * u, Y::NG4 - 1);
+    gdst[u] = Y::oG + (v / 16) * kPG + 8 * (v % 16);
+  }
+  f32x4 xr[Y::XR], gr[Y::GR];
+  auto fetch = [&](int n) {  // the workgroup's n-th image: from the last one down when `descending`
+    const int slot = static_cast<int>(blockIdx.x) + n * static_cast<int>(gridDim.x);
+    const int img = a.descending ? a.B - 1 - slot : slot;
+    const f32x4 *xs = reinterpret_cast<const f32x4 *>(a.x) + static_cast<long long>(img) * Y::NX4;
+    const f32x4 *gs = reinterpret_cast<const f32x4 *>(a.g) + static_cast<long long>(img) * Y::NG4;
+#pragma unroll
+    for (int u = 0; u < Y::GR; ++u) gr[u] = gs[min(tid + 512 * u, Y::NG4 - 1)];
+#pragma unroll
+    for (int u = 0; u < Y::XR; ++u) xr[u] = xs[min(tid + 512 * u, Y::NX4 - 1)];
+  };
+
+  const int g4 = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+  constexpr int OCT = G::OCT, CT = G::CT, CPT = G::IC / 16;
+  f32x4 acc[OCT][CT];
+#pragma unroll
+  for (int i = 0; i < OCT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const int oc_first = 2 * (wave & 1), ct_first = 9 * (wave >> 1);
+
+  // K step k of the run: the lane's two rows (K slots 4 r + q: pixel 32 k + 16 r + 4 g + q of the run), then the wave's
+  // tiles -- (column tile) units in order, the next unit's input fragment read behind this unit's first MFMAs
+  auto kstep = [&](int k) {
+    int grow[2], xrow[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int f = 32 * k + 16 * r + 4 * g4 + q, nf = f / Y::OHW;
+      const bool in = nf < nimg;  // (past the run: the zero gradient row x pixel 0 of the LAST image -- real, finite data;
+                                  // anything else of the slots may be pad bytes or never-written LDS, and NaN x 0 is NaN)
+      const int n = in ? nf : nimg - 1, p = in ? f - nf * Y::OHW : 0;
+      const int base = (n & 1) * Y::SLOT, rot = (n & 7) * kPG, py = p / G::OW, px = p - py * G::OW;
+      grow[r] = base + Y::oG + (in ? rot + p * kPG : Y::ZROW * kPG) + 8 * p4;
+      xrow[r] = base + Y::oX + rot + py * G::RP + px * G::PX + 8 * p4;
+    }
+    auto xoff = [&](int j) {
+      const int ct = ct_first + j, tap = ct / CPT, c0 = 16 * (ct % CPT);
+      return int2{xrow[0] + (tap / G::KW) * G::RP + (tap % G::KW) * G::PX + 2 * c0,
+                  xrow[1] + (tap / G::KW) * G::RP + (tap % G::KW) * G::PX + 2 * c0};
+    };
+    bf16x8 gf[OCT][3], xf[3];
+#pragma unroll
+    for (int i = 0; i < OCT; ++i) b6_read(smem, grow[0] + 32 * (oc_first + i), grow[1] + 32 * (oc_first + i), Y::GPLANE, gf[i]);
+    {
+      const int2 o = xoff(0);
+      b6_read(smem, o.x, o.y, Y::XPLANE, xf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      bf16x8 xfn[3];
+      const bool more = j + 1 < CT;  // (compile-time after unrolling)
+      if (more) {
+        const int2 o = xoff(j + 1);
+        b6_read(smem, o.x, o.y, Y::XPLANE, xfn);
+      }
+#pragma unroll
+      for (int i = 0; i < OCT; ++i) acc[i][j] = b6_mac(acc[i][j], gf[i], xf);
+      if (more) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * OCT - 6, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xf[pl] = xfn[pl];
+      }
+    }
+  };
+
+  fetch(0);
+  int k_done = 0;
+  for (int t = 0; t < nimg; ++t) {
+    __syncthreads();  // every wave is done with the steps run so far: none of them still reads image t - 2's slot
+    uint8_t *slot = smem + (t & 1) * Y::SLOT + (t & 7) * kPG;  // (the image's rotation inside its slot)
+#pragma unroll
+    for (int u = 0; u < Y::GR; ++u)
+      if (tid + 512 * u < Y::NG4) {
+        const Split4 s = split4(gr[u]);
+        *reinterpret_cast<uint2 *>(slot + gdst[u]) = s.hi;
+        *reinterpret_cast<uint2 *>(slot + gdst[u] + Y::GPLANE) = s.mid;
+        *reinterpret_cast<uint2 *>(slot + gdst[u] + 2 * Y::GPLANE) = s.lo;
+        bsum += gr[u];
+      }
+#pragma unroll
+    for (int u = 0; u < Y::XR; ++u)
+      if (tid + 512 * u < Y::NX4) {
+        const Split4 s = split4(xr[u]);
+        *reinterpret_cast<uint2 *>(slot + xdst[u]) = s.hi;
+        *reinterpret_cast<uint2 *>(slot + xdst[u] + Y::XPLANE) = s.mid;
+        *reinterpret_cast<uint2 *>(slot + xdst[u] + 2 * Y::XPLANE) = s.lo;
+      }
+    if (t + 1 < nimg) fetch(t + 1);
+    __syncthreads();
+    // the steps whose 32 pixels are all in LDS now (the last image: the padded last step too)
+    const int k_end = t + 1 < nimg ? (Y::OHW * (t + 1)) / 32 : (Y::OHW * nimg + 31) / 32;
+    for (int k = k_done; k < k_end; ++k) kstep(k);
+    k_done = k_end;
+  }
+
+  // ---- slab [oc][kh][kw][ic] and the bias row: as conv_wgrad_b6_kernel<2> ----
+  float *slab = a.slab + static_cast<long long>(blockIdx.x) * kOC * Y::KK;
+#pragma unroll
+  for (int i = 0; i < OCT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const int ct = ct_first + j, tap = ct / CPT, c0 = 16 * (ct % CPT);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        slab[(16 * (oc_first + i) + 4 * (lane >> 4) + r) * Y::KK + tap * G::IC + c0 + (lane & 15)] = acc[i][j][r];
+    }
+  __syncthreads();
+  reinterpret_cast<f32x4 *>(smem)[tid] = bsum;
+  __syncthreads();
+  if (tid < kOC) {
+    float s = 0.f;
+    for (int m = 0; m < 32; ++m) s += reinterpret_cast<const float *>(smem)[(16 * m + (tid >> 2)) * 4 + (tid & 3)];
+    a.bias_slab[static_cast<long long>(blockIdx.x) * kOC + tid] = s;
+  }
+}
+
+// DX_WGRAD_B6_STREAM=0: conv2's weight gradient image by image (two K steps per image, the second half empty)
+bool wgrad_b6_stream_on() { return DX_ENV("DX_WGRAD_B6_STREAM", 1) != 0; }
+
 template <int L>
 int launch_b6(const WgradDirectArgs &a, int nwg, hipStream_t stream) {
   constexpr int lds = B6Layout<L>::END;
@@ -279,6 +458,12 @@ int launch_wgrad_b6(const WgradDirectArgs &a_in, int stage, int nwg, hipStream_t
     return launch_b6<1>(a, nwg, stream);
   }
   DX_REQUIRE(stage == ST_CONV2_WGRAD && a.IH == 9 && a.IW == 9 && a.OH == 7 && a.OW == 7, "wgrad_b6: conv2 geometry");
+  if (wgrad_b6_stream_on()) {
+    DX_LDS_OPT_IN(conv2_wgrad_stream_kernel, B6Stream::END);
+    hipLaunchKernelGGL(conv2_wgrad_stream_kernel, dim3(nwg), dim3(512), B6Stream::END, stream, a);
+    DX_LAUNCH_CHECK();
+    return DX_OK;
+  }
   return launch_b6<2>(a, nwg, stream);
 }
 

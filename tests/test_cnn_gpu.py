@@ -728,7 +728,8 @@ SWITCH_SETTINGS = ["DX_CONV0_F32=1", "DX_DGRAD_PIX=0", "DX_TN_SWIZZLE=0", "DX_LA
                    "DX_BWD_OVERLAP=1 DX_FWD_LANES=1",            # side-stream routes at every batch size
                    "DX_BWD_OVERLAP=0 DX_C0_WAVES=4 DX_C0_GROUP4=0 DX_CONV0_KS=0",  # and their serial / round-2 twins
                    "DX_CONV0_KS=0",                              # the first layer's weight gradient on the 256-pixel-tile kernel
-                   "DX_BWD_ORDER=0", "DX_BWD_ORDER=10"]          # every backward stage ascending / the data gradients descending (default 21: the weight gradients)
+                   "DX_BWD_ORDER=0", "DX_BWD_ORDER=10",          # every backward stage ascending / the data gradients descending (default 21: the weight gradients)
+                   "DX_WGRAD_B6_STREAM=0"]                       # conv2's weight gradient image by image (two K steps each) instead of one run of pixels
 
 
 def test_diagnostic_switches_keep_parity():
