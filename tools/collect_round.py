@@ -59,7 +59,7 @@ def counters(prefix, passes):
   return {k: {c: v[1] / v[0] for c, v in cs.items()} for k, cs in acc.items()}
 
 
-KEEP = ("convstack", "conv_wgrad_b6", "conv_dgrad_b6", "conv0_wgrad_b16", "conv0_wgrad_ks", "tail_loss", "tail_bwd", "tail_grads", "tail_greduce")
+KEEP = ("convstack", "conv_wgrad_b6", "conv2_wgrad_stream", "conv_dgrad_b6", "conv0_wgrad_b16", "conv0_wgrad_ks", "tail_loss", "tail_bwd", "tail_grads", "tail_greduce")
 lines = ["# rocprofv3 --pmc passes (counters only, three groups, separate runs) at commit " + commit + ":",
          "#   bash tools/gpu_evidence.sh " + TAG + "   (tools/pmc_passes.sh <tag>sq 8192 ... over tools/stage_bench.py: the update's stages at minibatch 8192;",
          "#   tools/gpu_actpmc.sh <tag>actsq 256 ... over tools/act_bench.py: the rollout kernel, one act step of 256 envs)",

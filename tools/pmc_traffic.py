@@ -34,6 +34,7 @@ STAGE_OF = [  # substring of the kernel name -> stage
     ("convstack_image_kernel<true>", "conv_stack_fwd"), ("convstack_image_kernel<(bool)1>", "conv_stack_fwd"),
     ("convstack_train_kernel", "conv_stack_fwd"),  # round 5: the role-specialised training forward (convstack_train.hip)
     ("conv_wgrad_b6_kernel<1>", "conv1_wgrad"), ("conv_wgrad_b6_kernel<2>", "conv2_wgrad"),
+    ("conv2_wgrad_stream_kernel", "conv2_wgrad"),  # round 6: the pixel contraction streamed across images
     ("conv_dgrad_b6_kernel<1>", "conv1_dgrad"), ("conv_dgrad_b6_kernel<2>", "conv2_dgrad"),
 ]
 ROLLOUT_STEP = "rollout_step (convstack_roll_kernel, 256 images, one step)"
